@@ -1,0 +1,126 @@
+"""ctypes binding of include/cunvsm_amd.h (the stub a maintainer would write)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_SO = os.path.join(_HERE, "libcunvsm_amd.so")
+_HEADER = os.path.join(_ROOT, "include", "cunvsm_amd.h")
+
+TANH, HARD_TANH = 0, 1
+SGD, ADAGRAD, ADAM = 0, 1, 2
+ADAM_NONE, ADAM_SPARSE, ADAM_DENSE_UPDATE, ADAM_DENSE_UPDATE_DENSE_VARIANCE = 0, 1, 2, 3
+SAMPLER_HOST_MINSTD, SAMPLER_DEVICE = 0, 1
+
+STATUS = {0: "OK", 1: "INVALID_ARGUMENT", 2: "UNSUPPORTED", 3: "DEVICE", 4: "STATE", 5: "NO_DEVICE"}
+
+
+class NvsmError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("nvsm status %d (%s): %s" % (status, STATUS.get(status, "?"), message))
+        self.status = status
+
+
+class NvsmConfig(C.Structure):
+    _fields_ = [
+        ("num_words", C.c_int64), ("num_entities", C.c_int64),
+        ("word_repr_size", C.c_int32), ("entity_repr_size", C.c_int32),
+        ("batch_normalization", C.c_int32), ("nonlinearity", C.c_int32),
+        ("clip_sigmoid", C.c_int32), ("bias_negative_samples", C.c_int32),
+        ("l2_normalize_phrase_reprs", C.c_int32), ("l2_normalize_entity_reprs", C.c_int32),
+        ("window_size", C.c_int32), ("num_random_entities", C.c_int32),
+        ("regularization_lambda", C.c_float),
+        ("update_method", C.c_int32), ("adam_mode", C.c_int32), ("max_batch_size", C.c_int32),
+        ("device", C.c_int32), ("sampler", C.c_int32),
+        ("world_size", C.c_int32), ("rank", C.c_int32), ("sync_batch_norm", C.c_int32),
+        ("reserved", C.c_int32 * 5),
+    ]
+
+
+class NvsmBatch(C.Structure):
+    _fields_ = [
+        ("features", C.c_void_p), ("feature_weights", C.c_void_p), ("labels", C.c_void_p), ("weights", C.c_void_p),
+        ("num_instances", C.c_int64), ("on_device", C.c_int32),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False):
+    """Compiles the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"] + (["-B"] if force else []))
+    return _SO
+
+
+def abi_symbols():
+    """Every function the public header declares (used by the CPU-side ABI test)."""
+    with open(_HEADER) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nvsm_[a-z0-9_]+)\s*\(", src)) - {"nvsm_allreduce_fn"})
+
+
+_lib = None
+
+
+def lib():
+    """Loads libcunvsm_amd.so; fails loudly when the HIP extension is missing (no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(cunvsm_amd has no CPU fallback)" % _SO)
+    try:
+        # PyTorch ships its own libamdhip64 / librccl; load it first so one HIP runtime serves both.
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
+    vp, i64, cp = C.c_void_p, C.c_int64, C.c_char_p
+    P = C.POINTER
+    sig = {
+        "nvsm_last_error": (cp, []), "nvsm_version": (cp, []), "nvsm_device_count": (C.c_int, []),
+        "nvsm_config_default": (None, [P(NvsmConfig)]),
+        "nvsm_create": (C.c_int, [P(NvsmConfig), P(vp)]), "nvsm_destroy": (None, [vp]),
+        "nvsm_initialize": (C.c_int, [vp, C.c_uint64]),
+        "nvsm_rng_get_state": (C.c_int, [vp, P(C.c_uint64)]), "nvsm_rng_set_state": (C.c_int, [vp, C.c_uint64]),
+        "nvsm_param_size": (C.c_int, [vp, cp, P(i64)]),
+        "nvsm_get_param": (C.c_int, [vp, cp, vp, i64]), "nvsm_set_param": (C.c_int, [vp, cp, vp, i64]),
+        "nvsm_compute_cost": (C.c_int, [vp, P(NvsmBatch), vp]), "nvsm_compute_gradients": (C.c_int, [vp]),
+        "nvsm_update": (C.c_int, [vp, C.c_float, C.c_float]), "nvsm_get_cost": (C.c_int, [vp, P(C.c_float)]),
+        "nvsm_scaled_regularization_lambda": (C.c_float, [vp]),
+        "nvsm_step": (C.c_int, [vp, P(NvsmBatch), vp, C.c_float, P(C.c_float)]),
+        "nvsm_tensor_size": (C.c_int, [vp, cp, P(i64)]), "nvsm_get_tensor": (C.c_int, [vp, cp, vp, i64]),
+        "nvsm_set_stream": (C.c_int, [vp, vp]), "nvsm_synchronize": (C.c_int, [vp]),
+        "nvsm_comm_unique_id": (C.c_int, [vp]), "nvsm_comm_init": (C.c_int, [vp, vp]),
+        "nvsm_set_allreduce_callback": (C.c_int, [vp, ALLREDUCE_FN, vp]),
+        "nvsm_profile_enable": (C.c_int, [vp, C.c_int]), "nvsm_profile_reset": (C.c_int, [vp]),
+        "nvsm_profile_names": (C.c_int, [vp, vp, i64]),
+        "nvsm_profile_get": (C.c_int, [vp, cp, P(C.c_double), P(i64)]),
+        "nvsm_debug_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+        "nvsm_debug_gather_mean": (C.c_int, [i64, C.c_int, vp, vp, vp, C.c_int, i64, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        raise NvsmError(status, lib().nvsm_last_error().decode())
+
+
+def device_count():
+    return lib().nvsm_device_count()

@@ -1,0 +1,194 @@
+// extern "C" surface of libcunvsm_amd.so — see include/cunvsm_amd.h. No C++ exception and no abort
+// crosses this boundary: every entry point returns an nvsm_status and records nvsm_last_error().
+#include <cstring>
+#include <string>
+
+#include "model.h"
+
+namespace cunvsm {
+void rccl_unique_id(char id[128]);
+}
+
+using cunvsm::Error;
+using cunvsm::Model;
+
+static thread_local std::string g_last_error;
+
+struct nvsm_model {
+    Model impl;
+    explicit nvsm_model(const nvsm_config& c) : impl(c) {}
+};
+
+template <typename Fn>
+static int guarded(Fn&& fn) {
+    try {
+        fn();
+        return NVSM_OK;
+    } catch (const Error& e) {
+        g_last_error = e.what();
+        return e.status;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return NVSM_ERR_DEVICE;
+    } catch (...) {
+        g_last_error = "unknown error";
+        return NVSM_ERR_DEVICE;
+    }
+}
+
+#define NVSM_REQUIRE(ptr)                                          \
+    if (!(ptr)) {                                                  \
+        g_last_error = "null argument: " #ptr;                     \
+        return NVSM_ERR_INVALID_ARGUMENT;                          \
+    }
+
+extern "C" {
+
+const char* nvsm_last_error(void) { return g_last_error.c_str(); }
+const char* nvsm_version(void) { return "cunvsm_amd 0.1 (gfx950)"; }
+
+int nvsm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// Defaults of the reference CLI: cpp/main.cu:15-76 + the NVSM recipe of scripts/functions.sh:266,380-399.
+void nvsm_config_default(nvsm_config* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->word_repr_size = 300; c->entity_repr_size = 256;
+    c->batch_normalization = 1; c->nonlinearity = NVSM_HARD_TANH;
+    c->clip_sigmoid = 1; c->bias_negative_samples = 0;
+    c->window_size = 10; c->num_random_entities = 10;
+    c->regularization_lambda = 1e-2f;
+    c->update_method = NVSM_ADAM; c->adam_mode = NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE;
+    c->max_batch_size = 51200;
+    c->device = 0; c->sampler = NVSM_SAMPLER_HOST_MINSTD;
+    c->world_size = 1; c->rank = 0; c->sync_batch_norm = 1;
+}
+
+int nvsm_create(const nvsm_config* cfg, nvsm_model** out) {
+    NVSM_REQUIRE(cfg); NVSM_REQUIRE(out);
+    *out = nullptr;
+    return guarded([&] { *out = new nvsm_model(*cfg); });
+}
+
+void nvsm_destroy(nvsm_model* m) {
+    try { delete m; } catch (...) {}
+}
+
+int nvsm_initialize(nvsm_model* m, uint64_t seed) { NVSM_REQUIRE(m); return guarded([&] { m->impl.initialize(seed); }); }
+int nvsm_rng_get_state(nvsm_model* m, uint64_t* state) { NVSM_REQUIRE(m); NVSM_REQUIRE(state); return guarded([&] { *state = m->impl.rng_get_state(); }); }
+int nvsm_rng_set_state(nvsm_model* m, uint64_t state) { NVSM_REQUIRE(m); return guarded([&] { m->impl.rng_set_state(state); }); }
+
+int nvsm_param_size(nvsm_model* m, const char* name, int64_t* count) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(count);
+    return guarded([&] { *count = m->impl.param_size(name); });
+}
+int nvsm_get_param(nvsm_model* m, const char* name, float* dst, int64_t count) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(dst);
+    return guarded([&] { m->impl.get_param(name, dst, count); });
+}
+int nvsm_set_param(nvsm_model* m, const char* name, const float* src, int64_t count) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(src);
+    return guarded([&] { m->impl.set_param(name, src, count); });
+}
+
+int nvsm_compute_cost(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(batch);
+    return guarded([&] { m->impl.compute_cost(*batch, entity_ids); });
+}
+int nvsm_compute_gradients(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.compute_gradients(); }); }
+int nvsm_update(nvsm_model* m, float lr, float scaled_lambda) { NVSM_REQUIRE(m); return guarded([&] { m->impl.update(lr, scaled_lambda); }); }
+int nvsm_get_cost(nvsm_model* m, float* cost) { NVSM_REQUIRE(m); NVSM_REQUIRE(cost); return guarded([&] { *cost = m->impl.get_cost(); }); }
+float nvsm_scaled_regularization_lambda(nvsm_model* m) { return m ? m->impl.scaled_regularization_lambda() : 0.f; }
+int nvsm_step(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids, float lr, float* cost) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(batch);
+    return guarded([&] { m->impl.step(*batch, entity_ids, lr, cost); });
+}
+
+int nvsm_tensor_size(nvsm_model* m, const char* name, int64_t* count) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(count);
+    return guarded([&] { *count = m->impl.tensor_size(name); });
+}
+int nvsm_get_tensor(nvsm_model* m, const char* name, float* dst, int64_t count) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(dst);
+    return guarded([&] { m->impl.get_tensor(name, dst, count); });
+}
+
+int nvsm_set_stream(nvsm_model* m, void* s) { NVSM_REQUIRE(m); return guarded([&] { m->impl.set_stream(static_cast<hipStream_t>(s)); }); }
+int nvsm_synchronize(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.synchronize(); }); }
+
+int nvsm_comm_unique_id(char id[128]) { NVSM_REQUIRE(id); return guarded([&] { cunvsm::rccl_unique_id(id); }); }
+int nvsm_comm_init(nvsm_model* m, const char id[128]) { NVSM_REQUIRE(m); NVSM_REQUIRE(id); return guarded([&] { m->impl.comm_init(id); }); }
+int nvsm_set_allreduce_callback(nvsm_model* m, nvsm_allreduce_fn fn, void* user) {
+    NVSM_REQUIRE(m);
+    return guarded([&] { m->impl.set_allreduce_callback(fn, user); });
+}
+
+int nvsm_profile_enable(nvsm_model* m, int enable) { NVSM_REQUIRE(m); return guarded([&] { m->impl.synchronize(); m->impl.prof.enabled = enable != 0; }); }
+int nvsm_profile_reset(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.synchronize(); m->impl.prof.reset(); }); }
+int nvsm_profile_names(nvsm_model* m, char* buf, int64_t buf_bytes) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(buf);
+    return guarded([&] {
+        int64_t off = 0;
+        for (const std::string& n : m->impl.prof.names()) {
+            if (off + static_cast<int64_t>(n.size()) + 2 > buf_bytes) throw Error(NVSM_ERR_INVALID_ARGUMENT, "buffer too small");
+            std::memcpy(buf + off, n.c_str(), n.size() + 1);
+            off += n.size() + 1;
+        }
+        if (off + 1 > buf_bytes) throw Error(NVSM_ERR_INVALID_ARGUMENT, "buffer too small");
+        buf[off] = '\0';
+    });
+}
+int nvsm_profile_get(nvsm_model* m, const char* kernel, double* total_ms, int64_t* launches) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(kernel); NVSM_REQUIRE(total_ms); NVSM_REQUIRE(launches);
+    return guarded([&] {
+        if (!m->impl.prof.get(kernel, total_ms, launches)) throw Error(NVSM_ERR_INVALID_ARGUMENT, std::string("no such kernel: ") + kernel);
+    });
+}
+
+// ---- debug hooks (tests only) ----
+int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const float* hostB, float* hostC) {
+    NVSM_REQUIRE(hostA); NVSM_REQUIRE(hostB); NVSM_REQUIRE(hostC);
+    return guarded([&] {
+        const int al = (variant >> 1) & 1, bl = variant & 1;
+        const int split = variant >> 2;                       // variant bits: [split_k want << 2 | a_layout << 1 | b_layout]
+        cunvsm::DevBuf<float> A, B, C, P;
+        A.alloc(static_cast<size_t>(M) * K); B.alloc(static_cast<size_t>(K) * N); C.alloc(static_cast<size_t>(M) * N);
+        NVSM_HIP_CHECK(hipMemcpy(A.p, hostA, A.n * sizeof(float), hipMemcpyHostToDevice));
+        NVSM_HIP_CHECK(hipMemcpy(B.p, hostB, B.n * sizeof(float), hipMemcpyHostToDevice));
+        const int lda = al ? M : K, ldb = bl ? K : N;
+        if (split > 1) {
+            const int slabs = cunvsm::gemm_split_k_slabs(K, split);
+            P.alloc(static_cast<size_t>(slabs) * M * N);
+            cunvsm::launch_gemm(al, bl, A.p, B.p, P.p, M, N, K, lda, ldb, N, 1.f, nullptr, split, static_cast<size_t>(M) * N, nullptr);
+            cunvsm::launch_splitk_reduce(P.p, slabs, static_cast<size_t>(M) * N, C.p, static_cast<int64_t>(M) * N, nullptr);
+        } else {
+            cunvsm::launch_gemm(al, bl, A.p, B.p, C.p, M, N, K, lda, ldb, N, 1.f, nullptr, 1, 0, nullptr);
+        }
+        NVSM_HIP_CHECK(hipDeviceSynchronize());
+        NVSM_HIP_CHECK(hipMemcpy(hostC, C.p, C.n * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+int nvsm_debug_gather_mean(int64_t num_rows, int dim, const float* table, const int64_t* idx, const float* wts,
+                           int window, int64_t num_out, float* out) {
+    NVSM_REQUIRE(table); NVSM_REQUIRE(idx); NVSM_REQUIRE(out);
+    return guarded([&] {
+        cunvsm::DevBuf<float> T, W, O;
+        cunvsm::DevBuf<int64_t> I64;
+        cunvsm::DevBuf<int> I;
+        T.alloc(num_rows * dim); O.alloc(num_out * dim); I64.alloc(num_out * window); I.alloc(num_out * window);
+        NVSM_HIP_CHECK(hipMemcpy(T.p, table, T.n * sizeof(float), hipMemcpyHostToDevice));
+        NVSM_HIP_CHECK(hipMemcpy(I64.p, idx, I64.n * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (wts) { W.alloc(num_out * window); NVSM_HIP_CHECK(hipMemcpy(W.p, wts, W.n * sizeof(float), hipMemcpyHostToDevice)); }
+        cunvsm::launch_narrow_i64(I64.p, I.p, num_out * window, nullptr);
+        cunvsm::launch_gather_mean(T.p, dim, I.p, wts ? W.p : nullptr, window, num_out, O.p, nullptr);
+        NVSM_HIP_CHECK(hipDeviceSynchronize());
+        NVSM_HIP_CHECK(hipMemcpy(out, O.p, O.n * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

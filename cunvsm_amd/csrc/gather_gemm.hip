@@ -1,0 +1,335 @@
+// gfx950 kernels: embedding gather-mean, fp32 MFMA GEMM, split-K reduce, small utilities.
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace cunvsm {
+
+// =============================================================================================
+// gather-mean — replaces average_repr_kernel (cpp/params.cu:75-95), which runs one thread per
+// output element with `window` dependent loads. Here the (row, 16-byte chunk) space is flattened
+// so every lane issues independent, fully coalesced 16 B loads of consecutive chunks of one
+// embedding row (a 300-float row = 75 chunks; a wave covers parts of at most two rows).
+// out[b][t] = (Σ_j wt[b,j]·table[idx[b,j]][t]) / window     — divides by window even when weighted.
+// =============================================================================================
+template <int V>
+__global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restrict__ table, int dim,
+                                                          const int* __restrict__ idx,
+                                                          const float* __restrict__ wts, int window,
+                                                          uint32_t total, uint32_t nvec,
+                                                          float* __restrict__ out) {
+    const float fw = static_cast<float>(window);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        const uint32_t b = q / nvec;
+        const uint32_t c = (q - b * nvec) * V;
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+        const int* ip = idx + static_cast<size_t>(b) * window;
+        const float* wp = wts ? wts + static_cast<size_t>(b) * window : nullptr;
+        for (int j = 0; j < window; ++j) {
+            const size_t row = static_cast<size_t>(ip[j]);
+            const float wt = wp ? wp[j] : 1.f;
+            float x[V];
+            ldv<V>(table + row * dim + c, x);
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] += wt * x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = acc[i] / fw;
+        stv<V>(out + static_cast<size_t>(b) * dim + c, acc);
+    }
+}
+
+void launch_gather_mean(const float* table, int dim, const int* idx, const float* wts, int window,
+                        int64_t num_out, float* out, hipStream_t s) {
+    if (num_out <= 0) return;
+    if (dim % 4 == 0) {
+        const uint32_t nvec = dim / 4;
+        const uint32_t total = static_cast<uint32_t>(num_out * nvec);
+        hipLaunchKernelGGL(gather_mean_kernel<4>, dim3(stream_grid(total, 256)), dim3(256), 0, s,
+                           table, dim, idx, wts, window, total, nvec, out);
+    } else {
+        const uint32_t nvec = dim;
+        const uint32_t total = static_cast<uint32_t>(num_out * nvec);
+        hipLaunchKernelGGL(gather_mean_kernel<1>, dim3(stream_grid(total, 256)), dim3(256), 0, s,
+                           table, dim, idx, wts, window, total, nvec, out);
+    }
+}
+
+// =============================================================================================
+// fp32 GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 (exact f32, 157 TF/s peak on gfx950 — there
+// is no TF32/xf32 path on CDNA4). Replaces the three cuBLAS sgemm calls of the path.
+// Block = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 (2 x 2 MFMA tiles,
+// 64 accumulator VGPRs), K step 32 staged through LDS. Operand fragments: lane l feeds
+// A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; the LDS images are laid out so that both
+// fragment reads are bank-conflict-free ds_read_b32 (k-major image, or m-major image padded to 33).
+// =============================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K, lda, ldb, ldc;
+    int k_split_len;
+    size_t c_split_stride;
+    float alpha;
+    const float* bias_n;
+    int vec_a, vec_b;
+};
+
+template <int ALAY, int BLAY>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
+    constexpr int A_ELEMS = (ALAY == 0) ? BM * (BK + 1) : BK * BM;
+    constexpr int B_ELEMS = (BLAY == 0) ? BK * BN : BN * (BK + 1);
+    __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS + 8];
+    float* As = lds;
+    float* Bs = lds + ((A_ELEMS + 3) & ~3);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int l31 = lane & 31, lk = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * g.k_split_len;
+    const int kend = min(g.K, kbeg + g.k_split_len);
+    float* __restrict__ C = g.C + blockIdx.z * g.c_split_stride;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        // ---- stage A tile ----
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int f = tid + 256 * it;
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (ALAY == 0) {                     // A[M][K], k contiguous
+                const int row = f >> 3, kq = (f & 7) << 2;
+                const int gm = m0 + row, gk = k0 + kq;
+                if (gm < g.M) {
+                    const float* p = g.A + static_cast<size_t>(gm) * g.lda + gk;
+                    if (g.vec_a && gk + 3 < kend) {
+                        ldv<4>(p, x);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gk + j < kend) x[j] = p[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[row * (BK + 1) + kq + j] = x[j];
+            } else {                                       // A stored [K][M], m contiguous
+                const int kk = f >> 5, mq = (f & 31) << 2;
+                const int gk = k0 + kk, gm = m0 + mq;
+                if (gk < kend) {
+                    const float* p = g.A + static_cast<size_t>(gk) * g.lda + gm;
+                    if (g.vec_a && gm + 3 < g.M) {
+                        ldv<4>(p, x);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gm + j < g.M) x[j] = p[j];
+                    }
+                }
+                stv<4>(As + kk * BM + mq, x);
+            }
+        }
+        // ---- stage B tile ----
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int f = tid + 256 * it;
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (BLAY == 0) {                     // B[K][N], n contiguous
+                const int kk = f >> 5, nq = (f & 31) << 2;
+                const int gk = k0 + kk, gn = n0 + nq;
+                if (gk < kend) {
+                    const float* p = g.B + static_cast<size_t>(gk) * g.ldb + gn;
+                    if (g.vec_b && gn + 3 < g.N) {
+                        ldv<4>(p, x);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gn + j < g.N) x[j] = p[j];
+                    }
+                }
+                stv<4>(Bs + kk * BN + nq, x);
+            } else {                                       // B stored [N][K], k contiguous
+                const int row = f >> 3, kq = (f & 7) << 2;
+                const int gn = n0 + row, gk = k0 + kq;
+                if (gn < g.N) {
+                    const float* p = g.B + static_cast<size_t>(gn) * g.ldb + gk;
+                    if (g.vec_b && gk + 3 < kend) {
+                        ldv<4>(p, x);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gk + j < kend) x[j] = p[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[row * (BK + 1) + kq + j] = x[j];
+            }
+        }
+        __syncthreads();
+
+        // ---- 16 k-steps of 2; 4 MFMAs per step per wave ----
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int k = kk + lk;
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = wr * 64 + i * 32 + l31;
+                a[i] = (ALAY == 0) ? As[m * (BK + 1) + k] : As[k * BM + m];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = wc * 64 + j * 32 + l31;
+                b[j] = (BLAY == 0) ? Bs[k * BN + n] : Bs[n * (BK + 1) + k];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + l31;
+            if (col >= g.N) continue;
+            const float bias = g.bias_n ? g.bias_n[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < g.M) C[static_cast<size_t>(row) * g.ldc + col] = g.alpha * acc[i][j][r] + bias;
+            }
+        }
+}
+
+int gemm_split_k_slabs(int K, int want) {
+    if (want <= 1) return 1;
+    int len = (K + want - 1) / want;
+    len = ((len + BK - 1) / BK) * BK;
+    return (K + len - 1) / len;
+}
+
+void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
+                 int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
+                 hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.alpha = alpha; g.bias_n = bias_n; g.c_split_stride = c_split_stride;
+    int slabs = 1;
+    g.k_split_len = K;
+    if (split_k > 1) {
+        int len = (K + split_k - 1) / split_k;
+        len = ((len + BK - 1) / BK) * BK;
+        g.k_split_len = len;
+        slabs = (K + len - 1) / len;
+    }
+    if (g.k_split_len <= 0) g.k_split_len = BK;
+    g.vec_a = (lda % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
+    g.vec_b = (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
+    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, slabs);
+    dim3 block(256);
+    if (a_layout == 0 && b_layout == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 0>), grid, block, 0, s, g);
+    else if (a_layout == 0 && b_layout == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 1>), grid, block, 0, s, g);
+    else if (a_layout == 1 && b_layout == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 0>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 1>), grid, block, 0, s, g);
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int slabs, size_t stride,
+                                                            float* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < slabs; ++z) s += partial[z * stride + i];
+        out[i] = s;
+    }
+}
+
+void launch_splitk_reduce(const float* partial, int slabs, size_t stride, float* out, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, partial, slabs, stride, out, n);
+}
+
+// =============================================================================================
+// small utilities
+// =============================================================================================
+__global__ void narrow_i64_kernel(const int64_t* __restrict__ src, int* __restrict__ dst, int64_t n) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        dst[i] = static_cast<int>(src[i]);
+}
+void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(narrow_i64_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, src, dst, n);
+}
+
+__global__ void iota_kernel(int* __restrict__ dst, int64_t n) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        dst[i] = static_cast<int>(i);
+}
+void launch_iota(int* dst, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(iota_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, dst, n);
+}
+
+__global__ void fill_f32_kernel(float* __restrict__ dst, float v, int64_t n) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        dst[i] = v;
+}
+void launch_fill_f32(float* dst, float v, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(fill_f32_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, dst, v, n);
+}
+
+__global__ void scale_kernel(float* __restrict__ p, float sc, int64_t n) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        p[i] *= sc;
+}
+void launch_scale(float* p, float sc, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, p, sc, n);
+}
+
+// SplitMix64 finaliser as a counter-based generator; ids uniform over [0, num_entities) via 64-bit
+// multiply-high (bias < 2^-40). Same distribution as UniformLabelGenerator (cpp/labels.cu:4-22):
+// slot 0 = the positive label, slots 1..k uniform over ALL documents (may repeat / hit the positive).
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void sample_entities_kernel(const int64_t* __restrict__ labels, int64_t N, int R, uint64_t num_entities,
+                                       uint64_t seed, uint64_t step, int* __restrict__ ids) {
+    for (int64_t j = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; j < N;
+         j += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t b = j / R;
+        const int r = static_cast<int>(j - b * R);
+        if (r == 0) {
+            ids[j] = static_cast<int>(labels[b]);
+        } else {
+            const uint64_t h = splitmix64(splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + static_cast<uint64_t>(j));
+            ids[j] = static_cast<int>(__umul64hi(h, num_entities));
+        }
+    }
+}
+void launch_sample_entities(const int64_t* labels, int64_t B, int R, int64_t num_entities, uint64_t seed,
+                            uint64_t step, int* ids, hipStream_t s) {
+    const int64_t N = B * R;
+    if (N > 0)
+        hipLaunchKernelGGL(sample_entities_kernel, dim3(stream_grid(N, 256)), dim3(256), 0, s, labels, N, R,
+                           static_cast<uint64_t>(num_entities), seed, step, ids);
+}
+
+}  // namespace cunvsm

@@ -1,0 +1,146 @@
+// Launchers of the hand-written gfx950 kernels of the NVSM / LSE hot path. Host-callable; every
+// launcher enqueues on the given stream and returns immediately. See DESIGN.md for the data layout
+// and the per-kernel roofline; each kernel cites the reference code it replaces.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cunvsm {
+
+// ---- gather-mean (F3/F9; replaces average_repr_kernel, cpp/params.cu:75-95) ------------------
+void launch_gather_mean(const float* table, int dim, const int* idx, const float* wts, int window,
+                        int64_t num_out, float* out, hipStream_t s);
+
+// ---- fp32 MFMA GEMM (F5, B6, B7; replaces the cuBLAS calls at cpp/params.cu:417,528, objective.cu:453)
+// C[M][N] = alpha * A·B (+ bias[n]).  a_layout 0: A is [M][K] (lda); 1: A is stored [K][M] (lda).
+//                                      b_layout 0: B is [K][N] (ldb); 1: B is stored [N][K] (ldb).
+// split_k > 1: the K range is cut into split_k slabs, slab z writes C + z * c_split_stride (no bias/alpha fold
+// is lost: alpha applied per slab, bias must be null) and the caller reduces with launch_splitk_reduce.
+void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
+                 int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
+                 hipStream_t s);
+int gemm_split_k_slabs(int K, int want);   // actual number of slabs launch_gemm will use for `want`
+void launch_splitk_reduce(const float* partial, int slabs, size_t stride, float* out, int64_t n, hipStream_t s);
+
+// ---- batch normalisation (F6, B5; replaces cuDNN per-activation BN, cpp/cudnn_utils.cu:82-183) --
+void launch_bn_colstats(const float* x, int64_t rows, int dim, double* sums /*[2][dim]: Σx, Σx²*/, hipStream_t s);
+void launch_bn_finalize(const double* sums, int dim, double n_global, float eps, float* mean, float* inv_std, hipStream_t s);
+// dβ = Σdy, dγ = Σdy·x̂ (double sums [2][dim]) → floats + grad_bias
+void launch_bn_bwd_finalize(const double* sums, int dim, float* dbeta, float* dgamma, float* grad_bias, hipStream_t s);
+// dx = invσ·(dy − (dβ + x̂·dγ)/N), in place on dy
+void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* inv_std, const float* dbeta,
+                  const float* dgamma, double n_global, int64_t rows, int dim, hipStream_t s);
+void launch_colsum_finalize(const double* sums, int dim, float* out, hipStream_t s);   // no-BN grad_bias = Σdy
+
+// ---- negative sampling on device (F2; same distribution as cpp/labels.cu:4-22) ----------------
+void launch_sample_entities(const int64_t* labels, int64_t B, int R, int64_t num_entities, uint64_t seed,
+                            uint64_t step, int* ids, hipStream_t s);
+void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, hipStream_t s);
+void launch_iota(int* dst, int64_t n, hipStream_t s);
+void launch_fill_f32(float* dst, float v, int64_t n, hipStream_t s);
+
+// ---- fused loss forward + backward (F7–F16, B1–B4; replaces cpp/objective.cu:159-305,354-425 and the
+// nonlinearity at cpp/params.cu:430-446,474-491) ------------------------------------------------
+struct LossArgs {
+    const float* pre;         // [B][de]  T·x (+b when !bn)
+    const float* bn_mean;     // [de] (bn)
+    const float* bn_inv_std;  // [de] (bn)
+    const float* bias;        // [de] (bn: β)
+    const float* E;           // [nD][de]
+    const int* ids;           // [B*R]
+    const float* inst_w;      // [B] or null
+    float* proj;              // [B][de]  act(BN(pre))
+    float* dy;                // [B][de]  d/d(BN output) = gproj · act'
+    float* coef;              // [B*R]   ±m_j  (signed multipliers)
+    float* probs;             // [B*R]
+    float* pp;                // [B]     mean_t(proj²)
+    double* loss_acc;         // [1]     Σ ω·log p
+    double* colstats;         // [2][de] Σdy, Σdy·x̂ (x̂ only when bn)
+    int64_t B;
+    int de, R, k;
+    int bn, nonlinearity, rebalance;
+    float sig_eps, sig_hi, d_eps;
+    double d_hi;              // 1 − d_eps compared in double (include/cuNVSM/cuda_utils.h:230)
+    float inv_batch;          // exp(−log(B_global))
+    float neg_scale;          // (k+1)/(2k)
+    float clip_min, clip_max; // nextafter-widened hard_tanh bounds
+    float inv_de;             // exp(−log(de))
+};
+void launch_loss(const LossArgs& a, hipStream_t s);
+
+// per-row mean of squares: out[b] = Σ_t G[b][t]² · inv_dim  (cpp/updates_adam.cu:232-240)
+void launch_row_meansq(const float* G, int64_t rows, int dim, float inv_dim, float* out, hipStream_t s);
+// grad_entity[j][t] = coef[j] · proj[j/R][t]  (tests / gradient checker only)
+void launch_materialize_grad_entity(const float* coef, const float* proj, int64_t N, int R, int de, float* out, hipStream_t s);
+
+// ---- batch → CSR by table row (replaces the atomic scatter of update_repr_kernel, cpp/storage.cu:37-49)
+size_t sort_pairs_temp_bytes(int64_t n, int bits);
+void sort_pairs(void* temp, size_t temp_bytes, const int* keys_in, int* keys_out, const int* vals_in, int* vals_out,
+                int64_t n, int bits, hipStream_t s);
+struct Csr {
+    int* sorted_key;      // [n]
+    int* sorted_entry;    // [n]  entry ids ordered by row (stable)
+    int* row_begin;       // [rows]
+    int* row_end;         // [rows]
+    int* chunk_base;      // [rows]  first chunk of a long row
+    int* chunk_desc;      // [max_chunks][3] row, begin, end
+    int* num_chunks;      // [1]
+    float* partial;       // [max_chunks][dim]
+    float* partial_q;     // [max_chunks]
+    int64_t n;            // entries
+    int64_t rows;
+    int max_chunks;
+};
+constexpr int kChunk = 128;   // entries per chunk of a long row
+void launch_csr_build(const Csr& c, hipStream_t s);   // bounds + long-row chunk list, from sorted_key
+
+// ---- row passes: gather Σ coef·X[src] per table row, then the optimiser's row-local formula --------
+enum RowKind {
+    ROW_SGD = 0,               // P = P·decay + lr·g                         (cpp/storage.cu:51-102)
+    ROW_ADAGRAD_ENT = 1,       // a += q; P = P·decay + lr·g/sqrt(a+ε)       (cpp/updates_adagrad.cu:99-179, window 1)
+    ROW_ADAM_MV = 2,           // m = β1 m + (1−β1) g; v = β2 v + (1−β2) q   (cpp/updates_adam.cu:196-252)
+    ROW_ADAM_SPARSE_ENT = 3,   // ROW_ADAM_MV then P = P·decay + lr·cnt·bc·m/(√v+ε)   (:332-384, window 1)
+    ROW_ADAM_DENSE = 4,        // ROW_ADAM_MV then P = P·decay + lr·bc·m/(√v+ε)       (:293-311)
+    ROW_ADAM_FULL = 5,         // m,v with L2 folded in, v per element; P += lr·bc·m/(√v+ε)  (:203-213,253-282,312-328)
+    ROW_SCALAR_ACC = 6         // a += q only (Adagrad, window > 1)           (cpp/updates_adagrad.cu:136-158)
+};
+struct RowPassArgs {
+    int table;                 // 0 = words (entry e: src = e / div, coef = wts[e]), 1 = entities (src = j / div, coef = coefs[j])
+    int kind;
+    const float* X;            // [num_src][dim]   gradient source rows
+    const float* wts;          // words: per-entry weights or null
+    const float* coefs;        // entities: signed multipliers
+    const float* sq_src;       // words: msq[src]; entities: pp[src]
+    const float* src_scale;    // optional per-src scale (Adagrad, window > 1)
+    uint32_t div;              // window (words) or R (entities)
+    float* P; float* m; float* v;   // table, first moment [rows][dim], per-element second moment (ROW_ADAM_FULL only)
+    const float* sc_in;        // per-row scalar state in  (Adam v / Adagrad a, [rows]); ping-pong with sc_out because
+    float* sc_out;             //   every lane of a row's thread group reads the old value
+    int dim;
+    float lr, decay, lambda;
+    float one_m_b1, s_m, one_m_b2, s_v, bc, eps, c_reg;
+    int dense;                 // visit rows without entries (decay / dense Adam)
+};
+void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
+void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
+
+// words, window > 1 (cpp/updates_adagrad.cu:83-97, cpp/updates_adam.cu:132-151)
+void launch_adagrad_scale(const float* acc, const int* idx, int window, int64_t B, float eps, float* scale, hipStream_t s);
+void launch_adam_u(const float* m, const float* v, int dim, const int* idx, int window, int64_t B, float bc, float eps,
+                   float* U, hipStream_t s);
+
+// ---- dense projection optimiser (U4; cpp/updates.cu:24-34, updates_adagrad.cu:33-70, updates_adam.cu:46-105)
+struct TransformUpdateArgs {
+    float* T; float* b;              // parameters (nT = de*dw, nb = de)
+    float* gT; float* gb;            // gradients (overwritten with the applied direction, as the reference does)
+    float* s0T; float* s0b; float* s1T; float* s1b;
+    int nT, nb, method;
+    float lr, lambda, eps, one_m_b1, s_m, one_m_b2, s_v, bc;
+};
+void launch_transform_update(const TransformUpdateArgs& a, hipStream_t s);
+
+// scale (dense decay) — table *= s   (cpp/storage.cu:65-67), used when a table has no entries at all
+void launch_scale(float* p, float s, int64_t n, hipStream_t s_);
+
+}  // namespace cunvsm

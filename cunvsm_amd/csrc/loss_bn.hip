@@ -1,0 +1,335 @@
+// gfx950 kernels: batch-norm statistics / backward, and the fused loss forward+backward.
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace cunvsm {
+
+// =============================================================================================
+// Batch normalisation, per-activation, γ ≡ 1, β = projection bias, batch statistics only
+// (replaces cudnnBatchNormalizationForwardTraining/Backward, cpp/cudnn_utils.cu:107-124,158-177).
+// Column sums are accumulated in fp32 over a 128-row slab per block and merged with native fp64
+// atomics, so var = E[x²] − E[x]² is formed in double.
+// =============================================================================================
+constexpr int kStatRows = 128;
+
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, int64_t rows, int dim,
+                                                          double* __restrict__ sums) {
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kStatRows;
+    const int64_t r1 = min(rows, r0 + kStatRows);
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        float s = 0.f, s2 = 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            const float v = x[r * dim + c];
+            s += v;
+            s2 += v * v;
+        }
+        atomic_add_f64(sums + c, static_cast<double>(s));
+        atomic_add_f64(sums + dim + c, static_cast<double>(s2));
+    }
+}
+
+void launch_bn_colstats(const float* x, int64_t rows, int dim, double* sums, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(bn_colstats_kernel, dim3(ceil_div(rows, kStatRows)), dim3(256), 0, s, x, rows, dim, sums);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int dim, double n, float eps,
+                                   float* __restrict__ mean, float* __restrict__ inv_std) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= dim) return;
+    const double m = sums[c] / n;
+    double var = sums[dim + c] / n - m * m;            // biased variance
+    if (var < 0.0) var = 0.0;
+    mean[c] = static_cast<float>(m);
+    inv_std[c] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+}
+
+void launch_bn_finalize(const double* sums, int dim, double n_global, float eps, float* mean, float* inv_std, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, s, sums, dim, n_global, eps, mean, inv_std);
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int dim, float* __restrict__ dbeta,
+                                       float* __restrict__ dgamma, float* __restrict__ grad_bias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= dim) return;
+    const float db = static_cast<float>(sums[c]);
+    dbeta[c] = db;
+    dgamma[c] = static_cast<float>(sums[dim + c]);
+    grad_bias[c] = db;                                 // ∂β = Σdy; ∂γ is computed and dropped (cudnn_utils.cu:173)
+}
+
+void launch_bn_bwd_finalize(const double* sums, int dim, float* dbeta, float* dgamma, float* grad_bias, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, s, sums, dim, dbeta, dgamma, grad_bias);
+}
+
+__global__ void colsum_finalize_kernel(const double* __restrict__ sums, int dim, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < dim) out[c] = static_cast<float>(sums[c]);
+}
+
+void launch_colsum_finalize(const double* sums, int dim, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, s, sums, dim, out);
+}
+
+// dx = invσ · (dy − (dβ + x̂·dγ) / N)       (= invσ/N · (N·dy − dβ − x̂·dγ), cuDNN per-activation backward)
+template <int V>
+__global__ __launch_bounds__(256) void bn_dx_kernel(float* __restrict__ dy, const float* __restrict__ pre,
+                                                    const float* __restrict__ mean, const float* __restrict__ inv_std,
+                                                    const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                    float inv_n, uint32_t total, uint32_t nvec, int dim) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        const uint32_t b = q / nvec;
+        const uint32_t c = (q - b * nvec) * V;
+        const size_t off = static_cast<size_t>(b) * dim + c;
+        float g[V], x[V], mu[V], is[V], db[V], dg[V];
+        ldv<V>(dy + off, g);
+        ldv<V>(pre + off, x);
+        ldv<V>(mean + c, mu);
+        ldv<V>(inv_std + c, is);
+        ldv<V>(dbeta + c, db);
+        ldv<V>(dgamma + c, dg);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float xhat = (x[i] - mu[i]) * is[i];
+            g[i] = is[i] * (g[i] - (db[i] + xhat * dg[i]) * inv_n);
+        }
+        stv<V>(dy + off, g);
+    }
+}
+
+void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* inv_std, const float* dbeta,
+                  const float* dgamma, double n_global, int64_t rows, int dim, hipStream_t s) {
+    if (rows <= 0) return;
+    const float inv_n = static_cast<float>(1.0 / n_global);
+    if (dim % 4 == 0) {
+        const uint32_t nvec = dim / 4, total = static_cast<uint32_t>(rows * nvec);
+        hipLaunchKernelGGL(bn_dx_kernel<4>, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, pre, mean, inv_std,
+                           dbeta, dgamma, inv_n, total, nvec, dim);
+    } else {
+        const uint32_t nvec = dim, total = static_cast<uint32_t>(rows * nvec);
+        hipLaunchKernelGGL(bn_dx_kernel<1>, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, pre, mean, inv_std,
+                           dbeta, dgamma, inv_n, total, nvec, dim);
+    }
+}
+
+// =============================================================================================
+// Fused loss: one wave per example. The example's projection row (entity_dim floats) stays in
+// registers (float4 per lane at de = 256), the R = k+1 document rows are streamed with one
+// coalesced 1 KB load each, the dot products are wave-shuffle reductions, and the kernel emits
+//   proj[b] = act(BN(pre[b]))                      (cpp/params.cu:425-446)
+//   p_j = clamp(σ(±E[id_j]·proj[b]))               (cpp/objective.cu:184-246)
+//   Σ ω_j·log p_j                                  (:250-305)
+//   coef_j = ±ω_j·dlogσ(p_j)/B                     (:354-401)   signed multiplier
+//   dy[b] = (Σ_r coef_j·E[id_j]) · act'(proj[b])   (:420-425, cpp/params.cu:474-491)
+//   column sums Σdy, Σdy·x̂                        (grad_bias / BN backward statistics)
+// replacing F8–F16 and B1–B4 and their four (N x de) temporaries with a single pass over E.
+// A block of 4 waves walks kExamplesPerWave examples per wave so that the column statistics need one
+// fp64 atomic per column per 64 examples.
+// =============================================================================================
+constexpr int kExamplesPerWave = 16;
+
+template <int V, int NITER>
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+    extern __shared__ float lds[];          // [2][4][de] column stats + [4] loss
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int de = a.de, R = a.R;
+    const int64_t e0 = (static_cast<int64_t>(blockIdx.x) * 4 + wid) * kExamplesPerWave;
+    const int64_t e1 = min(a.B, e0 + kExamplesPerWave);
+
+    float sdy[NITER][V], sdyx[NITER][V];
+    float mu[NITER][V], is[NITER][V], beta[NITER][V];
+    bool valid[NITER];
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+        const int c = (it * 64 + lane) * V;
+        valid[it] = (c < de);
+#pragma unroll
+        for (int i = 0; i < V; ++i) { sdy[it][i] = 0.f; sdyx[it][i] = 0.f; mu[it][i] = 0.f; is[it][i] = 1.f; beta[it][i] = 0.f; }
+        if (a.bn && valid[it]) {
+            ldv<V>(a.bn_mean + c, mu[it]);
+            ldv<V>(a.bn_inv_std + c, is[it]);
+            ldv<V>(a.bias + c, beta[it]);
+        }
+    }
+    float wave_loss = 0.f;
+
+    for (int64_t b = e0; b < e1; ++b) {
+        float out[NITER][V], xhat[NITER][V], gp[NITER][V];
+        float ssq = 0.f;
+#pragma unroll
+        for (int it = 0; it < NITER; ++it) {
+            const int c = (it * 64 + lane) * V;
+#pragma unroll
+            for (int i = 0; i < V; ++i) { out[it][i] = 0.f; xhat[it][i] = 0.f; gp[it][i] = 0.f; }
+            if (valid[it]) {
+                float x[V];
+                ldv<V>(a.pre + b * de + c, x);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float y = x[i];
+                    if (a.bn) { xhat[it][i] = (x[i] - mu[it][i]) * is[it][i]; y = xhat[it][i] + beta[it][i]; }
+                    y = (a.nonlinearity == 0) ? tanhf(y) : fminf(fmaxf(y, a.clip_min), a.clip_max);
+                    out[it][i] = y;
+                    ssq += y * y;
+                }
+                stv<V>(a.proj + b * de + c, out[it]);
+            }
+        }
+        ssq = wave_sum(ssq);
+        if (lane == 0) a.pp[b] = ssq * a.inv_de;
+
+        float w = a.inst_w ? a.inst_w[b] : 1.f;
+        if (a.rebalance) w = w * a.neg_scale;                       // objective.cu:268-274
+        const float w_pos = a.rebalance ? w * static_cast<float>(a.k) : w;   // :282-290
+
+        // software-pipelined stream of the R document rows
+        float e_next[NITER][V];
+        {
+            const size_t id = static_cast<size_t>(a.ids[b * R]);
+#pragma unroll
+            for (int it = 0; it < NITER; ++it) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) e_next[it][i] = 0.f;
+                if (valid[it]) ldv<V>(a.E + id * de + (it * 64 + lane) * V, e_next[it]);
+            }
+        }
+        for (int r = 0; r < R; ++r) {
+            float e[NITER][V];
+#pragma unroll
+            for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                for (int i = 0; i < V; ++i) e[it][i] = e_next[it][i];
+            if (r + 1 < R) {
+                const size_t id = static_cast<size_t>(a.ids[b * R + r + 1]);
+#pragma unroll
+                for (int it = 0; it < NITER; ++it)
+                    if (valid[it]) ldv<V>(a.E + id * de + (it * 64 + lane) * V, e_next[it]);
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                for (int i = 0; i < V; ++i) dot += out[it][i] * e[it][i];
+            dot = wave_sum(dot);
+            const float sign = (r == 0) ? 1.f : -1.f;                // objective.cu:184-187
+            const float sx = sign * dot;
+            float p = (sx >= 0.f) ? 1.f / (1.f + expf(-sx)) : expf(sx) / (1.f + expf(sx));   // cuda_utils.h:205-207
+            p = fminf(fmaxf(p, a.sig_eps), a.sig_hi);                // :209
+            const float wj = (r == 0) ? w_pos : w;
+            wave_loss += logf(p) * wj;                               // objective.cu:250-305
+            const float d = (static_cast<double>(p) >= a.d_hi || p <= a.d_eps) ? 0.f : 1.f - p;   // cuda_utils.h:229-231
+            const float m = wj * (d * a.inv_batch);                  // objective.cu:357-371
+            const float cf = sign * m;
+            if (lane == 0) {
+                a.coef[b * R + r] = cf;
+                a.probs[b * R + r] = p;
+            }
+#pragma unroll
+            for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                for (int i = 0; i < V; ++i) gp[it][i] += cf * e[it][i];   // fold_columns, :420-425
+        }
+
+        // nonlinearity' on the OUTPUT (params.cu:474-491) and column statistics
+#pragma unroll
+        for (int it = 0; it < NITER; ++it) {
+            if (!valid[it]) continue;
+            float g[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float y = out[it][i];
+                const float dd = (a.nonlinearity == 0) ? (1.f - y * y) : ((y > a.clip_min && y < a.clip_max) ? 1.f : 0.f);
+                g[i] = dd * gp[it][i];
+                sdy[it][i] += g[i];
+                sdyx[it][i] += g[i] * xhat[it][i];
+            }
+            stv<V>(a.dy + b * de + (it * 64 + lane) * V, g);
+        }
+    }
+
+    // ---- block reduction of the column statistics and the loss ----
+    float* s_dy = lds;                       // [4][de]
+    float* s_dyx = lds + 4 * de;             // [4][de]
+    float* s_loss = lds + 8 * de;            // [4]
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+        const int c = (it * 64 + lane) * V;
+        if (!valid[it]) continue;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            s_dy[wid * de + c + i] = sdy[it][i];
+            s_dyx[wid * de + c + i] = sdyx[it][i];
+        }
+    }
+    if (lane == 0) s_loss[wid] = wave_loss;
+    __syncthreads();
+    for (int c = threadIdx.x; c < de; c += blockDim.x) {
+        const float t0 = (s_dy[c] + s_dy[de + c]) + (s_dy[2 * de + c] + s_dy[3 * de + c]);
+        atomic_add_f64(a.colstats + c, static_cast<double>(t0));
+        if (a.bn) {
+            const float t1 = (s_dyx[c] + s_dyx[de + c]) + (s_dyx[2 * de + c] + s_dyx[3 * de + c]);
+            atomic_add_f64(a.colstats + de + c, static_cast<double>(t1));
+        }
+    }
+    if (threadIdx.x == 0)
+        atomic_add_f64(a.loss_acc, static_cast<double>((s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3])));
+}
+
+template <int V, int NITER>
+static void launch_loss_t(const LossArgs& a, hipStream_t s) {
+    const int grid = ceil_div(a.B, 4 * kExamplesPerWave);
+    const size_t shmem = (8 * static_cast<size_t>(a.de) + 4) * sizeof(float);
+    hipLaunchKernelGGL((loss_kernel<V, NITER>), dim3(grid), dim3(256), shmem, s, a);
+}
+
+void launch_loss(const LossArgs& a, hipStream_t s) {
+    if (a.B <= 0) return;
+    const int de = a.de;
+    if (de % 4 == 0) {
+        if (de <= 256) launch_loss_t<4, 1>(a, s);
+        else if (de <= 512) launch_loss_t<4, 2>(a, s);
+        else launch_loss_t<4, 4>(a, s);                 // de ≤ 1024, the reference's own limit (block = dim)
+    } else {
+        if (de <= 64) launch_loss_t<1, 1>(a, s);
+        else if (de <= 128) launch_loss_t<1, 2>(a, s);
+        else launch_loss_t<1, 4>(a, s);                 // odd dims up to 256
+    }
+}
+
+// out[b] = Σ_t G[b][t]² · inv_dim — one wave per row (cpp/updates_adam.cu:232-240, updates_adagrad.cu:136-143)
+__global__ __launch_bounds__(256) void row_meansq_kernel(const float* __restrict__ G, int64_t rows, int dim, float inv_dim,
+                                                         float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < rows; b += static_cast<int64_t>(gridDim.x) * 4) {
+        float s = 0.f;
+        for (int t = lane; t < dim; t += 64) {
+            const float v = G[b * dim + t];
+            s += v * v;
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[b] = s * inv_dim;
+    }
+}
+
+void launch_row_meansq(const float* G, int64_t rows, int dim, float inv_dim, float* out, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(row_meansq_kernel, dim3(stream_grid(rows * 64, 256)), dim3(256), 0, s, G, rows, dim, inv_dim, out);
+}
+
+__global__ void materialize_grad_entity_kernel(const float* __restrict__ coef, const float* __restrict__ proj, int64_t N,
+                                               int R, int de, float* __restrict__ out) {
+    const int64_t total = N * de;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t j = i / de;
+        const int t = static_cast<int>(i - j * de);
+        out[i] = proj[(j / R) * de + t] * coef[j];
+    }
+}
+
+void launch_materialize_grad_entity(const float* coef, const float* proj, int64_t N, int R, int de, float* out, hipStream_t s) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(materialize_grad_entity_kernel, dim3(stream_grid(N * de, 256)), dim3(256), 0, s, coef, proj, N, R, de, out);
+}
+
+}  // namespace cunvsm

@@ -1,0 +1,724 @@
+// Host orchestration of the NVSM / LSE step on MI355X. See model.h.
+#include "model.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+namespace cunvsm {
+
+// ---------------------------------------------------------------------------------------------
+// RCCL through dlopen (rccl.h types restated minimally; ABI of RCCL 2.x / NCCL 2.x)
+// ---------------------------------------------------------------------------------------------
+struct RcclApi {
+    void* handle = nullptr;
+    typedef struct { char internal[128]; } UniqueId;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    static constexpr int kFloat32 = 7, kFloat64 = 8, kSum = 0;   // ncclFloat32, ncclFloat64, ncclSum
+
+    static RcclApi* load() {
+        static RcclApi api;
+        if (api.handle) return &api;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) throw Error(NVSM_ERR_DEVICE, std::string("cannot load librccl: ") + dlerror());
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+        if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy)
+            throw Error(NVSM_ERR_DEVICE, "librccl lacks the expected nccl* symbols");
+        return &api;
+    }
+};
+
+void rccl_unique_id(char id[128]) {
+    RcclApi* api = RcclApi::load();
+    RcclApi::UniqueId u;
+    const int rc = api->GetUniqueId(&u);
+    if (rc != 0) throw Error(NVSM_ERR_DEVICE, "ncclGetUniqueId failed");
+    std::memcpy(id, u.internal, 128);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Profiler: HIP events on the handle's stream around each kernel group
+// ---------------------------------------------------------------------------------------------
+void Profiler::begin(const char* name, hipStream_t s) {
+    if (!enabled) return;
+    Slot& sl = slots_[name];
+    if (sl.used == sl.ev.size()) {
+        hipEvent_t a, b;
+        NVSM_HIP_CHECK(hipEventCreate(&a));
+        NVSM_HIP_CHECK(hipEventCreate(&b));
+        sl.ev.emplace_back(a, b);
+    }
+    cur_ = &sl;
+    NVSM_HIP_CHECK(hipEventRecord(sl.ev[sl.used].first, s));
+}
+void Profiler::end(hipStream_t s) {
+    if (!enabled || !cur_) return;
+    NVSM_HIP_CHECK(hipEventRecord(cur_->ev[cur_->used].second, s));
+    cur_->used++;
+    cur_ = nullptr;
+}
+void Profiler::reset() {
+    for (auto& kv : slots_) kv.second.used = 0;
+}
+std::vector<std::string> Profiler::names() const {
+    std::vector<std::string> v;
+    for (auto& kv : slots_) v.push_back(kv.first);
+    return v;
+}
+bool Profiler::get(const std::string& name, double* ms, int64_t* launches) {
+    auto it = slots_.find(name);
+    if (it == slots_.end()) return false;
+    double total = 0.0;
+    for (size_t i = 0; i < it->second.used; ++i) {
+        NVSM_HIP_CHECK(hipEventSynchronize(it->second.ev[i].second));
+        float t = 0.f;
+        NVSM_HIP_CHECK(hipEventElapsedTime(&t, it->second.ev[i].first, it->second.ev[i].second));
+        total += t;
+    }
+    *ms = total;
+    *launches = static_cast<int64_t>(it->second.used);
+    return true;
+}
+Profiler::~Profiler() {
+    for (auto& kv : slots_)
+        for (auto& e : kv.second.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+}
+
+struct ProfScope {
+    Profiler& p; hipStream_t s;
+    ProfScope(Profiler& p_, const char* name, hipStream_t s_) : p(p_), s(s_) { p.begin(name, s); }
+    ~ProfScope() { p.end(s); }
+};
+#define PROF(name) ProfScope _prof_scope(prof, name, stream_)
+
+// ---------------------------------------------------------------------------------------------
+static int bits_for(int64_t n) {
+    int b = 1;
+    while ((int64_t(1) << b) < n) ++b;
+    return b;
+}
+
+void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entries) {
+    t.rows = rows; t.dim = dim; t.max_entries = max_entries;
+    t.P.alloc(rows * dim, true);
+    const int method = cfg_.update_method, mode = cfg_.adam_mode;
+    if (method == NVSM_ADAGRAD) {
+        t.sc[0].alloc(rows, true); t.sc[1].alloc(rows, true);
+    } else if (method == NVSM_ADAM) {
+        t.m.alloc(rows * dim, true);
+        if (mode == NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE) t.vfull.alloc(rows * dim, true);
+        else { t.sc[0].alloc(rows, true); t.sc[1].alloc(rows, true); }
+    }
+    t.sorted_key.alloc(max_entries); t.sorted_entry.alloc(max_entries);
+    t.row_begin.alloc(rows, true); t.row_end.alloc(rows, true); t.chunk_base.alloc(rows, true);
+    t.max_chunks = static_cast<int>(2 * max_entries / kChunk + 2);
+    t.chunk_desc.alloc(static_cast<size_t>(t.max_chunks) * 3, true);
+    t.num_chunks.alloc(1, true);
+    t.partial.alloc(static_cast<size_t>(t.max_chunks) * dim);
+    t.partial_q.alloc(t.max_chunks, true);
+    t.sort_bits = bits_for(rows);
+    t.sort_temp_bytes = sort_pairs_temp_bytes(max_entries, t.sort_bits);
+    t.sort_temp.alloc(t.sort_temp_bytes + 16);
+}
+
+Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1), rng_(1) {
+    auto bad = [](const std::string& m) { throw Error(NVSM_ERR_INVALID_ARGUMENT, m); };
+    if (cfg.num_words <= 0 || cfg.num_entities <= 0) bad("num_words and num_entities must be positive");
+    if (cfg.word_repr_size <= 0 || cfg.entity_repr_size <= 0) bad("representation sizes must be positive");
+    if (cfg.window_size <= 0 || cfg.num_random_entities < 0) bad("window_size must be > 0 and num_random_entities >= 0");
+    if (cfg.max_batch_size <= 0) bad("max_batch_size must be positive");
+    if (cfg.regularization_lambda < 0) bad("regularization_lambda must be >= 0");          // cpp/storage.cu:62-63
+    if (cfg.num_words >= (int64_t(1) << 31) || cfg.num_entities >= (int64_t(1) << 31)) bad("tables are limited to 2^31 rows");
+    if (cfg.nonlinearity != NVSM_TANH && cfg.nonlinearity != NVSM_HARD_TANH) bad("nonlinearity not implemented");  // params.cu:444-445
+    if (cfg.update_method < NVSM_SGD || cfg.update_method > NVSM_ADAM) bad("unknown update_method");
+    if (cfg.adam_mode < NVSM_ADAM_NONE || cfg.adam_mode > NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE) bad("unknown adam_mode");
+    if (cfg.l2_normalize_phrase_reprs || cfg.l2_normalize_entity_reprs)
+        throw Error(NVSM_ERR_UNSUPPORTED, "l2 phrase/entity normalisation is outside the accelerated hot path (off in the LSE and NVSM recipes)");
+    if (cfg.entity_repr_size > 1024 || (cfg.entity_repr_size % 4 != 0 && cfg.entity_repr_size > 256))
+        throw Error(NVSM_ERR_UNSUPPORTED, "entity_repr_size must be <= 1024 (multiple of 4) or <= 256");
+    if (cfg.word_repr_size > 4096) throw Error(NVSM_ERR_UNSUPPORTED, "word_repr_size must be <= 4096");
+    if (cfg.world_size < 1 || cfg.rank < 0 || cfg.rank >= cfg.world_size) bad("bad world_size / rank");
+    const int64_t B = cfg.max_batch_size;
+    if (B * std::max<int64_t>(cfg.word_repr_size, cfg.entity_repr_size) >= (int64_t(1) << 32) ||
+        B * R_ * cfg.entity_repr_size >= (int64_t(1) << 40))
+        bad("max_batch_size too large for 32-bit work indexing");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw Error(NVSM_ERR_NO_DEVICE, "no HIP device visible — cunvsm_amd has no CPU fallback");
+    if (cfg.device < 0 || cfg.device >= ndev) bad("device ordinal out of range");
+    NVSM_HIP_CHECK(hipSetDevice(cfg.device));
+    NVSM_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    own_stream_ = true;
+
+    const int dw = cfg.word_repr_size, de = cfg.entity_repr_size, w = cfg.window_size;
+    const int64_t N = B * R_;
+    alloc_table(words_, cfg.num_words, dw, B * w);
+    alloc_table(ents_, cfg.num_entities, de, N);
+    T_.alloc(static_cast<size_t>(de) * dw, true); b_.alloc(de, true);
+    if (cfg.update_method != NVSM_SGD) { s0T_.alloc(static_cast<size_t>(de) * dw, true); s0b_.alloc(de, true); }
+    if (cfg.update_method == NVSM_ADAM) { s1T_.alloc(static_cast<size_t>(de) * dw, true); s1b_.alloc(de, true); }
+
+    in_words_.alloc(B * w); in_labels_.alloc(B); in_ids64_.alloc(N); in_wwts_.alloc(B * w); in_instw_.alloc(B);
+    widx_.alloc(B * w); ids_.alloc(N); iota_.alloc(std::max<int64_t>(B * w, N));
+    launch_iota(iota_.p, static_cast<int64_t>(iota_.n), stream_);
+    phrase_.alloc(B * dw); pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
+    coef_.alloc(N); probs_.alloc(N); pp_.alloc(B); msq_w_.alloc(B);
+    if (cfg.update_method == NVSM_ADAM && cfg.adam_mode <= NVSM_ADAM_SPARSE) U_.alloc(B * dw);
+    if (cfg.update_method == NVSM_ADAGRAD) scale_w_.alloc(B);
+    stats_fwd_.alloc(2 * de, true); stats_bwd_.alloc(1 + 2 * de, true);
+    bn_mean_.alloc(de, true); bn_inv_std_.alloc(de, true); dbeta_.alloc(de, true); dgamma_.alloc(de, true);
+    gT_.alloc(static_cast<size_t>(de) * dw, true); gb_.alloc(de, true);
+    const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
+    gT_partial_.alloc(static_cast<size_t>(slabs) * de * dw);
+    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+Model::~Model() {
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (comm_ && rccl_) rccl_->CommDestroy(comm_);
+    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Model::set_stream(hipStream_t s) {
+    synchronize();
+    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+    if (s) { stream_ = s; own_stream_ = false; }
+    else { NVSM_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); own_stream_ = true; }
+}
+
+void Model::synchronize() { NVSM_HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+// ModelBase::initialize (cpp/model.cu:37-43) with init_matrix_glorot (include/cuNVSM/cuda_utils.h:35-56):
+// same generator, same draw order (words → entities → transform), same float expression.
+void Model::initialize(uint64_t seed) {
+    if (seed == 0) throw Error(NVSM_ERR_INVALID_ARGUMENT, "Please specify a seed value > 0");   // cpp/main.cu:708
+    rng_.seed(static_cast<std::minstd_rand0::result_type>(seed));
+    device_seed_ = seed;
+    auto glorot = [&](DevBuf<float>& dst, size_t rows, size_t cols) {
+        std::vector<float> h(rows * cols);
+        const float max = std::sqrt(6.0 / static_cast<double>(rows + cols));
+        for (size_t i = 0; i < h.size(); ++i) h[i] = 2 * max * (std::generate_canonical<float, 1>(rng_) - 0.5);
+        NVSM_HIP_CHECK(hipMemcpy(dst.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    };
+    glorot(words_.P, cfg_.word_repr_size, cfg_.num_words);
+    glorot(ents_.P, cfg_.entity_repr_size, cfg_.num_entities);
+    glorot(T_, cfg_.entity_repr_size, cfg_.word_repr_size);
+    NVSM_HIP_CHECK(hipMemset(b_.p, 0, b_.n * sizeof(float)));                                   // params.cu:368-369
+}
+
+uint64_t Model::rng_get_state() { std::stringstream ss; ss << rng_; uint64_t s; ss >> s; return s; }
+void Model::rng_set_state(uint64_t s) { std::stringstream ss; ss << s; ss >> rng_; }
+
+// ---------------------------------------------------------------------------------------------
+// collectives
+// ---------------------------------------------------------------------------------------------
+void Model::comm_init(const char id[128]) {
+    if (cfg_.world_size <= 1) return;
+    rccl_ = RcclApi::load();
+    RcclApi::UniqueId u;
+    std::memcpy(u.internal, id, 128);
+    NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    const int rc = rccl_->CommInitRank(&comm_, cfg_.world_size, u, cfg_.rank);
+    if (rc != 0) throw Error(NVSM_ERR_DEVICE, std::string("ncclCommInitRank: ") + (rccl_->GetErrorString ? rccl_->GetErrorString(rc) : "error"));
+}
+
+void Model::allreduce_f64(double* dev, int64_t n) {
+    if (cfg_.world_size <= 1) return;
+    if (comm_) {
+        const int rc = rccl_->AllReduce(dev, dev, n, RcclApi::kFloat64, RcclApi::kSum, comm_, stream_);
+        if (rc != 0) throw Error(NVSM_ERR_DEVICE, "ncclAllReduce(f64) failed");
+    } else if (ar_fn_) {
+        ar_host_.resize(n);
+        NVSM_HIP_CHECK(hipMemcpyAsync(ar_host_.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        if (ar_fn_(ar_host_.data(), n, ar_user_) != 0) throw Error(NVSM_ERR_DEVICE, "all-reduce callback failed");
+        NVSM_HIP_CHECK(hipMemcpyAsync(dev, ar_host_.data(), n * sizeof(double), hipMemcpyHostToDevice, stream_));
+        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    } else {
+        throw Error(NVSM_ERR_STATE, "world_size > 1 but neither nvsm_comm_init nor an all-reduce callback was set");
+    }
+}
+
+void Model::allreduce_f32(float* dev, int64_t n) {
+    if (cfg_.world_size <= 1) return;
+    if (comm_) {
+        const int rc = rccl_->AllReduce(dev, dev, n, RcclApi::kFloat32, RcclApi::kSum, comm_, stream_);
+        if (rc != 0) throw Error(NVSM_ERR_DEVICE, "ncclAllReduce(f32) failed");
+    } else if (ar_fn_) {
+        std::vector<float> h(n);
+        NVSM_HIP_CHECK(hipMemcpyAsync(h.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        ar_host_.assign(h.begin(), h.end());
+        if (ar_fn_(ar_host_.data(), n, ar_user_) != 0) throw Error(NVSM_ERR_DEVICE, "all-reduce callback failed");
+        for (int64_t i = 0; i < n; ++i) h[i] = static_cast<float>(ar_host_[i]);
+        NVSM_HIP_CHECK(hipMemcpyAsync(dev, h.data(), n * sizeof(float), hipMemcpyHostToDevice, stream_));
+        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    } else {
+        throw Error(NVSM_ERR_STATE, "world_size > 1 but neither nvsm_comm_init nor an all-reduce callback was set");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compute_cost — cpp/objective.cu:30-313
+// ---------------------------------------------------------------------------------------------
+void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
+    const int64_t B = batch.num_instances;
+    if (B <= 0 || B > cfg_.max_batch_size) throw Error(NVSM_ERR_INVALID_ARGUMENT, "num_instances must be in (0, max_batch_size]");
+    if (!batch.features || !batch.labels) throw Error(NVSM_ERR_INVALID_ARGUMENT, "features and labels are required");
+    NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size, w = cfg_.window_size, k = cfg_.num_random_entities;
+    const int64_t N = B * R_;
+    B_ = B;
+    have_forward_ = have_grads_ = false;
+    cost_valid_ = false;
+
+    // F1: batch → HBM (objective.cu:36-61)
+    const int64_t* words_dev;
+    {
+        PROF("h2d_batch");
+        if (batch.on_device) {
+            words_dev = batch.features;
+            labels_dev_ = batch.labels;
+            wwts_ = batch.feature_weights;
+            instw_ = batch.weights;
+        } else {
+            NVSM_HIP_CHECK(hipMemcpyAsync(in_words_.p, batch.features, B * w * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+            NVSM_HIP_CHECK(hipMemcpyAsync(in_labels_.p, batch.labels, B * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+            words_dev = in_words_.p;
+            labels_dev_ = in_labels_.p;
+            wwts_ = nullptr; instw_ = nullptr;
+            if (batch.feature_weights) {
+                NVSM_HIP_CHECK(hipMemcpyAsync(in_wwts_.p, batch.feature_weights, B * w * sizeof(float), hipMemcpyHostToDevice, stream_));
+                wwts_ = in_wwts_.p;
+            }
+            if (batch.weights) {
+                NVSM_HIP_CHECK(hipMemcpyAsync(in_instw_.p, batch.weights, B * sizeof(float), hipMemcpyHostToDevice, stream_));
+                instw_ = in_instw_.p;
+            }
+        }
+        launch_narrow_i64(words_dev, widx_.p, B * w, stream_);
+    }
+
+    // F2: target + negative document ids (objective.cu:63-89 → labels.cu:4-22)
+    {
+        PROF("sample_entities");
+        if (entity_ids) {
+            NVSM_HIP_CHECK(hipMemcpyAsync(in_ids64_.p, entity_ids, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+            launch_narrow_i64(in_ids64_.p, ids_.p, N, stream_);
+        } else if (cfg_.sampler == NVSM_SAMPLER_HOST_MINSTD) {
+            host_labels_.resize(B);
+            if (batch.on_device) {
+                NVSM_HIP_CHECK(hipMemcpyAsync(host_labels_.data(), batch.labels, B * sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
+                NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+            } else {
+                std::memcpy(host_labels_.data(), batch.labels, B * sizeof(int64_t));
+            }
+            host_ids_.resize(N);
+            for (int64_t i = 0; i < B; ++i) {                       // UniformLabelGenerator::generate
+                host_ids_[i * R_] = host_labels_[i];
+                for (int r = 1; r < R_; ++r)                          // generate_random_indexes: fresh distribution per draw
+                    host_ids_[i * R_ + r] = std::uniform_int_distribution<long>(0, cfg_.num_entities - 1)(rng_);
+            }
+            NVSM_HIP_CHECK(hipMemcpyAsync(in_ids64_.p, host_ids_.data(), N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+            NVSM_HIP_CHECK(hipStreamSynchronize(stream_));           // host_ids_ is pageable and reused next step
+            launch_narrow_i64(in_ids64_.p, ids_.p, N, stream_);
+        } else {
+            launch_sample_entities(labels_dev_, B, R_, cfg_.num_entities, device_seed_ + 0x9E37u * cfg_.rank, step_count_, ids_.p, stream_);
+        }
+    }
+    ++step_count_;
+
+    // F3: phrase representations (objective.cu:126-130)
+    { PROF("gather_mean_words"); launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, phrase_.p, stream_); }
+
+    // F5: projection GEMM  pre[B][de] = phrase[B][dw] · Tt[dw][de] (+ b when no BN)   (params.cu:417-421)
+    {
+        PROF("gemm_fwd");
+        launch_gemm(0, 0, phrase_.p, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
+                    cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_);
+    }
+
+    const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
+    const double bn_n = (cfg_.world_size > 1 && cfg_.sync_batch_norm) ? B_global : static_cast<double>(B);
+    // F6: batch statistics (cudnn_utils.cu:107-124), ε = 1e-4 (objective.cu:114)
+    if (cfg_.batch_normalization) {
+        PROF("bn_stats");
+        NVSM_HIP_CHECK(hipMemsetAsync(stats_fwd_.p, 0, stats_fwd_.n * sizeof(double), stream_));
+        launch_bn_colstats(pre_.p, B, de, stats_fwd_.p, stream_);
+        if (cfg_.world_size > 1 && cfg_.sync_batch_norm) allreduce_f64(stats_fwd_.p, 2 * de);
+        launch_bn_finalize(stats_fwd_.p, de, bn_n, 1e-4f, bn_mean_.p, bn_inv_std_.p, stream_);
+    }
+
+    // F7–F16 + B1–B4: fused loss
+    {
+        PROF("loss_fused");
+        NVSM_HIP_CHECK(hipMemsetAsync(stats_bwd_.p, 0, stats_bwd_.n * sizeof(double), stream_));
+        LossArgs a;
+        a.pre = pre_.p; a.bn_mean = bn_mean_.p; a.bn_inv_std = bn_inv_std_.p; a.bias = b_.p;
+        a.E = ents_.P.p; a.ids = ids_.p; a.inst_w = instw_;
+        a.proj = proj_.p; a.dy = dy_.p; a.coef = coef_.p; a.probs = probs_.p; a.pp = pp_.p;
+        a.loss_acc = stats_bwd_.p; a.colstats = stats_bwd_.p + 1;
+        a.B = B; a.de = de; a.R = R_; a.k = k;
+        a.bn = cfg_.batch_normalization; a.nonlinearity = cfg_.nonlinearity;
+        a.rebalance = (!cfg_.bias_negative_samples && k > 1);                                 // objective.cu:268
+        a.sig_eps = cfg_.clip_sigmoid ? 1e-7f : 0.f;                                            // :245-246
+        a.sig_hi = static_cast<float>(1.0 - static_cast<double>(a.sig_eps));
+        a.d_eps = cfg_.clip_sigmoid ? 1e-6f : 0.f;                                              // :367-368
+        a.d_hi = 1.0 - static_cast<double>(a.d_eps);
+        a.inv_batch = static_cast<float>(std::exp(-std::log(B_global)));                        // :354
+        a.neg_scale = static_cast<float>((static_cast<double>(static_cast<float>(k)) + 1.0) /
+                                         (2.0 * static_cast<double>(static_cast<float>(k))));   // :270-273
+        a.clip_min = std::nextafter(-1.0f, -1.0f - 1e-5f);                                      // cuda_utils.h:91-96
+        a.clip_max = std::nextafter(1.0f, 1.0f + 1e-5f);
+        a.inv_de = static_cast<float>(std::exp(-std::log(static_cast<double>(de))));
+        launch_loss(a, stream_);
+    }
+    have_forward_ = true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// compute_gradients — cpp/objective.cu:315-481, cpp/params.cu:453-535
+// ---------------------------------------------------------------------------------------------
+void Model::compute_gradients() {
+    if (!have_forward_) throw Error(NVSM_ERR_STATE, "compute_gradients requires compute_cost");
+    NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size, w = cfg_.window_size;
+    const int64_t B = B_;
+    const bool dp = cfg_.world_size > 1;
+    const double B_global = static_cast<double>(B) * (dp ? cfg_.world_size : 1);
+
+    // B5: bias gradient / BN backward (params.cu:509-521)
+    {
+        PROF("bn_backward");
+        if (cfg_.batch_normalization) {
+            if (dp && cfg_.sync_batch_norm) {
+                allreduce_f64(stats_bwd_.p, 1 + 2 * de);
+                launch_bn_bwd_finalize(stats_bwd_.p + 1, de, dbeta_.p, dgamma_.p, gb_.p, stream_);
+                launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, dbeta_.p, dgamma_.p, B_global, B, de, stream_);
+            } else {
+                launch_bn_bwd_finalize(stats_bwd_.p + 1, de, dbeta_.p, dgamma_.p, gb_.p, stream_);
+                launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, dbeta_.p, dgamma_.p, static_cast<double>(B), B, de, stream_);
+                if (dp) { allreduce_f64(stats_bwd_.p, 1 + 2 * de); launch_colsum_finalize(stats_bwd_.p + 1, de, gb_.p, stream_); }
+            }
+        } else {
+            if (dp) allreduce_f64(stats_bwd_.p, 1 + de);
+            launch_colsum_finalize(stats_bwd_.p + 1, de, gb_.p, stream_);
+        }
+    }
+    // B7 + B9: gphrase[B][dw] = dx[B][de] · T (stored [dw][de]) / w   (objective.cu:447-476)
+    {
+        PROF("gemm_bwd_x");
+        const float inv_w = static_cast<float>(std::exp(-std::log(static_cast<double>(w))));
+        launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, 1, 0, stream_);
+    }
+    // B6: ∂T (stored [dw][de]) = phraseᵀ[dw x B] · dx[B x de], split-K over the batch   (params.cu:526-531)
+    {
+        PROF("gemm_bwd_T");
+        const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
+        const size_t stride = static_cast<size_t>(de) * dw;
+        if (slabs == 1) {
+            launch_gemm(1, 0, phrase_.p, dy_.p, gT_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr, 1, 0, stream_);
+        } else {
+            launch_gemm(1, 0, phrase_.p, dy_.p, gT_partial_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr,
+                        gemm_slabs_want_, stride, stream_);
+            launch_splitk_reduce(gT_partial_.p, slabs, stride, gT_.p, static_cast<int64_t>(stride), stream_);
+        }
+    }
+    // data parallel: one all-reduce of the dense projection gradient over xGMI
+    if (dp) { PROF("allreduce_grad"); allreduce_f32(gT_.p, static_cast<int64_t>(de) * dw); cost_valid_ = false; }
+    have_grads_ = true;
+}
+
+float Model::scaled_regularization_lambda() const {
+    const double Bg = static_cast<double>(B_ > 0 ? B_ : cfg_.max_batch_size) * (cfg_.world_size > 1 ? cfg_.world_size : 1);
+    return cfg_.regularization_lambda / static_cast<float>(Bg);      // intermediate_results.cu:126-129
+}
+
+// ForwardResult::get_cost (intermediate_results.cu:80-124): −(Σ mass)/B, one D2H + stream sync.
+float Model::get_cost() {
+    if (!have_forward_) throw Error(NVSM_ERR_STATE, "get_cost requires compute_cost");
+    if (!cost_valid_) {
+        double s = 0.0;
+        if (cfg_.world_size > 1 && !have_grads_) {
+            // before compute_gradients the loss word has not been all-reduced yet: local contribution only
+        }
+        NVSM_HIP_CHECK(hipMemcpyAsync(&s, stats_bwd_.p, sizeof(double), hipMemcpyDeviceToHost, stream_));
+        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        const double Bg = static_cast<double>(B_) * (cfg_.world_size > 1 ? cfg_.world_size : 1);
+        cost_ = -(s / Bg);
+        cost_valid_ = true;
+    }
+    return static_cast<float>(cost_);
+}
+
+// ---------------------------------------------------------------------------------------------
+// update — cpp/model.cu:187-220: entities → words → transform
+// ---------------------------------------------------------------------------------------------
+float Model::adam_bc(uint64_t t) const {
+    const double b1 = static_cast<double>(0.9f), b2 = static_cast<double>(0.999f);
+    return static_cast<float>(std::sqrt(1.0 - std::pow(b2, static_cast<double>(t))) / (1.0 - std::pow(b1, static_cast<double>(t))));
+}
+
+Csr Model::csr_of(TableState& t, int64_t n) {
+    Csr c;
+    c.sorted_key = t.sorted_key.p; c.sorted_entry = t.sorted_entry.p;
+    c.row_begin = t.row_begin.p; c.row_end = t.row_end.p; c.chunk_base = t.chunk_base.p;
+    c.chunk_desc = t.chunk_desc.p; c.num_chunks = t.num_chunks.p;
+    c.partial = t.partial.p; c.partial_q = t.partial_q.p;
+    c.n = n; c.rows = t.rows; c.max_chunks = t.max_chunks;
+    return c;
+}
+
+void Model::build_csr(TableState& t, const int* keys, int64_t n) {
+    sort_pairs(t.sort_temp.p, t.sort_temp_bytes, keys, t.sorted_key.p, iota_.p, t.sorted_entry.p, n, t.sort_bits, stream_);
+    launch_csr_build(csr_of(t, n), stream_);
+}
+
+static void fill_adam_consts(RowPassArgs& a, float bc, float sl) {
+    const double b1 = static_cast<double>(0.9f), b2 = static_cast<double>(0.999f);
+    a.one_m_b1 = static_cast<float>(1.0 - b1);
+    a.one_m_b2 = static_cast<float>(1.0 - b2);
+    a.s_m = static_cast<float>(1.0 - 1.0 * static_cast<double>(a.one_m_b1));     // storage.cu:65-67 with λ = 1, lr = 1−β
+    a.s_v = static_cast<float>(1.0 - 1.0 * static_cast<double>(a.one_m_b2));
+    a.bc = bc;
+    a.eps = 1e-6f;                                                                 // updates.h:21
+    a.c_reg = static_cast<float>((1.0 - b1) * static_cast<double>(sl));            // updates_adam.cu:208-212
+}
+
+void Model::update_entities(float lr, float sl) {
+    const int64_t N = B_ * R_;
+    const int de = cfg_.entity_repr_size;
+    TableState& t = ents_;
+    { PROF("csr_entities"); build_csr(t, ids_.p, N); }
+    Csr c = csr_of(t, N);
+    RowPassArgs a{};
+    a.table = 1; a.X = proj_.p; a.coefs = coef_.p; a.sq_src = pp_.p; a.div = static_cast<uint32_t>(R_);
+    a.P = t.P.p; a.m = t.m.p; a.v = t.vfull.p; a.dim = de;
+    a.lr = lr; a.lambda = sl; a.eps = 1e-6f;
+    a.decay = sl > 0.f ? static_cast<float>(1.0 - static_cast<double>(sl) * static_cast<double>(lr)) : 1.f;
+    a.sc_in = t.sc[t.sc_cur].p; a.sc_out = t.sc[t.sc_cur ^ 1].p;
+    bool swap_sc = false;
+    switch (cfg_.update_method) {
+        case NVSM_SGD: a.kind = ROW_SGD; a.sq_src = nullptr; a.dense = sl > 0.f; break;
+        case NVSM_ADAGRAD: a.kind = ROW_ADAGRAD_ENT; a.dense = 1; swap_sc = true; break;
+        default: {
+            fill_adam_consts(a, adam_bc(t.t), sl);
+            t.t += 1;
+            a.dense = 1;
+            if (cfg_.adam_mode == NVSM_ADAM_DENSE_UPDATE) { a.kind = ROW_ADAM_DENSE; swap_sc = true; }
+            else if (cfg_.adam_mode == NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE) { a.kind = ROW_ADAM_FULL; a.sq_src = nullptr; a.decay = 1.f; }
+            else { a.kind = ROW_ADAM_SPARSE_ENT; swap_sc = true; }
+        }
+    }
+    { PROF("chunk_pass_entities"); launch_chunk_pass(c, a, stream_); }
+    { PROF("row_pass_entities"); launch_row_pass(c, a, stream_); }
+    if (swap_sc) t.sc_cur ^= 1;
+}
+
+void Model::update_words(float lr, float sl) {
+    const int dw = cfg_.word_repr_size, w = cfg_.window_size;
+    const int64_t n = B_ * w;
+    TableState& t = words_;
+    { PROF("csr_words"); build_csr(t, widx_.p, n); }
+    Csr c = csr_of(t, n);
+    RowPassArgs a{};
+    a.table = 0; a.X = gphrase_.p; a.wts = wwts_; a.div = static_cast<uint32_t>(w);
+    a.P = t.P.p; a.m = t.m.p; a.v = t.vfull.p; a.dim = dw;
+    a.lr = lr; a.lambda = sl; a.eps = 1e-6f;
+    a.decay = sl > 0.f ? static_cast<float>(1.0 - static_cast<double>(sl) * static_cast<double>(lr)) : 1.f;
+    const float inv_dw = static_cast<float>(std::exp(-std::log(static_cast<double>(dw))));
+    const int method = cfg_.update_method, mode = cfg_.adam_mode;
+
+    if (method == NVSM_SGD) {
+        a.kind = ROW_SGD; a.dense = sl > 0.f;
+        { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
+        { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
+        return;
+    }
+    if (method == NVSM_ADAGRAD) {
+        { PROF("row_meansq_words"); launch_row_meansq(gphrase_.p, B_, dw, inv_dw, msq_w_.p, stream_); }
+        RowPassArgs s = a;                                             // accumulator pass (updates_adagrad.cu:136-158)
+        s.kind = ROW_SCALAR_ACC; s.sq_src = msq_w_.p; s.dense = 1;
+        s.sc_in = t.sc[t.sc_cur].p; s.sc_out = t.sc[t.sc_cur ^ 1].p;
+        { PROF("adagrad_acc_words"); launch_chunk_pass(c, s, stream_); launch_row_pass(c, s, stream_); }
+        t.sc_cur ^= 1;
+        { PROF("adagrad_scale_words"); launch_adagrad_scale(t.sc[t.sc_cur].p, widx_.p, w, B_, 1e-6f, scale_w_.p, stream_); }
+        a.kind = ROW_SGD; a.src_scale = scale_w_.p; a.dense = sl > 0.f;
+        { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
+        { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
+        return;
+    }
+    // Adam
+    fill_adam_consts(a, adam_bc(t.t), sl);
+    t.t += 1;
+    if (mode == NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE) {
+        a.kind = ROW_ADAM_FULL; a.dense = 1; a.decay = 1.f;
+        { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
+        { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
+        return;
+    }
+    { PROF("row_meansq_words"); launch_row_meansq(gphrase_.p, B_, dw, inv_dw, msq_w_.p, stream_); }
+    a.sq_src = msq_w_.p; a.dense = 1;
+    a.sc_in = t.sc[t.sc_cur].p; a.sc_out = t.sc[t.sc_cur ^ 1].p;
+    if (mode == NVSM_ADAM_DENSE_UPDATE) {
+        a.kind = ROW_ADAM_DENSE;
+        { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
+        { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
+        t.sc_cur ^= 1;
+        return;
+    }
+    // SPARSE: moments, then the window-averaged direction, then the scatter (updates_adam.cu:332-384)
+    a.kind = ROW_ADAM_MV;
+    { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
+    { PROF("row_pass_words_mv"); launch_row_pass(c, a, stream_); }
+    t.sc_cur ^= 1;
+    { PROF("adam_u_words"); launch_adam_u(t.m.p, t.sc[t.sc_cur].p, dw, widx_.p, w, B_, a.bc, a.eps, U_.p, stream_); }
+    RowPassArgs r = a;
+    r.kind = ROW_SGD; r.X = U_.p; r.sq_src = nullptr; r.dense = sl > 0.f;
+    { PROF("chunk_pass_words_u"); launch_chunk_pass(c, r, stream_); }
+    { PROF("row_pass_words_u"); launch_row_pass(c, r, stream_); }
+}
+
+void Model::update_transform(float lr, float sl) {
+    PROF("transform_update");
+    TransformUpdateArgs a{};
+    a.T = T_.p; a.b = b_.p; a.gT = gT_.p; a.gb = gb_.p;
+    a.s0T = s0T_.p; a.s0b = s0b_.p; a.s1T = s1T_.p; a.s1b = s1b_.p;
+    a.nT = cfg_.entity_repr_size * cfg_.word_repr_size; a.nb = cfg_.entity_repr_size;
+    a.method = cfg_.update_method;
+    a.lr = lr; a.lambda = sl; a.eps = 1e-6f;
+    const double b1 = static_cast<double>(0.9f), b2 = static_cast<double>(0.999f);
+    a.one_m_b1 = static_cast<float>(1.0 - b1); a.one_m_b2 = static_cast<float>(1.0 - b2);
+    a.s_m = static_cast<float>(1.0 - 1.0 * static_cast<double>(a.one_m_b1));
+    a.s_v = static_cast<float>(1.0 - 1.0 * static_cast<double>(a.one_m_b2));
+    a.bc = adam_bc(t_transform_);
+    if (cfg_.update_method == NVSM_ADAM) t_transform_ += 1;
+    launch_transform_update(a, stream_);
+}
+
+void Model::update(float lr, float scaled_lambda) {
+    if (!have_grads_) throw Error(NVSM_ERR_STATE, "update requires compute_gradients");
+    if (lr < 0.f || scaled_lambda < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");   // storage.cu:62-63
+    NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    update_entities(lr, scaled_lambda);
+    update_words(lr, scaled_lambda);
+    update_transform(lr, scaled_lambda);
+    have_grads_ = false;      // gradients are consumed (the reference's optimisers overwrite them too)
+}
+
+void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, float* cost) {
+    compute_cost(batch, entity_ids);
+    compute_gradients();
+    update(lr, scaled_regularization_lambda());
+    if (cost) *cost = get_cost();
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameter / tensor access
+// ---------------------------------------------------------------------------------------------
+Model::ParamRef Model::find_param(const std::string& name) {
+    auto tab = [&](TableState& t, const std::string& sub) -> ParamRef {
+        if (sub == "representations") return {t.P.p, static_cast<int64_t>(t.P.n)};
+        if (sub == "m") return {t.m.p, static_cast<int64_t>(t.m.n)};
+        if (sub == "v") {
+            if (t.vfull.p) return {t.vfull.p, static_cast<int64_t>(t.vfull.n)};
+            if (cfg_.update_method == NVSM_ADAM) return {t.sc[t.sc_cur].p, static_cast<int64_t>(t.sc[t.sc_cur].n)};
+        }
+        if (sub == "a" && cfg_.update_method == NVSM_ADAGRAD) return {t.sc[t.sc_cur].p, static_cast<int64_t>(t.sc[t.sc_cur].n)};
+        return {nullptr, 0};
+    };
+    if (name == "word_representations-representations") return tab(words_, "representations");
+    if (name == "entity_representations-representations") return tab(ents_, "representations");
+    if (name == "word_entity_mapping-transform") return {T_.p, static_cast<int64_t>(T_.n)};
+    if (name == "word_entity_mapping-bias") return {b_.p, static_cast<int64_t>(b_.n)};
+    if (name.rfind("word_representations/", 0) == 0) return tab(words_, name.substr(21));
+    if (name.rfind("entity_representations/", 0) == 0) return tab(ents_, name.substr(23));
+    if (name == "word_entity_mapping/s0_transform") return {s0T_.p, static_cast<int64_t>(s0T_.n)};
+    if (name == "word_entity_mapping/s0_bias") return {s0b_.p, static_cast<int64_t>(s0b_.n)};
+    if (name == "word_entity_mapping/s1_transform") return {s1T_.p, static_cast<int64_t>(s1T_.n)};
+    if (name == "word_entity_mapping/s1_bias") return {s1b_.p, static_cast<int64_t>(s1b_.n)};
+    return {nullptr, 0};
+}
+
+int64_t Model::param_size(const std::string& name) {
+    ParamRef r = find_param(name);
+    if (!r.p) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown parameter: " + name);
+    return r.n;
+}
+void Model::get_param(const std::string& name, float* dst, int64_t count) {
+    ParamRef r = find_param(name);
+    if (!r.p) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown parameter: " + name);
+    if (count != r.n) throw Error(NVSM_ERR_INVALID_ARGUMENT, "size mismatch for " + name);
+    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    NVSM_HIP_CHECK(hipMemcpy(dst, r.p, count * sizeof(float), hipMemcpyDeviceToHost));
+}
+void Model::set_param(const std::string& name, const float* src, int64_t count) {
+    ParamRef r = find_param(name);
+    if (!r.p) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown parameter: " + name);
+    if (count != r.n) throw Error(NVSM_ERR_INVALID_ARGUMENT, "size mismatch for " + name);
+    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    NVSM_HIP_CHECK(hipMemcpy(r.p, src, count * sizeof(float), hipMemcpyHostToDevice));
+}
+
+int64_t Model::tensor_size(const std::string& name) {
+    const int64_t B = B_, N = B_ * R_;
+    const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size;
+    if (name == "phrase" || name == "grad_phrase") return B * dw;
+    if (name == "pre" || name == "proj" || name == "grad_proj") return B * de;
+    if (name == "probs" || name == "multipliers" || name == "entity_ids") return N;
+    if (name == "bn_mean" || name == "bn_inv_std" || name == "grad_bias") return de;
+    if (name == "grad_transform") return static_cast<int64_t>(de) * dw;
+    if (name == "grad_entity") return N * de;
+    throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown tensor: " + name);
+}
+
+void Model::get_tensor(const std::string& name, float* dst, int64_t count) {
+    if (!have_forward_) throw Error(NVSM_ERR_STATE, "no forward result");
+    if (count != tensor_size(name)) throw Error(NVSM_ERR_INVALID_ARGUMENT, "size mismatch for " + name);
+    const bool needs_grads = name.rfind("grad_", 0) == 0;
+    if (needs_grads && !have_grads_) throw Error(NVSM_ERR_STATE, name + " requires compute_gradients (and no update since)");
+    const float* src = nullptr;
+    std::vector<float> tmp;
+    if (name == "phrase") src = phrase_.p;
+    else if (name == "pre") src = pre_.p;
+    else if (name == "proj") src = proj_.p;
+    else if (name == "probs") src = probs_.p;
+    else if (name == "multipliers") src = coef_.p;
+    else if (name == "bn_mean") src = bn_mean_.p;
+    else if (name == "bn_inv_std") src = bn_inv_std_.p;
+    else if (name == "grad_phrase") src = gphrase_.p;
+    else if (name == "grad_proj") src = dy_.p;
+    else if (name == "grad_bias") src = gb_.p;
+    else if (name == "grad_transform") src = gT_.p;
+    else if (name == "grad_entity") {
+        if (grad_entity_.n < static_cast<size_t>(count)) grad_entity_.alloc(count);
+        launch_materialize_grad_entity(coef_.p, proj_.p, B_ * R_, R_, cfg_.entity_repr_size, grad_entity_.p, stream_);
+        src = grad_entity_.p;
+    } else if (name == "entity_ids") {
+        std::vector<int> h(count);
+        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        NVSM_HIP_CHECK(hipMemcpy(h.data(), ids_.p, count * sizeof(int), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < count; ++i) dst[i] = static_cast<float>(h[i]);
+        return;
+    }
+    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    NVSM_HIP_CHECK(hipMemcpy(dst, src, count * sizeof(float), hipMemcpyDeviceToHost));
+}
+
+}  // namespace cunvsm

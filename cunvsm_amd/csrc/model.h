@@ -1,0 +1,174 @@
+// Host side of the MI355X NVSM / LSE engine: owns the parameters, optimiser state and per-step
+// workspaces in HBM and sequences the gfx950 kernels of kernels.h on one HIP stream.
+// Mirrors Model<TextEntity::Objective> (include/cuNVSM/model.h:75-131): initialize / compute_cost /
+// compute_gradients / update / get_cost, same argument meaning.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/cunvsm_amd.h"
+#include "kernels.h"
+
+namespace cunvsm {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string& what) : std::runtime_error(what), status(st) {}
+};
+
+#define NVSM_HIP_CHECK(expr)                                                                         \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            throw ::cunvsm::Error(NVSM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void alloc(size_t count, bool zero = false) {
+        release();
+        n = count;
+        if (count == 0) return;
+        NVSM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        if (zero) NVSM_HIP_CHECK(hipMemset(p, 0, count * sizeof(T)));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// RCCL entry points resolved at run time (dlopen) so that single-GPU use never loads librccl and a
+// process that already holds PyTorch's RCCL shares it.
+struct RcclApi;
+
+class Profiler {
+ public:
+    bool enabled = false;
+    void begin(const char* name, hipStream_t s);
+    void end(hipStream_t s);
+    void reset();
+    std::vector<std::string> names() const;
+    bool get(const std::string& name, double* ms, int64_t* launches);
+    ~Profiler();
+ private:
+    struct Slot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
+    std::map<std::string, Slot> slots_;
+    Slot* cur_ = nullptr;
+};
+
+struct TableState {           // one embedding table + its optimiser state + its per-step CSR workspace
+    int64_t rows = 0;
+    int dim = 0;
+    DevBuf<float> P, m, vfull, sc[2];
+    int sc_cur = 0;
+    uint64_t t = 1;           // Adam step counter (cpp/updates_adam.cu:130)
+    // CSR workspace
+    DevBuf<int> sorted_key, sorted_entry, row_begin, row_end, chunk_base, chunk_desc, num_chunks;
+    DevBuf<float> partial, partial_q;
+    DevBuf<char> sort_temp;
+    size_t sort_temp_bytes = 0;
+    int sort_bits = 1;
+    int max_chunks = 0;
+    int64_t max_entries = 0;
+};
+
+class Model {
+ public:
+    explicit Model(const nvsm_config& cfg);
+    ~Model();
+
+    void initialize(uint64_t seed);
+    uint64_t rng_get_state();
+    void rng_set_state(uint64_t s);
+
+    void compute_cost(const nvsm_batch& batch, const int64_t* entity_ids);
+    void compute_gradients();
+    void update(float lr, float scaled_lambda);
+    float get_cost();
+    float scaled_regularization_lambda() const;
+    void step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, float* cost);
+
+    int64_t param_size(const std::string& name);
+    void get_param(const std::string& name, float* dst, int64_t count);
+    void set_param(const std::string& name, const float* src, int64_t count);
+    int64_t tensor_size(const std::string& name);
+    void get_tensor(const std::string& name, float* dst, int64_t count);
+
+    void set_stream(hipStream_t s);
+    void synchronize();
+    void comm_init(const char id[128]);
+    void set_allreduce_callback(nvsm_allreduce_fn fn, void* user) { ar_fn_ = fn; ar_user_ = user; }
+
+    Profiler prof;
+    const nvsm_config& config() const { return cfg_; }
+
+ private:
+    struct ParamRef { float* p; int64_t n; };
+    ParamRef find_param(const std::string& name);
+    void build_csr(TableState& t, const int* keys, int64_t n);
+    Csr csr_of(TableState& t, int64_t n);
+    void update_entities(float lr, float sl);
+    void update_words(float lr, float sl);
+    void update_transform(float lr, float sl);
+    void allreduce_f64(double* dev, int64_t n);
+    void allreduce_f32(float* dev, int64_t n);
+    void alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entries);
+    float adam_bc(uint64_t t) const;
+
+    nvsm_config cfg_;
+    int R_;
+    hipStream_t stream_ = nullptr;
+    bool own_stream_ = false;
+    std::minstd_rand0 rng_;           // include/cuNVSM/base.h:36
+    uint64_t device_seed_ = 1, step_count_ = 0;
+
+    TableState words_, ents_;
+    DevBuf<float> T_, b_, s0T_, s0b_, s1T_, s1b_;
+    uint64_t t_transform_ = 1;
+
+    // per-step inputs
+    DevBuf<int64_t> in_words_, in_labels_, in_ids64_;
+    DevBuf<float> in_wwts_, in_instw_;
+    DevBuf<int> widx_, ids_, iota_;
+    const float* wwts_ = nullptr;     // device pointer or null
+    const float* instw_ = nullptr;
+    const int64_t* labels_dev_ = nullptr;
+    std::vector<int64_t> host_labels_, host_ids_;
+    int64_t B_ = 0;                   // instances of the current batch (this rank)
+
+    // intermediates
+    DevBuf<float> phrase_, pre_, proj_, dy_, gphrase_, coef_, probs_, pp_, msq_w_, U_, scale_w_, grad_entity_;
+    DevBuf<double> stats_fwd_, stats_bwd_;   // [2 de], [1 + 2 de] = loss | Σdy | Σdy·x̂
+    DevBuf<float> bn_mean_, bn_inv_std_, dbeta_, dgamma_;
+    DevBuf<float> gT_, gb_, gT_partial_;
+    int gemm_slabs_want_ = 128;
+
+    bool have_forward_ = false, have_grads_ = false;
+    double cost_ = 0.0;
+    bool cost_valid_ = false;
+
+    // data parallel
+    RcclApi* rccl_ = nullptr;
+    void* comm_ = nullptr;
+    nvsm_allreduce_fn ar_fn_ = nullptr;
+    void* ar_user_ = nullptr;
+    std::vector<double> ar_host_;
+};
+
+}  // namespace cunvsm

@@ -1,0 +1,396 @@
+// gfx950 kernels: batch → CSR by table row, segmented row passes (the sparse optimisers), dense
+// projection optimiser.
+//
+// The reference applies sparse gradients with one fp32 atomicAdd per (entry, element)
+// (update_repr_kernel, cpp/storage.cu:37-49: 614 MB + 891 MB of atomics per step at the NVSM config,
+// hot words serialised) and needs separate dense passes for the L2 / Adam decay. Here the batch's
+// (row, entry) pairs are radix-sorted once per table and every table row is owned by one thread
+// group, which streams the gradient rows of its entries with coalesced 16 B loads, applies the decay
+// and the optimiser's row-local formula, and writes the row once: no atomics, deterministic sums,
+// decay and update fused in a single pass over the table.
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace cunvsm {
+
+// =============================================================================================
+// CSR construction from the sorted (row key, entry) pairs
+// =============================================================================================
+__global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* __restrict__ row_begin,
+                                  int* __restrict__ row_end) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int k = key[i];
+        if (i == 0 || key[i - 1] != k) row_begin[k] = static_cast<int>(i);
+        if (i == n - 1 || key[i + 1] != k) row_end[k] = static_cast<int>(i + 1);
+    }
+}
+
+// rows with more than kChunk entries (hot words) are cut into chunks that are reduced in parallel
+__global__ void csr_chunks_kernel(const int* __restrict__ row_begin, const int* __restrict__ row_end, int64_t rows,
+                                  int* __restrict__ chunk_base, int* __restrict__ chunk_desc, int* __restrict__ num_chunks,
+                                  int max_chunks) {
+    for (int64_t r = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; r < rows;
+         r += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int b = row_begin[r], e = row_end[r];
+        const int cnt = e - b;
+        if (cnt > kChunk) {
+            const int nch = (cnt + kChunk - 1) / kChunk;
+            const int base = atomicAdd(num_chunks, nch);
+            chunk_base[r] = base;
+            for (int c = 0; c < nch && base + c < max_chunks; ++c) {
+                chunk_desc[(base + c) * 3 + 0] = static_cast<int>(r);
+                chunk_desc[(base + c) * 3 + 1] = b + c * kChunk;
+                chunk_desc[(base + c) * 3 + 2] = min(e, b + (c + 1) * kChunk);
+            }
+        }
+    }
+}
+
+void launch_csr_build(const Csr& c, hipStream_t s) {
+    (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * c.rows, s);
+    (void)hipMemsetAsync(c.row_end, 0, sizeof(int) * c.rows, s);
+    (void)hipMemsetAsync(c.num_chunks, 0, sizeof(int), s);
+    if (c.n > 0)
+        hipLaunchKernelGGL(csr_bounds_kernel, dim3(stream_grid(c.n, 256)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end);
+    hipLaunchKernelGGL(csr_chunks_kernel, dim3(stream_grid(c.rows, 256)), dim3(256), 0, s, c.row_begin, c.row_end, c.rows,
+                       c.chunk_base, c.chunk_desc, c.num_chunks, c.max_chunks);
+}
+
+// =============================================================================================
+// Segment accumulation: g = Σ coef·X[src][col..col+V), q = Σ sq, over sorted entries [begin, end)
+// =============================================================================================
+template <int V, int TABLE, bool VEC>
+__device__ __forceinline__ void accumulate_segment(const RowPassArgs& a, const int* __restrict__ sorted_entry,
+                                                   int begin, int end, int col, float (&g)[V], float& q) {
+    const bool need_q = (a.sq_src != nullptr);
+    int e = begin;
+    for (; e + 4 <= end; e += 4) {
+        uint32_t src[4];
+        float cf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t en = static_cast<uint32_t>(sorted_entry[e + u]);
+            src[u] = en / a.div;
+            if (TABLE == 0) {
+                cf[u] = a.wts ? a.wts[en] : 1.f;
+                if (need_q) q += cf[u] * a.sq_src[src[u]];
+                if (a.src_scale) cf[u] *= a.src_scale[src[u]];
+            } else {
+                cf[u] = a.coefs[en];
+                if (need_q) q += (cf[u] * cf[u]) * a.sq_src[src[u]];
+            }
+        }
+        if (VEC) {
+            float x[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ldv<V>(a.X + static_cast<size_t>(src[u]) * a.dim + col, x[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < V; ++i) g[i] += cf[u] * x[u][i];
+        }
+    }
+    for (; e < end; ++e) {
+        const uint32_t en = static_cast<uint32_t>(sorted_entry[e]);
+        const uint32_t src = en / a.div;
+        float cf;
+        if (TABLE == 0) {
+            cf = a.wts ? a.wts[en] : 1.f;
+            if (need_q) q += cf * a.sq_src[src];
+            if (a.src_scale) cf *= a.src_scale[src];
+        } else {
+            cf = a.coefs[en];
+            if (need_q) q += (cf * cf) * a.sq_src[src];
+        }
+        if (VEC) {
+            float x[V];
+            ldv<V>(a.X + static_cast<size_t>(src) * a.dim + col, x);
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] += cf * x[i];
+        }
+    }
+}
+
+// one thread group (nvec threads, one 16 B column each) per chunk of a long row
+template <int V, int TABLE, bool VEC>
+__global__ __launch_bounds__(256) void chunk_pass_kernel(Csr c, RowPassArgs a, int G, int nvec) {
+    const int gpb = blockDim.x / G;
+    const int group = threadIdx.x / G, lig = threadIdx.x - group * G;
+    if (group >= gpb) return;
+    const int nchunks = min(*c.num_chunks, c.max_chunks);
+    for (int ci = blockIdx.x * gpb + group; ci < nchunks; ci += gridDim.x * gpb) {
+        const int begin = c.chunk_desc[ci * 3 + 1], end = c.chunk_desc[ci * 3 + 2];
+        for (int cv = lig; cv < nvec; cv += G) {
+            const int col = cv * V;
+            float g[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] = 0.f;
+            float q = 0.f;
+            accumulate_segment<V, TABLE, VEC>(a, c.sorted_entry, begin, end, col, g, q);
+            if (VEC) stv<V>(c.partial + static_cast<size_t>(ci) * a.dim + col, g);
+            if (cv == 0) c.partial_q[ci] = q;
+        }
+    }
+}
+
+template <int V, int TABLE, int KIND>
+__global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int G, int nvec) {
+    constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
+    const int rpb = blockDim.x / G;
+    const int group = threadIdx.x / G, lig = threadIdx.x - group * G;
+    if (group >= rpb) return;
+    const int dim = a.dim;
+    for (int64_t row = static_cast<int64_t>(blockIdx.x) * rpb + group; row < c.rows;
+         row += static_cast<int64_t>(gridDim.x) * rpb) {
+        const int begin = c.row_begin[row], end = c.row_end[row];
+        const int cnt = end - begin;
+        if (cnt == 0 && !a.dense) continue;
+        const bool is_long = cnt > kChunk;
+        const int cbase = is_long ? c.chunk_base[row] : 0;
+        const int nch = is_long ? (cnt + kChunk - 1) / kChunk : 0;
+        for (int cv = lig; cv < nvec; cv += G) {
+            const int col = cv * V;
+            float g[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] = 0.f;
+            float q = 0.f;
+            if (is_long) {                 // sum the chunk partials in chunk order (deterministic)
+                for (int ch = 0; ch < nch; ++ch) {
+                    if (VEC) {
+                        float x[V];
+                        ldv<V>(c.partial + static_cast<size_t>(cbase + ch) * dim + col, x);
+#pragma unroll
+                        for (int i = 0; i < V; ++i) g[i] += x[i];
+                    }
+                    q += c.partial_q[cbase + ch];
+                }
+            } else if (cnt > 0) {
+                accumulate_segment<V, TABLE, VEC>(a, c.sorted_entry, begin, end, col, g, q);
+            }
+
+            const size_t off = static_cast<size_t>(row) * dim + col;
+            if (KIND == ROW_SGD) {
+                if (cnt == 0 && a.decay == 1.f) continue;
+                float p[V];
+                ldv<V>(a.P + off, p);
+#pragma unroll
+                for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * g[i];
+                stv<V>(a.P + off, p);
+            } else if (KIND == ROW_ADAGRAD_ENT) {
+                const float acc = a.sc_in[row] + q;
+                if (cv == 0) a.sc_out[row] = acc;
+                if (cnt == 0 && a.decay == 1.f) continue;
+                const float sc = 1.f / sqrtf(acc + a.eps);
+                float p[V];
+                ldv<V>(a.P + off, p);
+#pragma unroll
+                for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * (g[i] * sc);
+                stv<V>(a.P + off, p);
+            } else if (KIND == ROW_SCALAR_ACC) {
+                if (cv == 0) a.sc_out[row] = a.sc_in[row] + q;
+            } else if (KIND == ROW_ADAM_FULL) {
+                float p[V], m[V], v[V];
+                ldv<V>(a.P + off, p);
+                ldv<V>(a.m + off, m);
+                ldv<V>(a.v + off, v);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float mn = m[i] * a.s_m + a.one_m_b1 * g[i];      // updates_adam.cu:196-200
+                    mn += (-a.c_reg) * p[i];                         // :203-213
+                    float ag = g[i] + (-a.lambda) * p[i];            // :264-273
+                    ag = ag * ag;
+                    const float vn = v[i] * a.s_v + ag * a.one_m_b2; // :277-281
+                    m[i] = mn;
+                    v[i] = vn;
+                    p[i] = p[i] + ((mn / (sqrtf(vn) + a.eps)) * a.bc) * a.lr;   // :312-328 (λ = 0)
+                }
+                stv<V>(a.m + off, m);
+                stv<V>(a.v + off, v);
+                stv<V>(a.P + off, p);
+            } else {
+                // ROW_ADAM_MV / ROW_ADAM_SPARSE_ENT / ROW_ADAM_DENSE: v is one scalar per row (updates_adam.cu:126).
+                float m[V];
+                ldv<V>(a.m + off, m);
+#pragma unroll
+                for (int i = 0; i < V; ++i) m[i] = m[i] * a.s_m + a.one_m_b1 * g[i];
+                stv<V>(a.m + off, m);
+                const float vn = a.sc_in[row] * a.s_v + a.one_m_b2 * q;
+                if (cv == 0) a.sc_out[row] = vn;
+                if (KIND == ROW_ADAM_SPARSE_ENT) {
+                    if (cnt == 0 && a.decay == 1.f) continue;
+                    const float denom = sqrtf(vn) + a.eps;
+                    const float fc = static_cast<float>(cnt);
+                    float p[V];
+                    ldv<V>(a.P + off, p);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + (a.lr * fc) * ((a.bc * m[i]) / denom);
+                    stv<V>(a.P + off, p);
+                } else if (KIND == ROW_ADAM_DENSE) {
+                    const float denom = sqrtf(vn) + a.eps;
+                    float p[V];
+                    ldv<V>(a.P + off, p);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + ((m[i] / denom) * a.bc) * a.lr;
+                    stv<V>(a.P + off, p);
+                }
+            }
+        }
+    }
+}
+
+static void group_geometry(int dim, int& V, int& nvec, int& G) {
+    V = (dim % 4 == 0) ? 4 : 1;
+    nvec = dim / V;
+    G = nvec < 256 ? nvec : 256;
+}
+
+template <int V, int TABLE>
+static void chunk_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nvec, hipStream_t s) {
+    const int gpb = 256 / G;
+    const int grid = (c.max_chunks + gpb - 1) / gpb;
+    if (a.kind == ROW_SCALAR_ACC)
+        hipLaunchKernelGGL((chunk_pass_kernel<V, TABLE, false>), dim3(grid), dim3(256), 0, s, c, a, G, nvec);
+    else
+        hipLaunchKernelGGL((chunk_pass_kernel<V, TABLE, true>), dim3(grid), dim3(256), 0, s, c, a, G, nvec);
+}
+
+void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s) {
+    if (c.n <= 0 || c.max_chunks <= 0) return;
+    int V, nvec, G;
+    group_geometry(a.dim, V, nvec, G);
+    if (V == 4) { if (a.table == 0) chunk_pass_dispatch<4, 0>(c, a, G, nvec, s); else chunk_pass_dispatch<4, 1>(c, a, G, nvec, s); }
+    else        { if (a.table == 0) chunk_pass_dispatch<1, 0>(c, a, G, nvec, s); else chunk_pass_dispatch<1, 1>(c, a, G, nvec, s); }
+}
+
+template <int V, int TABLE>
+static void row_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nvec, hipStream_t s) {
+    const int rpb = 256 / G;
+    int64_t blocks = (c.rows + rpb - 1) / rpb;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+#define NVSM_ROW_CASE(K) case K: hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K>), grid, block, 0, s, c, a, G, nvec); break;
+    switch (a.kind) {
+        NVSM_ROW_CASE(ROW_SGD)
+        NVSM_ROW_CASE(ROW_ADAGRAD_ENT)
+        NVSM_ROW_CASE(ROW_ADAM_MV)
+        NVSM_ROW_CASE(ROW_ADAM_SPARSE_ENT)
+        NVSM_ROW_CASE(ROW_ADAM_DENSE)
+        NVSM_ROW_CASE(ROW_ADAM_FULL)
+        NVSM_ROW_CASE(ROW_SCALAR_ACC)
+        default: break;
+    }
+#undef NVSM_ROW_CASE
+}
+
+void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s) {
+    if (c.rows <= 0) return;
+    int V, nvec, G;
+    group_geometry(a.dim, V, nvec, G);
+    if (V == 4) { if (a.table == 0) row_pass_dispatch<4, 0>(c, a, G, nvec, s); else row_pass_dispatch<4, 1>(c, a, G, nvec, s); }
+    else        { if (a.table == 0) row_pass_dispatch<1, 0>(c, a, G, nvec, s); else row_pass_dispatch<1, 1>(c, a, G, nvec, s); }
+}
+
+// =============================================================================================
+// window > 1 per-example passes
+// =============================================================================================
+// scale[b] = 1 / sqrt(mean_j acc[idx[b,j]] + ε)      (adagrad_update_kernel, cpp/updates_adagrad.cu:83-97)
+__global__ void adagrad_scale_kernel(const float* __restrict__ acc, const int* __restrict__ idx, int window, int64_t B,
+                                     float eps, float* __restrict__ scale) {
+    for (int64_t b = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; b < B;
+         b += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < window; ++j) s += acc[idx[b * window + j]];
+        s /= static_cast<float>(window);
+        scale[b] = 1.f / sqrtf(s + eps);
+    }
+}
+void launch_adagrad_scale(const float* acc, const int* idx, int window, int64_t B, float eps, float* scale, hipStream_t s) {
+    if (B > 0) hipLaunchKernelGGL(adagrad_scale_kernel, dim3(stream_grid(B, 256)), dim3(256), 0, s, acc, idx, window, B, eps, scale);
+}
+
+// U[b] = bc · mean_j m[idx[b,j]] / (sqrt(mean_j v[idx[b,j]]) + ε)      (adam_sparse_update_kernel, cpp/updates_adam.cu:132-151)
+template <int V>
+__global__ __launch_bounds__(256) void adam_u_kernel(const float* __restrict__ m, const float* __restrict__ v, int dim,
+                                                     const int* __restrict__ idx, int window, uint32_t total, uint32_t nvec,
+                                                     float bc, float eps, float* __restrict__ U) {
+    const float fw = static_cast<float>(window);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        const uint32_t b = q / nvec;
+        const uint32_t c = (q - b * nvec) * V;
+        const int* ip = idx + static_cast<size_t>(b) * window;
+        float am[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) am[i] = 0.f;
+        float av = 0.f;
+        for (int j = 0; j < window; ++j) {
+            const size_t row = static_cast<size_t>(ip[j]);
+            float x[V];
+            ldv<V>(m + row * dim + c, x);
+#pragma unroll
+            for (int i = 0; i < V; ++i) am[i] += x[i];
+            av += v[row];
+        }
+        av /= fw;
+        const float denom = sqrtf(av) + eps;
+#pragma unroll
+        for (int i = 0; i < V; ++i) am[i] = bc * (am[i] / fw) / denom;
+        stv<V>(U + static_cast<size_t>(b) * dim + c, am);
+    }
+}
+void launch_adam_u(const float* m, const float* v, int dim, const int* idx, int window, int64_t B, float bc, float eps,
+                   float* U, hipStream_t s) {
+    if (B <= 0) return;
+    if (dim % 4 == 0) {
+        const uint32_t nvec = dim / 4, total = static_cast<uint32_t>(B * nvec);
+        hipLaunchKernelGGL(adam_u_kernel<4>, dim3(stream_grid(total, 256)), dim3(256), 0, s, m, v, dim, idx, window, total, nvec, bc, eps, U);
+    } else {
+        const uint32_t nvec = dim, total = static_cast<uint32_t>(B * nvec);
+        hipLaunchKernelGGL(adam_u_kernel<1>, dim3(stream_grid(total, 256)), dim3(256), 0, s, m, v, dim, idx, window, total, nvec, bc, eps, U);
+    }
+}
+
+// =============================================================================================
+// Dense projection optimiser: one launch over the nT + nb scalars of (T, b).
+// Quirks reproduced: Adam folds L2 into the gradient for T only
+// (include/cuNVSM/updates.h:39-62); the bias slot of every TransformStorage::update hard-codes λ = 0
+// (cpp/storage.cu:223-227) so the Adam bias moments never decay; SGD/Adagrad decay T by (1 − λ·lr).
+// =============================================================================================
+__global__ void transform_update_kernel(TransformUpdateArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nT + a.nb) return;
+    const bool is_bias = i >= a.nT;
+    float* P = is_bias ? a.b + (i - a.nT) : a.T + i;
+    float* G = is_bias ? a.gb + (i - a.nT) : a.gT + i;
+    float g = *G;
+    float p = *P;
+    if (a.method == 0) {                                             // SGD  (updates.cu:24-34)
+        const float dec = is_bias ? 1.f : static_cast<float>(1.0 - static_cast<double>(a.lambda) * static_cast<double>(a.lr));
+        *P = p * dec + g * a.lr;
+    } else if (a.method == 1) {                                      // Adagrad (updates_adagrad.cu:33-70)
+        float* A = is_bias ? a.s0b + (i - a.nT) : a.s0T + i;
+        const float acc = *A * 1.f + (g * g) * 1.f;
+        *A = acc;
+        g = g / sqrtf(acc + a.eps);
+        *G = g;
+        const float dec = is_bias ? 1.f : static_cast<float>(1.0 - static_cast<double>(a.lambda) * static_cast<double>(a.lr));
+        *P = p * dec + g * a.lr;
+    } else {                                                         // Adam (updates_adam.cu:46-105)
+        float* M = is_bias ? a.s0b + (i - a.nT) : a.s0T + i;
+        float* Vv = is_bias ? a.s1b + (i - a.nT) : a.s1T + i;
+        if (!is_bias) g += (-a.lambda) * p;                          // apply_regularization: T only
+        const float m = *M * (is_bias ? 1.f : a.s_m) + g * a.one_m_b1;
+        const float v = *Vv * (is_bias ? 1.f : a.s_v) + (g * g) * a.one_m_b2;
+        *M = m;
+        *Vv = v;
+        g = (m * a.bc) / (sqrtf(v) + a.eps);
+        *G = g;
+        *P = p * 1.f + g * a.lr;
+    }
+}
+
+void launch_transform_update(const TransformUpdateArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(transform_update_kernel, dim3(ceil_div(a.nT + a.nb, 256)), dim3(256), 0, s, a);
+}
+
+}  // namespace cunvsm

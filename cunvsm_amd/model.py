@@ -1,0 +1,218 @@
+"""Host-side mirror of ``Model<TextEntity::Objective>`` and ``TextEntity::Batch`` over the C ABI.
+
+Same method names and argument meaning as the reference (include/cuNVSM/model.h:97-115):
+``initialize``, ``compute_cost``, ``compute_gradients``, ``update``, ``get_cost``; the forward result
+and the gradients live inside the handle (the reference returns owning pointers, cpp/main.cu:405-411).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import NvsmBatch, NvsmConfig, check, lib
+
+# --update_method of the reference CLI (cpp/main.cu:479-485)
+UPDATE_METHODS = {
+    "sgd": (_lib.SGD, _lib.ADAM_NONE),
+    "adagrad": (_lib.ADAGRAD, _lib.ADAM_NONE),
+    "sparse_adam": (_lib.ADAM, _lib.ADAM_SPARSE),
+    "dense_adam": (_lib.ADAM, _lib.ADAM_DENSE_UPDATE),
+    "full_adam": (_lib.ADAM, _lib.ADAM_DENSE_UPDATE_DENSE_VARIANCE),
+}
+NONLINEARITIES = {"tanh": _lib.TANH, "hard_tanh": _lib.HARD_TANH}      # cpp/main.cu:487-490
+
+PARAM_NAMES = (
+    "word_representations-representations",
+    "entity_representations-representations",
+    "word_entity_mapping-transform",
+    "word_entity_mapping-bias",
+)
+
+
+def default_config(**overrides):
+    """nvsm_config with the reference CLI defaults, then keyword overrides.
+    ``update_method`` / ``nonlinearity`` accept the CLI strings."""
+    cfg = NvsmConfig()
+    lib().nvsm_config_default(C.byref(cfg))
+    for k, v in overrides.items():
+        if k == "update_method" and isinstance(v, str):
+            cfg.update_method, cfg.adam_mode = UPDATE_METHODS[v]
+        elif k == "nonlinearity" and isinstance(v, str):
+            cfg.nonlinearity = NONLINEARITIES[v]
+        else:
+            if not hasattr(cfg, k):
+                raise AttributeError("nvsm_config has no field %r" % k)
+            setattr(cfg, k, int(v) if isinstance(v, (bool, np.bool_)) else v)
+    return cfg
+
+
+class Batch:
+    """TextEntity::Batch (include/cuNVSM/data.h:114-177): features [B*w] int64, feature_weights [B*w] float,
+    labels [B] int64, weights [B] float. Arrays may be numpy (host) or torch CUDA tensors (already in HBM)."""
+
+    def __init__(self, features, labels, feature_weights=None, weights=None):
+        self.features, self.labels = features, labels
+        self.feature_weights, self.weights = feature_weights, weights
+        self.on_device = hasattr(features, "data_ptr")
+        if self.on_device:
+            import torch
+            assert features.dtype == torch.int64 and labels.dtype == torch.int64
+            for t in (feature_weights, weights):
+                assert t is None or t.dtype == torch.float32
+            self.num_instances = int(labels.numel())
+        else:
+            self.features = np.ascontiguousarray(features, dtype=np.int64)
+            self.labels = np.ascontiguousarray(labels, dtype=np.int64)
+            if feature_weights is not None:
+                self.feature_weights = np.ascontiguousarray(feature_weights, dtype=np.float32)
+            if weights is not None:
+                self.weights = np.ascontiguousarray(weights, dtype=np.float32)
+            self.num_instances = int(self.labels.size)
+
+    def _ptr(self, a):
+        if a is None:
+            return None
+        return a.data_ptr() if self.on_device else a.ctypes.data
+
+    def as_struct(self):
+        return NvsmBatch(self._ptr(self.features), self._ptr(self.feature_weights), self._ptr(self.labels),
+                         self._ptr(self.weights), self.num_instances, int(self.on_device))
+
+
+class Model:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib().nvsm_create(C.byref(cfg), C.byref(self._h)))
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().nvsm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- Model::initialize(RNG*) ------------------------------------------------------------------
+    def initialize(self, seed):
+        check(lib().nvsm_initialize(self._h, seed))
+
+    @property
+    def rng_state(self):
+        s = C.c_uint64()
+        check(lib().nvsm_rng_get_state(self._h, C.byref(s)))
+        return s.value
+
+    @rng_state.setter
+    def rng_state(self, s):
+        check(lib().nvsm_rng_set_state(self._h, s))
+
+    # -- the step ----------------------------------------------------------------------------------
+    def compute_cost(self, batch, entity_ids=None):
+        ids = None
+        if entity_ids is not None:
+            ids = np.ascontiguousarray(entity_ids, dtype=np.int64)
+            assert ids.size == batch.num_instances * (self.cfg.num_random_entities + 1)
+        st = batch.as_struct()
+        self._keep = (batch, ids)
+        check(lib().nvsm_compute_cost(self._h, C.byref(st), None if ids is None else ids.ctypes.data))
+
+    def compute_gradients(self):
+        check(lib().nvsm_compute_gradients(self._h))
+
+    def update(self, learning_rate, scaled_regularization_lambda=None):
+        if scaled_regularization_lambda is None:
+            scaled_regularization_lambda = self.scaled_regularization_lambda()
+        check(lib().nvsm_update(self._h, learning_rate, scaled_regularization_lambda))
+
+    def get_cost(self):
+        c = C.c_float()
+        check(lib().nvsm_get_cost(self._h, C.byref(c)))
+        return c.value
+
+    def scaled_regularization_lambda(self):
+        return lib().nvsm_scaled_regularization_lambda(self._h)
+
+    def step(self, batch, learning_rate, entity_ids=None, want_cost=False):
+        ids = None
+        if entity_ids is not None:
+            ids = np.ascontiguousarray(entity_ids, dtype=np.int64)
+        st = batch.as_struct()
+        self._keep = (batch, ids)
+        c = C.c_float()
+        check(lib().nvsm_step(self._h, C.byref(st), None if ids is None else ids.ctypes.data, learning_rate,
+                              C.byref(c) if want_cost else None))
+        return c.value if want_cost else None
+
+    # -- parameters / tensors ----------------------------------------------------------------------
+    def get_param(self, name):
+        n = C.c_int64()
+        check(lib().nvsm_param_size(self._h, name.encode(), C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        check(lib().nvsm_get_param(self._h, name.encode(), out.ctypes.data, n.value))
+        return out
+
+    def set_param(self, name, value):
+        v = np.ascontiguousarray(value, dtype=np.float32).ravel()
+        check(lib().nvsm_set_param(self._h, name.encode(), v.ctypes.data, v.size))
+
+    def get_data(self):
+        """ModelBase::get_data() (cpp/model.cu:64-93): the four tensors the HDF5 writer dumps."""
+        return {n: self.get_param(n) for n in PARAM_NAMES}
+
+    def get_tensor(self, name):
+        n = C.c_int64()
+        check(lib().nvsm_tensor_size(self._h, name.encode(), C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        check(lib().nvsm_get_tensor(self._h, name.encode(), out.ctypes.data, n.value))
+        return out
+
+    # -- runtime -----------------------------------------------------------------------------------
+    def synchronize(self):
+        check(lib().nvsm_synchronize(self._h))
+
+    def set_stream(self, stream_ptr):
+        check(lib().nvsm_set_stream(self._h, stream_ptr))
+
+    def comm_init(self, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(lib().nvsm_comm_init(self._h, buf))
+
+    def set_allreduce_callback(self, fn):
+        """fn(numpy float64 array) must sum the array in place across ranks."""
+        def tramp(ptr, n, _user):
+            try:
+                fn(np.ctypeslib.as_array(ptr, shape=(n,)))
+                return 0
+            except Exception:  # pragma: no cover
+                return 1
+        self._cb = _lib.ALLREDUCE_FN(tramp)
+        check(lib().nvsm_set_allreduce_callback(self._h, self._cb, None))
+
+    def profile_enable(self, on=True):
+        check(lib().nvsm_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        check(lib().nvsm_profile_reset(self._h))
+
+    def profile(self):
+        """{kernel name: (total_ms, launches)} measured with HIP events on the model's stream."""
+        buf = C.create_string_buffer(1 << 14)
+        check(lib().nvsm_profile_names(self._h, buf, len(buf)))
+        names = [n.decode() for n in buf.raw.split(b"\0\0")[0].split(b"\0") if n]
+        out = {}
+        for n in names:
+            ms, cnt = C.c_double(), C.c_int64()
+            check(lib().nvsm_profile_get(self._h, n.encode(), C.byref(ms), C.byref(cnt)))
+            out[n] = (ms.value, cnt.value)
+        return out
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib().nvsm_comm_unique_id(buf))
+    return buf.raw

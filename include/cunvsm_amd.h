@@ -1,0 +1,185 @@
+/*
+ * cunvsm_amd — C ABI of the MI355X-native NVSM / LSE training hot path.
+ *
+ * Drop-in boundary for cuNVSM's `Model<TextEntity::Objective>` (include/cuNVSM/model.h:75-131):
+ * the per-batch compute_cost → compute_gradients → update → get_cost sequence driven by
+ * iterate_data (cpp/main.cu:400-444) and ModelTest::train (include/cuNVSM/tests_base_cuda.h:161-190).
+ * Plain pointers and sizes only; the library owns every device-side object, the caller owns its
+ * host buffers; nothing but the opaque handle crosses the boundary. Every entry point returns an
+ * nvsm_status (0 = OK) instead of aborting (the reference CHECK()s / LOG(FATAL)s).
+ *
+ * Layouts are the reference's raw buffers:
+ *   embedding tables   [num_objects][dim] row-major  (device_matrix dim x n, column-major)
+ *   projection         entity_dim x word_dim column-major: T[r + entity_dim * c]
+ *   bias               [entity_dim]
+ *   indices            int64 (include/cuNVSM/base.h:28  `typedef long int32`)
+ *   floating point     float32 (release build, cpp/CMakeLists.txt:17)
+ */
+#ifndef CUNVSM_AMD_H
+#define CUNVSM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nvsm_model nvsm_model;
+
+typedef enum {
+    NVSM_OK = 0,
+    NVSM_ERR_INVALID_ARGUMENT = 1,
+    NVSM_ERR_UNSUPPORTED = 2,      /* configuration outside the hot-path scope (e.g. l2 normalisers) */
+    NVSM_ERR_DEVICE = 3,           /* HIP / RCCL error, see nvsm_last_error() */
+    NVSM_ERR_STATE = 4,            /* call sequence violated (e.g. compute_gradients before compute_cost) */
+    NVSM_ERR_NO_DEVICE = 5         /* no MI355X visible: there is NO CPU fallback */
+} nvsm_status;
+
+/* proto/nvsm.proto:11-14 (ModelDesc.TransformDesc.Nonlinearity) */
+enum { NVSM_TANH = 0, NVSM_HARD_TANH = 1 };
+/* proto/nvsm.proto:40-44 (TrainConfig.UpdateMethod) */
+enum { NVSM_SGD = 0, NVSM_ADAGRAD = 1, NVSM_ADAM = 2 };
+/* proto/nvsm.proto:50-55 (AdamConf.AdamMode); NONE behaves as SPARSE (cpp/updates_adam.cu:289,332) */
+enum { NVSM_ADAM_NONE = 0, NVSM_ADAM_SPARSE = 1, NVSM_ADAM_DENSE_UPDATE = 2, NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE = 3 };
+/* negative sampling: F2, cpp/objective.cu:5-28 → cpp/labels.cu:4-22 */
+enum {
+    NVSM_SAMPLER_HOST_MINSTD = 0,  /* std::minstd_rand0 + fresh uniform_int_distribution<long> per draw: draw-for-draw the reference */
+    NVSM_SAMPLER_DEVICE = 1        /* counter-based hash on the GPU, same distribution (uniform over all documents) */
+};
+
+/*
+ * Replaces the constructor arguments Model(num_words, num_entities, ModelDesc, TrainConfig)
+ * (cpp/model.cu:95-103); field names follow proto/nvsm.proto:7-71.
+ */
+typedef struct {
+    int64_t num_words;
+    int64_t num_entities;
+    /* ModelDesc */
+    int32_t word_repr_size;
+    int32_t entity_repr_size;
+    int32_t batch_normalization;       /* transform_desc.batch_normalization */
+    int32_t nonlinearity;              /* transform_desc.nonlinearity */
+    int32_t clip_sigmoid;              /* forced true by the reference CLI (cpp/main.cu:645) */
+    int32_t bias_negative_samples;
+    int32_t l2_normalize_phrase_reprs; /* must be 0: NVSM_ERR_UNSUPPORTED otherwise */
+    int32_t l2_normalize_entity_reprs; /* must be 0 */
+    /* TrainConfig */
+    int32_t window_size;
+    int32_t num_random_entities;
+    float   regularization_lambda;
+    int32_t update_method;
+    int32_t adam_mode;
+    int32_t max_batch_size;            /* TrainConfig.batch_size: capacity of the per-step device buffers (per rank) */
+    /* runtime */
+    int32_t device;                    /* HIP device ordinal */
+    int32_t sampler;                   /* NVSM_SAMPLER_* */
+    /* data parallelism (new). world_size 1 = single GPU. */
+    int32_t world_size;
+    int32_t rank;
+    int32_t sync_batch_norm;           /* 1: global batch statistics (exact single-GPU maths); 0: per-shard */
+    int32_t reserved[5];
+} nvsm_config;
+
+/* Fills the reference CLI defaults (cpp/main.cu:15-76,637-721; scripts/functions.sh:380-399). */
+void nvsm_config_default(nvsm_config* cfg);
+
+/*
+ * Replaces TextEntity::Batch (include/cuNVSM/data.h:114-177, cpp/data.cu:8-124): four flat arrays.
+ * on_device = 0: host pointers (the reference's pinned-host batch; copied H2D asynchronously);
+ * on_device = 1: device pointers already resident in HBM (no copy).
+ */
+typedef struct {
+    const int64_t* features;          /* [num_instances * window_size] word ids */
+    const float*   feature_weights;   /* [num_instances * window_size] or NULL (= all 1.0) */
+    const int64_t* labels;            /* [num_instances] document ids */
+    const float*   weights;           /* [num_instances] or NULL (= all 1.0) */
+    int64_t        num_instances;
+    int32_t        on_device;
+} nvsm_batch;
+
+const char* nvsm_last_error(void);
+const char* nvsm_version(void);
+/* number of visible HIP devices (0 ⇒ nvsm_create fails with NVSM_ERR_NO_DEVICE) */
+int nvsm_device_count(void);
+
+/* Model::Model (cpp/model.cu:95-103) / ~Model */
+int nvsm_create(const nvsm_config* cfg, nvsm_model** out);
+void nvsm_destroy(nvsm_model* m);
+
+/* ModelBase::initialize(RNG*) (cpp/model.cu:37-43): Glorot-uniform words → entities → transform, bias = 0,
+ * drawn from std::minstd_rand0(seed) exactly as include/cuNVSM/cuda_utils.h:35-56; the same generator then
+ * feeds the host negative sampler (as `rng` does in cpp/main.cu:729-730,405). */
+int nvsm_initialize(nvsm_model* m, uint64_t seed);
+int nvsm_rng_get_state(nvsm_model* m, uint64_t* state);   /* `rng_state << *rng`  (cpp/main.cu:401-402) */
+int nvsm_rng_set_state(nvsm_model* m, uint64_t state);
+
+/* ModelBase::get_data() (cpp/model.cu:64-93) — the four tensors write_to_hdf5 dumps. Names:
+ *   "word_representations-representations"   [num_words][word_repr_size]
+ *   "entity_representations-representations" [num_entities][entity_repr_size]
+ *   "word_entity_mapping-transform"          entity_repr_size x word_repr_size, column-major
+ *   "word_entity_mapping-bias"               [entity_repr_size]
+ * nvsm_set_param is the test hook that replaces Storage::increment_parameter / initialize_with_constant
+ * (cpp/storage.cu:108-131,252-264). Optimiser state is reachable under "<param>/m", "<param>/v", "<param>/a". */
+int nvsm_param_size(nvsm_model* m, const char* name, int64_t* count);
+int nvsm_get_param(nvsm_model* m, const char* name, float* host_dst, int64_t count);
+int nvsm_set_param(nvsm_model* m, const char* name, const float* host_src, int64_t count);
+
+/* Model::compute_cost(batch, rng) (cpp/model.cu:135-143 → cpp/objective.cu:30-313).
+ * entity_ids: optional [num_instances * (num_random_entities + 1)] int64 HOST array laid out as
+ * generate_labels does ([label, neg_1..neg_k] per instance); NULL ⇒ sampled per cfg.sampler. */
+int nvsm_compute_cost(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids);
+/* Model::compute_gradients(result) (cpp/model.cu:145-152 → cpp/objective.cu:315-481) */
+int nvsm_compute_gradients(nvsm_model* m);
+/* Model::update(gradients, learning_rate, scaled_regularization_lambda) (cpp/model.cu:187-220) */
+int nvsm_update(nvsm_model* m, float learning_rate, float scaled_regularization_lambda);
+/* ForwardResult::get_cost() (cpp/intermediate_results.cu:80-124) — synchronises the stream, like the reference. */
+int nvsm_get_cost(nvsm_model* m, float* cost);
+/* ForwardResult::scaled_regularization_lambda() (cpp/intermediate_results.cu:126-129): lambda / (global) batch */
+float nvsm_scaled_regularization_lambda(nvsm_model* m);
+
+/* One iterate_data loop body (cpp/main.cu:400-444): compute_cost + compute_gradients + update with
+ * scaled lambda; fully asynchronous. cost may be NULL (no read-back, no sync). */
+int nvsm_step(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids, float learning_rate, float* cost);
+
+/* Intermediates / gradients of the last compute_cost / compute_gradients, for parity tests and the
+ * gradient checker (Parameters::get_parameter_gradient, cpp/storage.cu:133-183,264-283). Names:
+ *   "phrase" [B][dw], "pre" [B][de], "proj" [B][de], "probs" [B*R], "entity_ids" [B*R] (as float),
+ *   "bn_mean" [de], "bn_inv_std" [de], "multipliers" [B*R] (signed),
+ *   "grad_transform" (de x dw col-major), "grad_bias" [de], "grad_phrase" [B][dw], "grad_entity" [B*R][de],
+ *   "grad_proj" [B][de]. */
+int nvsm_tensor_size(nvsm_model* m, const char* name, int64_t* count);
+int nvsm_get_tensor(nvsm_model* m, const char* name, float* host_dst, int64_t count);
+
+/* Streams: all work of a handle runs on one HIP stream (the reference collapses to one stream too,
+ * cpp/model.cu:13-14). NULL stream = the handle's own stream. */
+int nvsm_set_stream(nvsm_model* m, void* hip_stream);
+int nvsm_synchronize(nvsm_model* m);
+
+/* Data parallelism over RCCL / xGMI: one all-reduce of [grad_transform | grad_bias] per
+ * step (+ two of the batch-norm statistics when sync_batch_norm). The 128-byte id is ncclUniqueId. */
+int nvsm_comm_unique_id(char id[128]);
+int nvsm_comm_init(nvsm_model* m, const char id[128]);
+/* Alternative transport for tests: the library hands a HOST double buffer to the callback, which must
+ * sum it in place across ranks (e.g. torch.distributed gloo). */
+typedef int (*nvsm_allreduce_fn)(double* host_buf, int64_t count, void* user);
+int nvsm_set_allreduce_callback(nvsm_model* m, nvsm_allreduce_fn fn, void* user);
+
+/* Per-kernel timing of the hot path, measured with HIP events on the handle's stream (bench.py's
+ * roofline leg). enable=1 records around every launch of subsequent steps (adds sync points at
+ * read-out only). nvsm_profile_get returns accumulated milliseconds and launch counts per kernel name;
+ * names are listed by nvsm_profile_names (NUL-separated, double-NUL terminated). */
+int nvsm_profile_enable(nvsm_model* m, int enable);
+int nvsm_profile_reset(nvsm_model* m);
+int nvsm_profile_names(nvsm_model* m, char* buf, int64_t buf_bytes);
+int nvsm_profile_get(nvsm_model* m, const char* kernel, double* total_ms, int64_t* launches);
+
+/* Debug / unit-test hooks for individual kernels (tests only; not part of the drop-in surface). */
+int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const float* hostB, float* hostC);
+int nvsm_debug_gather_mean(int64_t num_rows, int dim, const float* table, const int64_t* idx, const float* wts,
+                           int window, int64_t num_out, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUNVSM_AMD_H */

@@ -1,0 +1,61 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, exports every symbol the
+public header declares, and refuses to run without a GPU (no CPU fallback, no oracle in the product path)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import cunvsm_amd as ca
+from tests.conftest import ROOT, gpu_available
+
+
+def test_library_exports_every_declared_symbol():
+    ca.build_library()
+    L = ca.lib()
+    names = ca.abi_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), "libcunvsm_amd.so does not export %s" % n
+
+
+def test_version_and_defaults():
+    L = ca.lib()
+    assert b"gfx950" in L.nvsm_version()
+    cfg = ca.default_config()
+    # scripts/functions.sh:380-399 + NVSM flags (:266)
+    assert (cfg.word_repr_size, cfg.entity_repr_size, cfg.window_size) == (300, 256, 10)
+    assert cfg.batch_normalization == 1 and cfg.nonlinearity == ca.HARD_TANH and cfg.clip_sigmoid == 1
+    assert cfg.update_method == ca.ADAM and cfg.adam_mode == ca.ADAM_DENSE_UPDATE_DENSE_VARIANCE
+    assert abs(cfg.regularization_lambda - 1e-2) < 1e-9 and cfg.max_batch_size == 51200
+
+
+def test_null_arguments_are_status_codes_not_crashes():
+    L = ca.lib()
+    assert L.nvsm_create(None, None) == 1
+    assert L.nvsm_compute_gradients(None) == 1
+    assert b"null" in L.nvsm_last_error()
+
+
+@pytest.mark.skipif(gpu_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    cfg = ca.default_config(num_words=10, num_entities=10, max_batch_size=8)
+    with pytest.raises(ca.NvsmError) as e:
+        ca.Model(cfg)
+    assert e.value.status == 5          # NVSM_ERR_NO_DEVICE
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "cunvsm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                with open(os.path.join(dirpath, f), errors="ignore") as fh:
+                    src = fh.read()
+                assert not re.search(r"nvsm_oracle|from oracle|import oracle|oracle/", src), os.path.join(dirpath, f)
+
+
+def test_config_struct_matches_header_size():
+    # 2 x int64 + 19 x int32/float + 5 reserved int32 = 16 + 24*4 = 112 bytes
+    assert C.sizeof(ca.NvsmConfig) == 112
+    assert C.sizeof(ca.NvsmBatch) == 48

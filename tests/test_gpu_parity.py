@@ -1,0 +1,272 @@
+"""-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (fp32 HIP vs fp64 oracle; the reference's release build is itself fp32 + -use_fast_math with
+atomics of unspecified order):
+  forward tensors / loss   rel 2e-5
+  gradients                rel-L2 2e-4 (loss-scale independent), grad-norm rel 1e-4
+  parameters after updates rel-L2 1e-4 of the parameter *change*
+"""
+import numpy as np
+import pytest
+
+import cunvsm_amd as ca
+from oracle import nvsm_oracle as orc
+from tests.helpers import PARAMS, gpu_model, load_params, oracle_model, random_batch, random_params, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL, GRAD_TOL, UPD_TOL = 2e-5, 2e-4, 2e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# unit kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (130, 70, 45), (64, 256, 300), (300, 256, 1000), (5, 3, 2), (257, 300, 256)])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
+def test_gemm_layouts(M, N, K, layout):
+    """fp32 MFMA GEMM incl. an asymmetric operand (transposed-output bugs show up, cdna guide G9)."""
+    rs = np.random.RandomState(M * 7 + N * 3 + K + layout)
+    A = rs.uniform(-1, 1, (M, K)).astype(np.float32)
+    Bm = (rs.uniform(-1, 1, (K, N)) + np.arange(N)[None, :] * 0.01).astype(np.float32)
+    al, bl = (layout >> 1) & 1, layout & 1
+    Ah = np.ascontiguousarray(A.T if al else A)
+    Bh = np.ascontiguousarray(Bm.T if bl else Bm)
+    Cout = np.empty((M, N), np.float32)
+    ca._lib.check(ca.lib().nvsm_debug_gemm(layout, M, N, K, Ah.ctypes.data, Bh.ctypes.data, Cout.ctypes.data))
+    ref = A.astype(np.float64) @ Bm.astype(np.float64)
+    assert rel_err(Cout, ref) < 2e-6
+
+
+@pytest.mark.parametrize("split", [2, 7, 128])
+def test_gemm_split_k(split):
+    rs = np.random.RandomState(split)
+    M, N, K = 300, 256, 4096
+    A = rs.uniform(-1, 1, (K, M)).astype(np.float32)       # stored [K][M] like phrase
+    Bm = rs.uniform(-1, 1, (K, N)).astype(np.float32)
+    Cout = np.empty((M, N), np.float32)
+    ca._lib.check(ca.lib().nvsm_debug_gemm((split << 2) | 2, M, N, K, A.ctypes.data, Bm.ctypes.data, Cout.ctypes.data))
+    assert rel_err(Cout, A.T.astype(np.float64) @ Bm.astype(np.float64)) < 2e-6
+
+
+def test_gemm_identity_asymmetric():
+    M = N = K = 128
+    A = np.eye(M, dtype=np.float32)
+    Bm = np.arange(K * N, dtype=np.float32).reshape(K, N) / 1000.0
+    Cout = np.empty((M, N), np.float32)
+    ca._lib.check(ca.lib().nvsm_debug_gemm(0, M, N, K, A.ctypes.data, Bm.ctypes.data, Cout.ctypes.data))
+    np.testing.assert_array_equal(Cout, Bm)
+
+
+@pytest.mark.parametrize("dim,window,weighted", [(3, 3, False), (3, 3, True), (300, 10, True), (256, 1, False), (128, 10, True), (7, 2, True)])
+def test_gather_mean(dim, window, weighted):
+    rs = np.random.RandomState(dim + window)
+    rows, n = 50, 37
+    table = rs.uniform(-1, 1, rows * dim).astype(np.float32)
+    idx = rs.randint(0, rows, n * window).astype(np.int64)
+    w = rs.uniform(0, 2, n * window).astype(np.float32) if weighted else None
+    out = np.empty(n * dim, np.float32)
+    ca._lib.check(ca.lib().nvsm_debug_gather_mean(rows, dim, table.ctypes.data, idx.ctypes.data,
+                                                  None if w is None else w.ctypes.data, window, n, out.ctypes.data))
+    ref = orc.average_repr(table, dim, idx, w, window)
+    np.testing.assert_allclose(out, ref, rtol=2e-6, atol=1e-7)
+
+
+def test_gather_mean_reference_kat():
+    """cpp/model_tests.cu:52-123 through the HIP kernel."""
+    table = np.arange(12, dtype=np.float32)
+    idx = np.array([1, 3, 2, 0, 3, 1], np.int64)
+    w = np.array([0.5, 0.3, 0.1, 1.0, 2.0, 0.2], np.float32)
+    out = np.empty(6, np.float32)
+    ca._lib.check(ca.lib().nvsm_debug_gather_mean(4, 3, table.ctypes.data, idx.ctypes.data, None, 3, 2, out.ctypes.data))
+    np.testing.assert_allclose(out, [6, 7, 8, 4, 5, 6], rtol=1e-6)
+    ca._lib.check(ca.lib().nvsm_debug_gather_mean(4, 3, table.ctypes.data, idx.ctypes.data, w.ctypes.data, 3, 2, out.ctypes.data))
+    np.testing.assert_allclose(out, [(0.5 * 3 + 0.3 * 9 + 0.1 * 6) / 3., (0.5 * 4 + 0.3 * 10 + 0.1 * 7) / 3.,
+                                     (0.5 * 5 + 0.3 * 11 + 0.1 * 8) / 3., (0 + 2.0 * 9 + 0.2 * 3) / 3.,
+                                     (1.0 + 2.0 * 10 + 0.2 * 4) / 3., (2.0 + 2.0 * 11 + 0.2 * 5) / 3.], rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# initialisation + sampling replay the reference's RNG stream draw for draw
+# ---------------------------------------------------------------------------------------------
+def test_initialize_and_host_sampler_match_reference_rng():
+    spec = dict(num_words=40, num_entities=30, word_dim=6, entity_dim=8, window=3, num_random=4)
+    g = gpu_model(spec, 16, sampler=ca.SAMPLER_HOST_MINSTD)
+    g.initialize(7)
+    rng = orc.Rng(7)
+    o = oracle_model(spec, orc.F32)
+    o.initialize(rng)
+    for name in PARAMS:
+        np.testing.assert_array_equal(g.get_param(name), o.get(name).astype(np.float32))
+    assert g.rng_state == rng.state
+    rs = np.random.RandomState(0)
+    words, ww, labels, iw, _ = random_batch(spec, rs, 16)
+    g.compute_cost(ca.Batch(words, labels, ww, iw))
+    expect = rng.generate_labels(labels, 30, 4)
+    np.testing.assert_array_equal(g.get_tensor("entity_ids").astype(np.int64), expect)
+    assert g.rng_state == rng.state
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own end-to-end KAT (cpp/model_tests.cu:341-466) through the HIP path
+# ---------------------------------------------------------------------------------------------
+def test_transform_backward_golden(golden):
+    gd = golden("transform_backward")
+    spec = dict(num_words=gd["num_words"], num_entities=gd["num_entities"], word_dim=gd["word_dim"],
+                entity_dim=gd["entity_dim"], window=gd["window_size"], num_random=gd["num_random_entities"],
+                bias_negative_samples=True, clip_sigmoid=False, lambda_=gd["regularization_lambda"])
+    B, w = gd["batch_size"], gd["window_size"]
+    m = gpu_model(spec, B, sampler=ca.SAMPLER_HOST_MINSTD)
+    m.initialize(gd["seed"])
+    batch = ca.Batch(np.full(B * w, gd["feature_value"]), np.full(B, gd["label"]), np.ones(B * w), np.ones(B))
+    m.compute_cost(batch)
+    m.get_cost()
+    m.compute_gradients()
+    # fp32 against fp64 goldens
+    np.testing.assert_allclose(m.get_tensor("grad_transform"), gd["grad_transform"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(m.get_tensor("grad_bias"), gd["grad_bias"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(m.get_tensor("grad_phrase"), gd["grad_phrase"], rtol=5e-4, atol=2e-7)
+
+
+# ---------------------------------------------------------------------------------------------
+# forward / backward parity on random models
+# ---------------------------------------------------------------------------------------------
+SPECS = {
+    # LSE recipe shape (tanh, no BN, bias_negative_samples) — scripts/functions.sh:267
+    "lse": dict(num_words=500, num_entities=200, word_dim=128, entity_dim=256, window=10, num_random=16,
+                nonlinearity="tanh", batch_norm=False, bias_negative_samples=True, lambda_=0.01),
+    # NVSM recipe shape (hard_tanh + BN, reweighted negatives) — scripts/functions.sh:266
+    "nvsm": dict(num_words=500, num_entities=300, word_dim=300, entity_dim=256, window=10, num_random=16,
+                 nonlinearity="hard_tanh", batch_norm=True, lambda_=0.01),
+    # the gradient-check fixture of the reference (tests_base_cuda.h:196-200): tiny odd dims
+    "tiny": dict(num_words=20, num_entities=15, word_dim=3, entity_dim=4, window=3, num_random=1,
+                 nonlinearity="tanh", batch_norm=True, lambda_=0.01),
+    "tiny_odd": dict(num_words=20, num_entities=15, word_dim=5, entity_dim=7, window=2, num_random=3,
+                     nonlinearity="hard_tanh", batch_norm=False, lambda_=0.0),
+    "wide": dict(num_words=64, num_entities=64, word_dim=64, entity_dim=512, window=4, num_random=2,
+                 nonlinearity="tanh", batch_norm=True, lambda_=0.0),
+}
+for _s in SPECS.values():
+    _s["lambda"] = _s.pop("lambda_")
+
+
+def _pair(spec, B, seed, max_batch=None):
+    rs = np.random.RandomState(seed)
+    params = random_params(spec, rs)
+    o = oracle_model(spec)
+    g = gpu_model(spec, max_batch or B)
+    load_params(o, params, False)
+    load_params(g, params, True)
+    return o, g, rs
+
+
+@pytest.mark.parametrize("name,B", [("lse", 256), ("nvsm", 1024), ("tiny", 1024), ("tiny_odd", 100), ("wide", 130), ("nvsm", 1000)])
+def test_forward_backward_parity(name, B):
+    spec = SPECS[name]
+    o, g, rs = _pair(spec, B, 11)
+    words, ww, labels, iw, ids = random_batch(spec, rs, B, zipf=True)
+    o.forward(words, ww, ids, iw)
+    g.compute_cost(ca.Batch(words, labels, ww, iw), ids)
+    co, cg = o.get_cost(), g.get_cost()
+    assert abs(cg - co) <= FWD_TOL * abs(co), (cg, co)
+    for t in ("phrase", "pre", "proj", "probs"):
+        assert rel_err(g.get_tensor(t), o.get(t)) < FWD_TOL, t
+    if spec.get("batch_norm"):
+        assert rel_err(g.get_tensor("bn_inv_std"), o.get("bn_inv_std")) < FWD_TOL
+    o.backward()
+    g.compute_gradients()
+    for gt, ot in (("grad_transform", "grad_transform"), ("grad_bias", "grad_bias"), ("grad_phrase", "grad_phrase"),
+                   ("grad_entity", "grad_entity"), ("grad_proj", "grad_proj")):
+        a, b = g.get_tensor(gt), o.get(ot)
+        assert rel_err(a, b) < GRAD_TOL, (gt, rel_err(a, b))
+        assert abs(np.linalg.norm(a) - np.linalg.norm(b)) <= 1e-4 * np.linalg.norm(b), gt
+    # signed multipliers: oracle keeps |m| and negates the entity rows instead
+    R = spec["num_random"] + 1
+    sign = np.where(np.arange(B * R) % R == 0, 1.0, -1.0)
+    assert rel_err(g.get_tensor("multipliers"), o.get("multipliers") * sign) < GRAD_TOL
+
+
+@pytest.mark.parametrize("method", ["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
+@pytest.mark.parametrize("name", ["nvsm", "tiny", "lse"])
+@pytest.mark.parametrize("lam", [0.0, 0.01])
+def test_update_parity(method, name, lam):
+    """Three optimiser steps on identical batches; parameters and optimiser state must track the oracle."""
+    spec = dict(SPECS[name], update_method=method)
+    spec["lambda"] = lam
+    B = 512
+    o, g, rs = _pair(spec, B, 5)
+    lr = {"sgd": 0.1, "adagrad": 0.01}.get(method, 0.001)      # tests_base_cuda.h:117-130
+    start = {p: o.get(p).copy() for p in PARAMS}
+    for step in range(3):
+        words, ww, labels, iw, ids = random_batch(spec, rs, B, zipf=True)
+        o.forward(words, ww, ids, iw)
+        o.backward()
+        o.update(lr)
+        g.compute_cost(ca.Batch(words, labels, ww, iw), ids)
+        g.compute_gradients()
+        g.update(lr)
+        assert abs(g.get_cost() - o.get_cost()) <= 5e-5 * abs(o.get_cost()), step
+    for p in PARAMS:
+        delta = np.linalg.norm(o.get(p) - start[p])
+        err = np.linalg.norm(g.get_param(p).astype(np.float64) - o.get(p))
+        assert err <= UPD_TOL * max(delta, 1e-12) + 1e-7 * np.linalg.norm(o.get(p)), (p, err, delta)
+    if method != "sgd":
+        pairs = {"adagrad": [("word_representations/a", "words.s0"), ("entity_representations/a", "entities.s0"),
+                             ("word_entity_mapping/s0_transform", "transform.s0.transform")],
+                 }.get(method, [("word_representations/m", "words.s0"), ("entity_representations/m", "entities.s0"),
+                                ("word_representations/v", "words.s1"), ("entity_representations/v", "entities.s1"),
+                                ("word_entity_mapping/s0_bias", "transform.s0.bias"),
+                                ("word_entity_mapping/s1_transform", "transform.s1.transform")])
+        for gn, on in pairs:
+            assert rel_err(g.get_param(gn), o.get(on)) < 5e-4, gn
+
+
+def test_hot_rows_are_chunked():
+    """A handful of words receiving thousands of updates each (Zipf head): rows longer than the 128-entry
+    chunk go through the two-level reduction; result must still match the oracle."""
+    spec = dict(num_words=6, num_entities=50, word_dim=300, entity_dim=256, window=10, num_random=4,
+                nonlinearity="hard_tanh", batch_norm=True, update_method="sparse_adam")
+    spec["lambda"] = 0.01
+    B = 2048
+    o, g, rs = _pair(spec, B, 3)
+    start = {p: o.get(p).copy() for p in PARAMS}
+    for _ in range(2):
+        words, ww, labels, iw, ids = random_batch(spec, rs, B, zipf=True)
+        o.forward(words, ww, ids, iw); o.backward(); o.update(0.001)
+        g.compute_cost(ca.Batch(words, labels, ww, iw), ids); g.compute_gradients(); g.update(0.001)
+    for p in PARAMS:
+        delta = np.linalg.norm(o.get(p) - start[p])
+        assert np.linalg.norm(g.get_param(p).astype(np.float64) - o.get(p)) <= UPD_TOL * delta + 1e-7 * np.linalg.norm(o.get(p)), p
+
+
+def test_edge_cases_ragged_and_minimal():
+    """B not a multiple of anything, B = 1, k = 0 (no negatives), window = 1, NULL weights."""
+    spec = dict(num_words=30, num_entities=20, word_dim=8, entity_dim=12, window=1, num_random=0,
+                nonlinearity="tanh", batch_norm=False, bias_negative_samples=True, update_method="sgd")
+    spec["lambda"] = 0.0
+    for B in (1, 3, 65):
+        o, g, rs = _pair(spec, B, B, max_batch=65)
+        words, _, labels, _, ids = random_batch(spec, rs, B, weighted=False)
+        o.forward(words, np.ones(B), ids, np.ones(B))
+        g.compute_cost(ca.Batch(words, labels), ids)          # NULL feature_weights / weights = 1.0
+        assert abs(g.get_cost() - o.get_cost()) <= FWD_TOL * abs(o.get_cost())
+        o.backward(); g.compute_gradients()
+        assert rel_err(g.get_tensor("grad_transform"), o.get("grad_transform")) < GRAD_TOL
+        o.update(0.1); g.update(0.1)
+        for p in PARAMS:
+            assert rel_err(g.get_param(p), o.get(p)) < 1e-5, p
+
+
+def test_error_behaviour():
+    spec = dict(num_words=30, num_entities=20, word_dim=8, entity_dim=12, window=2, num_random=1)
+    g = gpu_model(spec, 8)
+    with pytest.raises(ca.NvsmError) as e:
+        g.compute_gradients()
+    assert e.value.status == 4
+    with pytest.raises(ca.NvsmError) as e:
+        g.compute_cost(ca.Batch(np.zeros(2 * 9, np.int64), np.zeros(9, np.int64)))     # over capacity
+    assert e.value.status == 1
+    with pytest.raises(ca.NvsmError) as e:
+        gpu_model(dict(spec), 8, l2_normalize_phrase_reprs=1)
+    assert e.value.status == 2
+    with pytest.raises(ca.NvsmError):
+        g.initialize(0)                                                                 # cpp/main.cu:708

@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Benchmark of the NVSM training hot path on MI355X (BASELINE.json metric: n-gram windows/sec).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (compute_cost → compute_gradients → update, negatives sampled on
+device) over one synthetic batch of 51 200 windows per GPU that is already resident in HBM. Workload =
+BASELINE.json configs[1]: |V| = 50k, |D| = 100k, d_word = 300, d_doc = 256, window 10, 16 negatives,
+batch 51 200, hard_tanh + batch-norm, Adam (sparse_adam; --update-method selects the others), λ = 1e-2,
+lr = 1e-3, Zipf(1) word ids, uniform document ids, all weights 1. Weak scaling: every rank gets its own
+51 200-window batch; the dense projection gradient is all-reduced over RCCL each step.
+
+Rank 0 prints ONE JSON line. `roofline` is for the kernel group with the largest share of the step, timed
+with HIP events on the engine's stream during the timed region; `cpu_baseline` is the CPU oracle (fp32,
+OpenMP) timed on this box's host cores on a bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def zipf_ids(rs, n, size):
+    p = 1.0 / np.arange(1, n + 1)
+    p /= p.sum()
+    return rs.choice(n, size=size, p=p).astype(np.int64)
+
+
+def workload(args):
+    return dict(num_words=args.num_words, num_entities=args.num_entities, word_dim=300, entity_dim=256,
+                window=10, num_random=16, batch=args.batch)
+
+
+def algorithmic_bytes(kernel, wl, method):
+    """Algorithmic HBM bytes per launch of each kernel group (SURVEY.md §8d per-window figures
+    x the windows one launch processes). Index/weight traffic (<1 %) is excluded as in the survey."""
+    B, w, dw, de, R = wl["batch"], wl["window"], wl["word_dim"], wl["entity_dim"], wl["num_random"] + 1
+    nV, nD = wl["num_words"], wl["num_entities"]
+    F = 4
+    word_gather = B * w * dw * F              # 12 000 B / window
+    ent_gather = B * R * de * F               # 17 408 B / window
+    table = {
+        "gather_mean_words": word_gather + B * dw * F,
+        "loss_fused": ent_gather + 3 * B * de * F,
+        "gemm_fwd": None, "gemm_bwd_x": None, "gemm_bwd_T": None,
+        # row passes: gather of the gradient source rows + read/write of the table (+ state) rows
+        "row_pass_entities": ent_gather + 2 * nD * de * F * (2 if method != "sgd" else 1),
+        "row_pass_words": word_gather + 2 * nV * dw * F * (2 if method != "sgd" else 1),
+        "row_pass_words_mv": word_gather + 2 * nV * dw * F,
+        "row_pass_words_u": word_gather + 2 * nV * dw * F,
+        "adam_u_words": word_gather + B * dw * F,
+        "bn_stats": B * de * F,
+        "bn_backward": 3 * B * de * F,
+    }
+    return table.get(kernel)
+
+
+def gemm_flops(wl):
+    return 2.0 * wl["batch"] * wl["word_dim"] * wl["entity_dim"]
+
+
+def cpu_baseline(args, wl, method):
+    """Times the CPU oracle (test infrastructure, used here ONLY as the reported host baseline)."""
+    from oracle import nvsm_oracle as orc
+    from tests.helpers import METHODS
+    m, mode = METHODS[method]
+    cfg = orc.make_config(wl["num_words"], wl["num_entities"], wl["word_dim"], wl["entity_dim"], wl["window"],
+                          wl["num_random"], batch_norm=True, nonlinearity=orc.HARD_TANH, clip_sigmoid=True,
+                          lambda_=1e-2, update_method=m, adam_mode=mode)
+    model = orc.Model(cfg, orc.F32)
+    rng = orc.Rng(1)
+    model.initialize(rng)
+    rs = np.random.RandomState(1)
+    B = wl["batch"]
+    steps, warm = args.cpu_steps, 1
+    t_total = 0.0
+    for s in range(warm + steps):
+        words = zipf_ids(rs, wl["num_words"], B * wl["window"])
+        labels = rs.randint(0, wl["num_entities"], B).astype(np.int64)
+        ww = np.ones(B * wl["window"], np.float32)
+        iw = np.ones(B, np.float32)
+        t0 = time.perf_counter()
+        ids = rng.generate_labels(labels, wl["num_entities"], wl["num_random"])      # host sampling, as the reference
+        model.forward_native(words, ww, ids, iw)
+        model.backward()
+        model.update(1e-3)
+        model.get_cost()
+        dt = time.perf_counter() - t0
+        if s >= warm:
+            t_total += dt
+    return {"value": B * steps / t_total, "unit": "windows/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
+            "sample": "%d full steps (batch %d) of the fp32 OpenMP oracle after %d warm-up, incl. host negative sampling"
+                      % (steps, B, warm)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--update-method", default="sparse_adam", choices=["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
+    ap.add_argument("--batch", type=int, default=51200)
+    ap.add_argument("--num-words", type=int, default=50000)
+    ap.add_argument("--num-entities", type=int, default=100000)
+    ap.add_argument("--uniform-words", action="store_true", help="uniform instead of Zipf(1) word ids (worst case for caches)")
+    ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step (PCIe-inclusive rate)")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--read-cost-every", type=int, default=0, help="read the loss back every n steps (0 = never inside the timed region)")
+    args = ap.parse_args()
+
+    import torch
+    import cunvsm_amd as ca
+    from cunvsm_amd.model import comm_unique_id
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    wl = workload(args)
+    method = args.update_method
+    cfg = ca.default_config(num_words=wl["num_words"], num_entities=wl["num_entities"], word_repr_size=wl["word_dim"],
+                            entity_repr_size=wl["entity_dim"], window_size=wl["window"],
+                            num_random_entities=wl["num_random"], batch_normalization=1, nonlinearity="hard_tanh",
+                            clip_sigmoid=1, bias_negative_samples=0, regularization_lambda=1e-2, update_method=method,
+                            max_batch_size=wl["batch"], device=local_rank, sampler=ca.SAMPLER_DEVICE,
+                            world_size=world, rank=rank, sync_batch_norm=1)
+    model = ca.Model(cfg)
+    model.initialize(1)                     # --seed 1 (scripts/functions.sh:393); identical replicas on every rank
+    if world > 1:
+        obj = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0)
+        model.comm_init(obj[0])
+
+    # synthetic batches, resident in HBM before the timed region
+    rs = np.random.RandomState(1234 + rank)
+    B, w = wl["batch"], wl["window"]
+    pool = []
+    for _ in range(4):
+        words = (rs.randint(0, wl["num_words"], B * w).astype(np.int64) if args.uniform_words
+                 else zipf_ids(rs, wl["num_words"], B * w))
+        labels = rs.randint(0, wl["num_entities"], B).astype(np.int64)
+        if args.host_batches:
+            pool.append(ca.Batch(words, labels, np.ones(B * w, np.float32), np.ones(B, np.float32)))
+        else:
+            dev = torch.device("cuda", local_rank)
+            pool.append(ca.Batch(torch.from_numpy(words).to(dev), torch.from_numpy(labels).to(dev),
+                                 torch.ones(B * w, dtype=torch.float32, device=dev),
+                                 torch.ones(B, dtype=torch.float32, device=dev)))
+    lr = 1e-3
+
+    def sync_all():
+        model.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for s in range(args.warmup):
+        model.step(pool[s % len(pool)], lr)
+    sync_all()
+    model.profile_enable(True)
+    model.profile_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    last_cost = None
+    for s in range(args.steps):
+        want = args.read_cost_every > 0 and (s + 1) % args.read_cost_every == 0
+        c = model.step(pool[s % len(pool)], lr, want_cost=want)
+        if want:
+            last_cost = c
+    model.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_cost = model.get_cost()
+    prof = model.profile()
+    model.profile_enable(False)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = B * world * args.steps / elapsed
+        # dominant kernel group and its roofline
+        breakdown = {}
+        for k, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+            if n == 0:
+                continue
+            avg = ms / n
+            ent = {"avg_ms": round(avg, 4), "launches_per_step": round(n / args.steps, 2)}
+            ab = algorithmic_bytes(k, wl, method)
+            if ab:
+                ent["algorithmic_GBps"] = round(ab / (avg * 1e-3) / 1e9, 1)
+            if k.startswith("gemm_"):
+                ent["TFLOPs"] = round(gemm_flops(wl) / (avg * 1e-3) / 1e12, 1)
+            breakdown[k] = ent
+        dom = next((k for k in breakdown if algorithmic_bytes(k, wl, method)), None)
+        roofline = None
+        if dom:
+            ab = algorithmic_bytes(dom, wl, method)
+            avg = breakdown[dom]["avg_ms"]
+            ach = ab / (avg * 1e-3) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg}
+        out = {
+            "metric": "n-gram windows/sec (batch=51200, NVSM config)", "value": round(value, 1), "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "NVSM synthetic |V|=%d |D|=%d d_word=300 d_doc=256 window=10 neg=16 batch=%d/GPU "
+                                   "hard_tanh+BN %s lambda=1e-2 lr=1e-3 %s word ids, inputs resident in HBM, device negative sampler"
+                                   % (wl["num_words"], wl["num_entities"], B, method,
+                                      "uniform" if args.uniform_words else "Zipf(1)"),
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "update_method": method,
+                       "inputs": "host" if args.host_batches else "hbm"},
+            "roofline": roofline,
+            "kernel_breakdown": breakdown,
+            "final_cost": round(float(final_cost), 6),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, wl, method)
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

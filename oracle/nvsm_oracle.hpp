@@ -117,21 +117,51 @@ inline void init_matrix_glorot(F* data, size_t rows, size_t cols, RNG* rng) {
 // Batch normalisation — cpp/cudnn_utils.cu:82-183 (cuDNN PER_ACTIVATION training mode, γ≡1).
 // x, y: [n][dim] row-major (= reference dim x n column-major).
 // ---------------------------------------------------------------------------------------------
+// Column sums over the batch in double, accumulated per thread over contiguous row blocks and merged in
+// thread order (deterministic for a given thread count).
+template <typename Fn>
+inline void column_sums(size_t n, size_t dim, std::vector<double>* a, std::vector<double>* b2, Fn fn) {
+#ifdef _OPENMP
+    const int nt = (n * dim > (size_t(1) << 16)) ? omp_get_max_threads() : 1;
+#else
+    const int nt = 1;
+#endif
+    std::vector<std::vector<double>> la(nt, std::vector<double>(dim, 0.0)), lb(nt, std::vector<double>(dim, 0.0));
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num();
+#else
+        const int tid = 0;
+#endif
+        const size_t lo = n * tid / nt, hi = n * (tid + 1) / nt;
+        double* pa = la[tid].data();
+        double* pb = lb[tid].data();
+        for (size_t r0 = lo; r0 < hi; ++r0) fn(r0, pa, pb);
+    }
+    a->assign(dim, 0.0); b2->assign(dim, 0.0);
+    for (int t = 0; t < nt; ++t)
+        for (size_t r = 0; r < dim; ++r) { (*a)[r] += la[t][r]; (*b2)[r] += lb[t][r]; }
+}
+
 template <typename F>
 inline void bn_forward(const F* x, size_t n, size_t dim, const F* bias, F eps,
                        F* y, F* mean, F* inv_std) {
-    std::vector<double> s(dim, 0.0), s2(dim, 0.0);
-    for (size_t b = 0; b < n; ++b)
-        for (size_t r = 0; r < dim; ++r) s[r] += x[b * dim + r];
+    std::vector<double> s, s2, unused;
+    column_sums(n, dim, &s, &unused, [&](size_t b, double* pa, double*) {
+        for (size_t r = 0; r < dim; ++r) pa[r] += x[b * dim + r];
+    });
     for (size_t r = 0; r < dim; ++r) mean[r] = static_cast<F>(s[r] / n);
-    for (size_t b = 0; b < n; ++b)
+    column_sums(n, dim, &s2, &unused, [&](size_t b, double* pa, double*) {
         for (size_t r = 0; r < dim; ++r) {
             const double d = static_cast<double>(x[b * dim + r]) - mean[r];
-            s2[r] += d * d;
+            pa[r] += d * d;
         }
+    });
     for (size_t r = 0; r < dim; ++r)
         inv_std[r] = static_cast<F>(1.0 / std::sqrt(s2[r] / n + static_cast<double>(eps)));   // biased variance
-    for (size_t b = 0; b < n; ++b)
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < static_cast<int64_t>(n); ++b)
         for (size_t r = 0; r < dim; ++r)
             y[b * dim + r] = (x[b * dim + r] - mean[r]) * inv_std[r] + bias[r];
 }
@@ -141,14 +171,16 @@ inline void bn_forward(const F* x, size_t n, size_t dim, const F* bias, F eps,
 template <typename F>
 inline void bn_backward(const F* dy, const F* x, size_t n, size_t dim, const F* mean,
                         const F* inv_std, F* dx, F* grad_bias) {
-    std::vector<double> dbeta(dim, 0.0), dgamma(dim, 0.0);
-    for (size_t b = 0; b < n; ++b)
+    std::vector<double> dbeta, dgamma;
+    column_sums(n, dim, &dbeta, &dgamma, [&](size_t b, double* pa, double* pb) {
         for (size_t r = 0; r < dim; ++r) {
             const double xhat = (static_cast<double>(x[b * dim + r]) - mean[r]) * inv_std[r];
-            dbeta[r] += dy[b * dim + r];
-            dgamma[r] += static_cast<double>(dy[b * dim + r]) * xhat;
+            pa[r] += dy[b * dim + r];
+            pb[r] += static_cast<double>(dy[b * dim + r]) * xhat;
         }
-    for (size_t b = 0; b < n; ++b)
+    });
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < static_cast<int64_t>(n); ++b)
         for (size_t r = 0; r < dim; ++r) {
             const double xhat = (static_cast<double>(x[b * dim + r]) - mean[r]) * inv_std[r];
             dx[b * dim + r] = static_cast<F>(
@@ -233,13 +265,25 @@ struct RepresentationsStorage {
             for (int64_t i = 0; i < total; ++i) d[i] *= s;
         }
         for (const SparseGrad<F>& g : descs) {
-            for (size_t b = 0; b < g.num_grads; ++b)
-                for (size_t w = 0; w < g.window; ++w) {
-                    const F wt = g.weights ? g.weights[b * g.window + w] : F(1);
-                    F* row = data.data() + static_cast<size_t>(g.indices[b * g.window + w]) * dim;
-                    const F* src = g.grad + b * g.dim;
+            // Each thread owns the rows with (row % nthreads == tid) and walks the entries in order, so
+            // every row sees its contributions in exactly the serial order (deterministic, race-free).
+            const size_t total = g.num_grads * g.window;
+#pragma omp parallel if (total * dim > (size_t(1) << 16))
+            {
+#ifdef _OPENMP
+                const size_t nth = omp_get_num_threads(), tid = omp_get_thread_num();
+#else
+                const size_t nth = 1, tid = 0;
+#endif
+                for (size_t e = 0; e < total; ++e) {
+                    const size_t r = static_cast<size_t>(g.indices[e]);
+                    if (r % nth != tid) continue;
+                    const F wt = g.weights ? g.weights[e] : F(1);
+                    F* row = data.data() + r * dim;
+                    const F* src = g.grad + (e / g.window) * g.dim;
                     for (size_t t = 0; t < dim; ++t) row[t] += lr * wt * src[t];
                 }
+            }
         }
     }
 
@@ -247,7 +291,10 @@ struct RepresentationsStorage {
     template <typename GradFn>
     void update_dense(GradFn grad_at, F lr, F scaled_lambda) {
         const F s = static_cast<F>(1.0 - static_cast<double>(scaled_lambda) * static_cast<double>(lr));
-        for (size_t i = 0; i < data.size(); ++i) data[i] = data[i] * s + grad_at(i) * lr;
+        F* d = data.data();
+        const int64_t total = static_cast<int64_t>(data.size());
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < total; ++i) d[i] = d[i] * s + grad_at(static_cast<size_t>(i)) * lr;
     }
 };
 
@@ -275,7 +322,8 @@ struct RepresentationsUpdater {
     static void mean_squares(const SparseGrad<F>& g, std::vector<F>* out) {
         out->assign(g.num_grads, F(0));
         const F inv = static_cast<F>(std::exp(-std::log(static_cast<double>(g.dim))));
-        for (size_t b = 0; b < g.num_grads; ++b) {
+#pragma omp parallel for schedule(static)
+        for (int64_t b = 0; b < static_cast<int64_t>(g.num_grads); ++b) {
             F s = 0;
             for (size_t t = 0; t < g.dim; ++t) s += g.grad[b * g.dim + t] * g.grad[b * g.dim + t];
             (*out)[b] = s * inv;
@@ -300,7 +348,8 @@ struct RepresentationsUpdater {
         mean_squares(g, &avg);
         std::vector<SparseGrad<F>> avg_desc{{avg.data(), g.num_grads, 1, g.indices, g.window, g.weights}};
         s0.update(avg_desc, F(1), F(0));                                             // :153-158
-        for (size_t b = 0; b < g.num_grads; ++b) {                                   // adagrad_update_kernel :83-97
+#pragma omp parallel for schedule(static)
+        for (int64_t b = 0; b < static_cast<int64_t>(g.num_grads); ++b) {            // adagrad_update_kernel :83-97
             F agg = 0;
             for (size_t w = 0; w < g.window; ++w) agg += s0.data[static_cast<size_t>(g.indices[b * g.window + w])];
             agg /= static_cast<F>(g.window);
@@ -319,7 +368,9 @@ struct RepresentationsUpdater {
         s0.update(*descs, one_m_b1, F(1));                                           // m_t  :196-200
         if (!use_sgd_regularization) {                                               // :203-213
             const F c = static_cast<F>((1.0 - static_cast<double>(beta1)) * static_cast<double>(scaled_lambda));
-            for (size_t i = 0; i < s0.data.size(); ++i) s0.data[i] += (-c) * storage->data[i];
+            const int64_t tot = static_cast<int64_t>(s0.data.size());
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < tot; ++i) s0.data[i] += (-c) * storage->data[i];
         }
         if (mode < ADAM_DENSE_UPDATE_DENSE_VARIANCE) {                               // v_t  :216-252
             std::vector<std::vector<F>> keep(descs->size());
@@ -333,7 +384,9 @@ struct RepresentationsUpdater {
         } else {                                                                     // :253-282
             RepresentationsStorage<F> agg(s1.n, s1.dim);
             agg.update(*descs, F(1), F(0));
-            for (size_t i = 0; i < agg.data.size(); ++i) {
+            const int64_t tot = static_cast<int64_t>(agg.data.size());
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < tot; ++i) {
                 agg.data[i] += (-scaled_lambda) * storage->data[i];
                 agg.data[i] = agg.data[i] * agg.data[i];
             }
@@ -355,7 +408,8 @@ struct RepresentationsUpdater {
             if (descs->size() != 1) throw std::runtime_error("Sparse Adam currently does not implement multiple gradients.");
             SparseGrad<F>& g = descs->front();
             const size_t dim = g.dim;
-            for (size_t b = 0; b < g.num_grads; ++b) {                               // adam_sparse_update_kernel :132-151
+#pragma omp parallel for schedule(static)
+            for (int64_t b = 0; b < static_cast<int64_t>(g.num_grads); ++b) {        // adam_sparse_update_kernel :132-151
                 F agg_v = 0;
                 for (size_t w = 0; w < g.window; ++w) agg_v += s1.data[static_cast<size_t>(g.indices[b * g.window + w])];
                 agg_v /= static_cast<F>(g.window);
@@ -519,9 +573,9 @@ struct Model {
     void forward(const idx_t* w_idx, const F* w_wt, const idx_t* entity_ids, const F* inst_w, size_t B) {
         const size_t dw = cfg.word_dim, de = cfg.entity_dim, win = cfg.window;
         const size_t k = cfg.num_random, R = k + 1, N = B * R;
-        ForwardResult<F>& f = fwd;
-        f = ForwardResult<F>();
+        ForwardResult<F>& f = fwd;          // buffers are reused across steps (no 2 GB of fresh pages per step)
         f.B = B; f.window = win; f.R = R;
+        f.phrase_raw.clear(); f.phrase_norms.clear(); f.ent_raw.clear(); f.ent_norms.clear();
         f.words.assign(w_idx, w_idx + B * win);
         f.word_weights.assign(w_wt, w_wt + B * win);
         f.entity_ids.assign(entity_ids, entity_ids + N);
@@ -586,7 +640,6 @@ struct Model {
         const ForwardResult<F>& f = fwd;
         const size_t B = f.B, R = f.R, N = B * R;
         Gradients<F>& g = grads;
-        g = Gradients<F>();
         g.multipliers.resize(N); g.grad_entity.resize(N * de); g.grad_proj.assign(B * de, F(0));
         const F bsn = static_cast<F>(std::exp(-std::log(static_cast<double>(B))));                            // :354
         const F d_eps = cfg.clip_sigmoid ? F(1e-6) : F(0);                                                    // :367-368
@@ -682,7 +735,12 @@ struct Model {
             g.grad_phrase.swap(tmp);
         }
         const F inv_w = static_cast<F>(std::exp(-std::log(static_cast<double>(f.window))));                   // :471-476
-        for (size_t i = 0; i < g.grad_phrase.size(); ++i) g.grad_phrase[i] = g.grad_phrase[i] * inv_w;
+        {
+            F* gp = g.grad_phrase.data();
+            const int64_t tot = static_cast<int64_t>(g.grad_phrase.size());
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < tot; ++i) gp[i] = gp[i] * inv_w;
+        }
     }
 
     // model.cu:187-220: entities → words → transform. Gradients are consumed (modified in place).

@@ -10,6 +10,7 @@ from ._lib import (  # noqa: F401
     SAMPLER_DEVICE, SAMPLER_HOST_MINSTD, SGD, TANH, NvsmBatch, NvsmConfig, NvsmError, abi_symbols, build_library,
     device_count, lib, library_path,
 )
+from . import dp  # noqa: F401
 from .model import Batch, Model, UPDATE_METHODS, default_config  # noqa: F401
 
 __all__ = ["Model", "Batch", "default_config", "UPDATE_METHODS", "NvsmConfig", "NvsmBatch", "NvsmError", "lib",

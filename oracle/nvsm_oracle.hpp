@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <cstdint>
 #include <cstring>
 #include <random>
@@ -144,22 +145,28 @@ inline void column_sums(size_t n, size_t dim, std::vector<double>* a, std::vecto
         for (size_t r = 0; r < dim; ++r) { (*a)[r] += la[t][r]; (*b2)[r] += lb[t][r]; }
 }
 
+typedef std::function<void(double*, size_t)> AllReduce;   // in-place sum across data-parallel ranks (tests only)
+
+// n_total = number of rows the statistics span (= n, or the global batch under sync batch-norm).
 template <typename F>
 inline void bn_forward(const F* x, size_t n, size_t dim, const F* bias, F eps,
-                       F* y, F* mean, F* inv_std) {
+                       F* y, F* mean, F* inv_std, const AllReduce* ar = nullptr, size_t n_total = 0) {
+    const double nn = static_cast<double>(n_total ? n_total : n);
     std::vector<double> s, s2, unused;
     column_sums(n, dim, &s, &unused, [&](size_t b, double* pa, double*) {
         for (size_t r = 0; r < dim; ++r) pa[r] += x[b * dim + r];
     });
-    for (size_t r = 0; r < dim; ++r) mean[r] = static_cast<F>(s[r] / n);
+    if (ar) (*ar)(s.data(), dim);
+    for (size_t r = 0; r < dim; ++r) mean[r] = static_cast<F>(s[r] / nn);
     column_sums(n, dim, &s2, &unused, [&](size_t b, double* pa, double*) {
         for (size_t r = 0; r < dim; ++r) {
             const double d = static_cast<double>(x[b * dim + r]) - mean[r];
             pa[r] += d * d;
         }
     });
+    if (ar) (*ar)(s2.data(), dim);
     for (size_t r = 0; r < dim; ++r)
-        inv_std[r] = static_cast<F>(1.0 / std::sqrt(s2[r] / n + static_cast<double>(eps)));   // biased variance
+        inv_std[r] = static_cast<F>(1.0 / std::sqrt(s2[r] / nn + static_cast<double>(eps)));   // biased variance
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < static_cast<int64_t>(n); ++b)
         for (size_t r = 0; r < dim; ++r)
@@ -170,7 +177,8 @@ inline void bn_forward(const F* x, size_t n, size_t dim, const F* bias, F eps,
 // dx may alias dy.
 template <typename F>
 inline void bn_backward(const F* dy, const F* x, size_t n, size_t dim, const F* mean,
-                        const F* inv_std, F* dx, F* grad_bias) {
+                        const F* inv_std, F* dx, F* grad_bias, const AllReduce* ar = nullptr, size_t n_total = 0) {
+    const double nn = static_cast<double>(n_total ? n_total : n);
     std::vector<double> dbeta, dgamma;
     column_sums(n, dim, &dbeta, &dgamma, [&](size_t b, double* pa, double* pb) {
         for (size_t r = 0; r < dim; ++r) {
@@ -179,12 +187,13 @@ inline void bn_backward(const F* dy, const F* x, size_t n, size_t dim, const F* 
             pb[r] += static_cast<double>(dy[b * dim + r]) * xhat;
         }
     });
+    if (ar) { (*ar)(dbeta.data(), dim); (*ar)(dgamma.data(), dim); }
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < static_cast<int64_t>(n); ++b)
         for (size_t r = 0; r < dim; ++r) {
             const double xhat = (static_cast<double>(x[b * dim + r]) - mean[r]) * inv_std[r];
             dx[b * dim + r] = static_cast<F>(
-                (static_cast<double>(inv_std[r]) / n) * (n * static_cast<double>(dy[b * dim + r]) - dbeta[r] - xhat * dgamma[r]));
+                (static_cast<double>(inv_std[r]) / nn) * (nn * static_cast<double>(dy[b * dim + r]) - dbeta[r] - xhat * dgamma[r]));
         }
     for (size_t r = 0; r < dim; ++r) grad_bias[r] = static_cast<F>(dbeta[r]);
 }
@@ -265,21 +274,28 @@ struct RepresentationsStorage {
             for (int64_t i = 0; i < total; ++i) d[i] *= s;
         }
         for (const SparseGrad<F>& g : descs) {
-            // Each thread owns the rows with (row % nthreads == tid) and walks the entries in order, so
+            // Each thread owns the rows with (row % nthreads == tid) and walks ITS entries in batch order, so
             // every row sees its contributions in exactly the serial order (deterministic, race-free).
             const size_t total = g.num_grads * g.window;
-#pragma omp parallel if (total * dim > (size_t(1) << 16))
-            {
 #ifdef _OPENMP
-                const size_t nth = omp_get_num_threads(), tid = omp_get_thread_num();
+            const size_t nth = (total * dim > (size_t(1) << 16)) ? static_cast<size_t>(omp_get_max_threads()) : 1;
 #else
-                const size_t nth = 1, tid = 0;
+            const size_t nth = 1;
 #endif
-                for (size_t e = 0; e < total; ++e) {
-                    const size_t r = static_cast<size_t>(g.indices[e]);
-                    if (r % nth != tid) continue;
+            std::vector<size_t> start(nth + 1, 0);
+            std::vector<uint32_t> order(total);
+            for (size_t e = 0; e < total; ++e) start[static_cast<size_t>(g.indices[e]) % nth + 1]++;
+            for (size_t t = 0; t < nth; ++t) start[t + 1] += start[t];
+            {
+                std::vector<size_t> cur(start.begin(), start.end() - 1);
+                for (size_t e = 0; e < total; ++e) order[cur[static_cast<size_t>(g.indices[e]) % nth]++] = static_cast<uint32_t>(e);
+            }
+#pragma omp parallel for schedule(static, 1) num_threads(nth)
+            for (int64_t tid = 0; tid < static_cast<int64_t>(nth); ++tid) {
+                for (size_t q = start[tid]; q < start[tid + 1]; ++q) {
+                    const size_t e = order[q];
                     const F wt = g.weights ? g.weights[e] : F(1);
-                    F* row = data.data() + r * dim;
+                    F* row = data.data() + static_cast<size_t>(g.indices[e]) * dim;
                     const F* src = g.grad + (e / g.window) * g.dim;
                     for (size_t t = 0; t < dim; ++t) row[t] += lr * wt * src[t];
                 }
@@ -524,6 +540,9 @@ struct Model {
     TransformUpdater<F> transform_upd;
     ForwardResult<F> fwd;
     Gradients<F> grads;
+    // data-parallel test hooks: world size and an in-place cross-rank sum
+    size_t world = 1;
+    AllReduce allreduce;
 
     explicit Model(const Config& c) : cfg(c),
         words(c.num_words, c.word_dim), entities(c.num_entities, c.entity_dim),
@@ -556,7 +575,8 @@ struct Model {
                 for (size_t r = 0; r < de; ++r) p[r] += col[r] * xc;
             }
         }
-        if (bn) bn_forward(pre, B, de, bias, bn_eps, out, mean, inv_std);         // :425-428
+        if (bn) bn_forward(pre, B, de, bias, bn_eps, out, mean, inv_std,          // :425-428
+                           (world > 1 && allreduce) ? &allreduce : nullptr, B * world);
         else std::memcpy(out, pre, sizeof(F) * B * de);
         const Clip<F> clip;
         const int64_t total = static_cast<int64_t>(B * de);
@@ -625,14 +645,15 @@ struct Model {
             F s = 0;
             for (size_t j = 0; j < fwd.mass.size(); ++j) s += fwd.mass[j];
             F log_data_prob = s;
-            log_data_prob /= static_cast<F>(fwd.B);
+            if (world > 1 && allreduce) { double d = static_cast<double>(s); allreduce(&d, 1); log_data_prob = static_cast<F>(d); }
+            log_data_prob /= static_cast<F>(fwd.B * world);
             fwd.cost = -static_cast<double>(log_data_prob);
         }
         return fwd.cost;
     }
 
     // intermediate_results.cu:126-129
-    F scaled_regularization_lambda() const { return static_cast<F>(cfg.lambda) / static_cast<F>(fwd.B); }
+    F scaled_regularization_lambda() const { return static_cast<F>(cfg.lambda) / static_cast<F>(fwd.B * world); }
 
     // objective.cu:315-481 — compute_gradients; params.cu:453-535 — Transform::backward.
     void backward() {
@@ -641,7 +662,8 @@ struct Model {
         const size_t B = f.B, R = f.R, N = B * R;
         Gradients<F>& g = grads;
         g.multipliers.resize(N); g.grad_entity.resize(N * de); g.grad_proj.assign(B * de, F(0));
-        const F bsn = static_cast<F>(std::exp(-std::log(static_cast<double>(B))));                            // :354
+        const F bsn = static_cast<F>(std::exp(-std::log(static_cast<double>(B * world))));                    // :354 (global batch)
+        const AllReduce* ar = (world > 1 && allreduce) ? &allreduce : nullptr;
         const F d_eps = cfg.clip_sigmoid ? F(1e-6) : F(0);                                                    // :367-368
 #pragma omp parallel for schedule(static)
         for (int64_t b = 0; b < static_cast<int64_t>(B); ++b) {
@@ -681,9 +703,14 @@ struct Model {
         if (!cfg.batch_norm) {                                                                                // :509-514
             for (size_t b = 0; b < B; ++b)
                 for (size_t r = 0; r < de; ++r) g.grad_bias[r] += g.grad_proj[b * de + r];
+            if (ar) {
+                std::vector<double> t(g.grad_bias.begin(), g.grad_bias.end());
+                (*ar)(t.data(), t.size());
+                for (size_t r = 0; r < de; ++r) g.grad_bias[r] = static_cast<F>(t[r]);
+            }
         } else {                                                                                              // :515-521
             bn_backward(g.grad_proj.data(), f.pre.data(), B, de, f.bn_mean.data(), f.bn_inv_std.data(),
-                        g.grad_proj.data(), g.grad_bias.data());
+                        g.grad_proj.data(), g.grad_bias.data(), ar, B * world);
         }
         // ∂T = gproj · phraseᵀ — params.cu:526-531
         g.grad_transform.assign(de * dw, F(0));
@@ -714,6 +741,11 @@ struct Model {
             }
             for (int t = 0; t < nt; ++t)
                 for (size_t i = 0; i < de * dw; ++i) g.grad_transform[i] += local[t][i];
+            if (ar) {                                  // the one dense all-reduce of the data-parallel step
+                std::vector<double> t(g.grad_transform.begin(), g.grad_transform.end());
+                (*ar)(t.data(), t.size());
+                for (size_t i = 0; i < de * dw; ++i) g.grad_transform[i] = static_cast<F>(t[i]);
+            }
         }
         // gphrase = Tᵀ·gproj — objective.cu:447-456
         g.grad_phrase.assign(B * dw, F(0));

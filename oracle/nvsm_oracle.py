@@ -43,6 +43,8 @@ class OrcConfig(C.Structure):
     ]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
+
 _lib = None
 
 
@@ -71,6 +73,7 @@ def lib():
         "orc_model_forward_native": (None, [vp, vp, vp, vp, vp, i64]),
         "orc_model_get_cost": (dbl, [vp]), "orc_model_backward": (None, [vp]),
         "orc_model_update": (C.c_int, [vp, dbl, dbl]), "orc_model_scaled_lambda": (dbl, [vp]),
+        "orc_model_set_allreduce": (None, [vp, ALLREDUCE_FN, vp, C.c_int]),
         "orc_model_gradcheck": (C.c_int, [vp, vp, vp, vp, vp, i64, dbl, dbl, P(dbl), P(C.c_int)]),
         "orc_num_threads": (C.c_int, []),
         "orc_reps_create": (vp, [i64, i64, C.c_int, C.c_int, dbl, dbl, dbl, C.c_int]), "orc_reps_free": (None, [vp]),
@@ -206,6 +209,14 @@ class Model:
 
     def get_cost(self):
         return lib().orc_model_get_cost(self.h)
+
+    def set_allreduce(self, fn, world):
+        """Data-parallel test hook: fn(numpy float64 view) sums in place across `world` ranks."""
+        def tramp(ptr, n, _user):
+            fn(np.ctypeslib.as_array(ptr, shape=(n,)))
+            return 0
+        self._cb = ALLREDUCE_FN(tramp)
+        lib().orc_model_set_allreduce(self.h, self._cb, None, world)
 
     def backward(self):
         lib().orc_model_backward(self.h)

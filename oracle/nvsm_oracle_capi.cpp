@@ -62,6 +62,7 @@ struct ModelBase {
     virtual void update(double lr, double scaled_lambda) = 0;
     virtual double scaled_lambda() = 0;
     virtual int gradcheck(const idx_t*, const double*, const idx_t*, const double*, size_t, double, double, double*, int*) = 0;
+    virtual void set_allreduce(int (*fn)(double*, int64_t, void*), void* user, int world) = 0;
 };
 
 template <typename F>
@@ -98,6 +99,11 @@ struct ModelImpl : ModelBase {
         m.forward(w, static_cast<const F*>(ww), ids, static_cast<const F*>(iw), B);
     }
     double get_cost() override { return m.get_cost(); }
+    void set_allreduce(int (*fn)(double*, int64_t, void*), void* user, int world_size) override {
+        m.world = world_size > 1 ? world_size : 1;
+        if (fn) m.allreduce = [fn, user](double* p, size_t n) { if (fn(p, static_cast<int64_t>(n), user) != 0) throw std::runtime_error("allreduce failed"); };
+        else m.allreduce = nullptr;
+    }
     void backward() override { m.backward(); }
     void update(double lr, double sl) override { m.update(static_cast<F>(lr), static_cast<F>(sl)); }
     double scaled_lambda() override { return static_cast<double>(m.scaled_regularization_lambda()); }
@@ -287,6 +293,9 @@ double orc_model_get_cost(void* h) { return static_cast<ModelBase*>(h)->get_cost
 void orc_model_backward(void* h) { static_cast<ModelBase*>(h)->backward(); }
 int orc_model_update(void* h, double lr, double scaled_lambda) {
     try { static_cast<ModelBase*>(h)->update(lr, scaled_lambda); return 0; } catch (...) { return -1; }
+}
+void orc_model_set_allreduce(void* h, int (*fn)(double*, int64_t, void*), void* user, int world) {
+    static_cast<ModelBase*>(h)->set_allreduce(fn, user, world);
 }
 double orc_model_scaled_lambda(void* h) { return static_cast<ModelBase*>(h)->scaled_lambda(); }
 int orc_model_gradcheck(void* h, const idx_t* words, const double* ww, const idx_t* ids, const double* iw, int64_t B,

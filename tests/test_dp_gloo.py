@@ -1,0 +1,136 @@
+"""world_size-2 data-parallel tests.
+
+CPU (gloo): the sharding rule + the three reductions of cunvsm_amd.dp (sync batch-norm statistics, batch-norm
+backward statistics, dense projection gradient) reproduce the single-process gradients and loss EXACTLY when
+the per-rank arithmetic is the fp64 oracle — i.e. the data-parallel algorithm is the same maths as one GPU.
+GPU (-m gpu): the same check with the HIP path on both ranks (two processes sharing GPU 0, gloo as the
+transport through nvsm_set_allreduce_callback), against the single-process HIP path.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _global_problem(spec, B, seed):
+    from tests.helpers import random_batch, random_params
+    rs = np.random.RandomState(seed)
+    params = random_params(spec, rs)
+    return params, random_batch(spec, rs, B, zipf=True)
+
+
+SPEC = dict(num_words=60, num_entities=40, word_dim=12, entity_dim=8, window=3, num_random=4,
+            nonlinearity="hard_tanh", batch_norm=True, update_method="sgd")
+SPEC["lambda"] = 0.01
+SPEC_NOBN = dict(SPEC, batch_norm=False, nonlinearity="tanh", bias_negative_samples=True)
+
+
+def _worker_oracle(rank, port, spec, B, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from cunvsm_amd import dp
+    from tests.helpers import load_params, oracle_model
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
+    params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
+    w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
+    m = oracle_model(spec)
+    load_params(m, params, False)
+    m.set_allreduce(dp.torch_allreduce(dist), WORLD)
+    m.forward(w, wwt, wid, wi)
+    m.backward()
+    cost = m.get_cost()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), cost=cost, gT=m.get("grad_transform"), gb=m.get("grad_bias"),
+             gphrase=m.get("grad_phrase"), sl=m.scaled_regularization_lambda())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("spec", [SPEC, SPEC_NOBN], ids=["bn", "nobn"])
+def test_dp_equals_single_process_oracle(spec, tmp_path):
+    import torch.multiprocessing as mp
+    from tests.helpers import load_params, oracle_model
+    B = 64
+    port = _free_port()
+    mp.spawn(_worker_oracle, args=(port, spec, B, str(tmp_path)), nprocs=WORLD, join=True)
+    params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
+    ref = oracle_model(spec)
+    load_params(ref, params, False)
+    ref.forward(words, ww, ids, iw)
+    ref.backward()
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(WORLD)]
+    for k in range(WORLD):
+        np.testing.assert_allclose(r[k]["cost"], ref.get_cost(), rtol=1e-13)
+        np.testing.assert_allclose(r[k]["gT"], ref.get("grad_transform"), rtol=1e-11, atol=1e-16)
+        np.testing.assert_allclose(r[k]["gb"], ref.get("grad_bias"), rtol=1e-11, atol=1e-16)
+        np.testing.assert_allclose(r[k]["sl"], ref.scaled_regularization_lambda(), rtol=1e-15)
+    # the sparse side stays shard-local: each rank holds the gradient rows of ITS windows, scaled by 1/B_global
+    np.testing.assert_allclose(np.concatenate([r[0]["gphrase"], r[1]["gphrase"]]), ref.get("grad_phrase"), rtol=1e-10, atol=1e-16)
+
+
+def test_shard_batch_rules():
+    from cunvsm_amd import dp
+    feats, labels = np.arange(24), np.arange(8)
+    ids = np.arange(8 * 3)
+    f, l, fw, w, i = dp.shard_batch(feats, labels, None, None, ids, 3, 2, 1, 2)
+    assert list(l) == [4, 5, 6, 7] and list(f) == list(range(12, 24)) and list(i) == list(range(12, 24))
+    assert fw is None and w is None
+    with pytest.raises(ValueError):
+        dp.shard_bounds(9, 0, 2)
+
+
+def _worker_gpu(rank, port, spec, B, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import cunvsm_amd as ca
+    from cunvsm_amd import dp
+    from tests.helpers import gpu_model, load_params
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
+    params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
+    w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
+    m = gpu_model(spec, B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0)
+    load_params(m, params, True)
+    m.set_allreduce_callback(dp.torch_allreduce(dist))
+    m.compute_cost(ca.Batch(w, wl, wwt, wi), wid)
+    m.compute_gradients()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), cost=m.get_cost(), gT=m.get_tensor("grad_transform"),
+             gb=m.get_tensor("grad_bias"), gphrase=m.get_tensor("grad_phrase"), sl=m.scaled_regularization_lambda())
+    m.update(0.1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", [SPEC, SPEC_NOBN], ids=["bn", "nobn"])
+def test_dp_hip_equals_single_gpu(spec, tmp_path):
+    import torch.multiprocessing as mp
+    import cunvsm_amd as ca
+    from tests.helpers import gpu_model, load_params, rel_err
+    B = 256
+    port = _free_port()
+    mp.spawn(_worker_gpu, args=(port, spec, B, str(tmp_path)), nprocs=WORLD, join=True)
+    params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
+    ref = gpu_model(spec, B)
+    load_params(ref, params, True)
+    ref.compute_cost(ca.Batch(words, labels, ww, iw), ids)
+    ref.compute_gradients()
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(WORLD)]
+    for k in range(WORLD):
+        assert abs(r[k]["cost"] - ref.get_cost()) <= 1e-5 * abs(ref.get_cost())
+        assert rel_err(r[k]["gT"], ref.get_tensor("grad_transform")) < 1e-5
+        assert rel_err(r[k]["gb"], ref.get_tensor("grad_bias")) < 1e-5
+        assert abs(r[k]["sl"] - ref.scaled_regularization_lambda()) < 1e-12
+    assert rel_err(np.concatenate([r[0]["gphrase"], r[1]["gphrase"]]), ref.get_tensor("grad_phrase")) < 1e-5

@@ -27,11 +27,22 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const float (&x)[V]) 
     }
 }
 
-// all 64 lanes receive the sum
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// Wave64 sum on the DPP cross-lane network (no LDS round trips): inclusive scan inside each 16-lane row
+// (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 fold the four row totals into lane 63, whose value is
+// returned to every lane through an SGPR. ~6 VALU issues instead of a 6-deep ds_bpermute dependency chain.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_mov<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_mov<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_mov<0x118, 0xf>(v);   // row_shr:8
+    v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    v += dpp_mov<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {

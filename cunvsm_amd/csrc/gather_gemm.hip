@@ -76,7 +76,112 @@ struct GemmArgs {
     float alpha;
     const float* bias_n;
     int vec_a, vec_b;
+    int mtiles, ntiles, slabs, groups, members;   // see gemm_decode_block
 };
+
+// Global → register staging of one K tile (8 float4 per thread: 4 of A, 4 of B), bounds-checked, zero-filled.
+template <int ALAY, int BLAY>
+__device__ __forceinline__ void gemm_load_tile(const GemmArgs& g, int tid, int m0, int n0, int k0, int kend,
+                                               float (&ra)[4][4], float (&rb)[4][4]) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int f = tid + 256 * it;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ra[it][j] = 0.f; rb[it][j] = 0.f; }
+        if constexpr (ALAY == 0) {                     // A[M][K], k contiguous
+            const int row = f >> 3, kq = (f & 7) << 2;
+            const int gm = m0 + row, gk = k0 + kq;
+            if (gm < g.M) {
+                const float* p = g.A + static_cast<size_t>(gm) * g.lda + gk;
+                if (g.vec_a && gk + 3 < kend) {
+                    ldv<4>(p, ra[it]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gk + j < kend) ra[it][j] = p[j];
+                }
+            }
+        } else {                                       // A stored [K][M], m contiguous
+            const int kk = f >> 5, mq = (f & 31) << 2;
+            const int gk = k0 + kk, gm = m0 + mq;
+            if (gk < kend) {
+                const float* p = g.A + static_cast<size_t>(gk) * g.lda + gm;
+                if (g.vec_a && gm + 3 < g.M) {
+                    ldv<4>(p, ra[it]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gm + j < g.M) ra[it][j] = p[j];
+                }
+            }
+        }
+        if constexpr (BLAY == 0) {                     // B[K][N], n contiguous
+            const int kk = f >> 5, nq = (f & 31) << 2;
+            const int gk = k0 + kk, gn = n0 + nq;
+            if (gk < kend) {
+                const float* p = g.B + static_cast<size_t>(gk) * g.ldb + gn;
+                if (g.vec_b && gn + 3 < g.N) {
+                    ldv<4>(p, rb[it]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gn + j < g.N) rb[it][j] = p[j];
+                }
+            }
+        } else {                                       // B stored [N][K], k contiguous
+            const int row = f >> 3, kq = (f & 7) << 2;
+            const int gn = n0 + row, gk = k0 + kq;
+            if (gn < g.N) {
+                const float* p = g.B + static_cast<size_t>(gn) * g.ldb + gk;
+                if (g.vec_b && gk + 3 < kend) {
+                    ldv<4>(p, rb[it]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gk + j < kend) rb[it][j] = p[j];
+                }
+            }
+        }
+    }
+}
+
+template <int ALAY, int BLAY>
+__device__ __forceinline__ void gemm_store_tile(int tid, float* As, float* Bs, const float (&ra)[4][4], const float (&rb)[4][4]) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int f = tid + 256 * it;
+        if constexpr (ALAY == 0) {
+            const int row = f >> 3, kq = (f & 7) << 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[row * (BK + 1) + kq + j] = ra[it][j];
+        } else {
+            const int kk = f >> 5, mq = (f & 31) << 2;
+            stv<4>(As + kk * BM + mq, ra[it]);
+        }
+        if constexpr (BLAY == 0) {
+            const int kk = f >> 5, nq = (f & 31) << 2;
+            stv<4>(Bs + kk * BN + nq, rb[it]);
+        } else {
+            const int row = f >> 3, kq = (f & 7) << 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs[row * (BK + 1) + kq + j] = rb[it][j];
+        }
+    }
+}
+
+// Block → (m tile, n tile, k slab). Tiles that share an operand slab (the n tiles of one m tile; all tiles of one
+// split-K slab) get linear ids that are equal mod 8 and close together, i.e. they run at about the same time on
+// the SAME XCD (observed placement: block b → XCD b % 8), so the shared slab is fetched from HBM once and served
+// from that XCD's L2 afterwards. A different placement only costs speed.
+__device__ __forceinline__ bool gemm_decode_block(const GemmArgs& g, int& mt, int& nt, int& z) {
+    const int id = blockIdx.x;
+    const int grp = id / (8 * g.members), rem = id - grp * (8 * g.members);
+    const int member = rem >> 3, lane8 = rem & 7;
+    const int group = grp * 8 + lane8;
+    if (group >= g.groups) return false;
+    if (g.slabs > 1) {              // group = k slab, member = (m tile, n tile)
+        z = group; mt = member % g.mtiles; nt = member / g.mtiles;
+    } else {                        // group = m tile, member = n tile
+        z = 0; mt = group; nt = member;
+    }
+    return true;
+}
 
 template <int ALAY, int BLAY>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
@@ -86,14 +191,16 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     float* As = lds;
     float* Bs = lds + ((A_ELEMS + 3) & ~3);
 
+    int mt, nt, z;
+    if (!gemm_decode_block(g, mt, nt, z)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int l31 = lane & 31, lk = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * g.k_split_len;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kbeg = z * g.k_split_len;
     const int kend = min(g.K, kbeg + g.k_split_len);
-    float* __restrict__ C = g.C + blockIdx.z * g.c_split_stride;
+    float* __restrict__ C = g.C + z * g.c_split_stride;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -103,76 +210,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float ra[4][4], rb[4][4];
+    gemm_load_tile<ALAY, BLAY>(g, tid, m0, n0, kbeg, kend, ra, rb);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        // ---- stage A tile ----
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int f = tid + 256 * it;
-            float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (ALAY == 0) {                     // A[M][K], k contiguous
-                const int row = f >> 3, kq = (f & 7) << 2;
-                const int gm = m0 + row, gk = k0 + kq;
-                if (gm < g.M) {
-                    const float* p = g.A + static_cast<size_t>(gm) * g.lda + gk;
-                    if (g.vec_a && gk + 3 < kend) {
-                        ldv<4>(p, x);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (gk + j < kend) x[j] = p[j];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) As[row * (BK + 1) + kq + j] = x[j];
-            } else {                                       // A stored [K][M], m contiguous
-                const int kk = f >> 5, mq = (f & 31) << 2;
-                const int gk = k0 + kk, gm = m0 + mq;
-                if (gk < kend) {
-                    const float* p = g.A + static_cast<size_t>(gk) * g.lda + gm;
-                    if (g.vec_a && gm + 3 < g.M) {
-                        ldv<4>(p, x);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (gm + j < g.M) x[j] = p[j];
-                    }
-                }
-                stv<4>(As + kk * BM + mq, x);
-            }
-        }
-        // ---- stage B tile ----
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int f = tid + 256 * it;
-            float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (BLAY == 0) {                     // B[K][N], n contiguous
-                const int kk = f >> 5, nq = (f & 31) << 2;
-                const int gk = k0 + kk, gn = n0 + nq;
-                if (gk < kend) {
-                    const float* p = g.B + static_cast<size_t>(gk) * g.ldb + gn;
-                    if (g.vec_b && gn + 3 < g.N) {
-                        ldv<4>(p, x);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (gn + j < g.N) x[j] = p[j];
-                    }
-                }
-                stv<4>(Bs + kk * BN + nq, x);
-            } else {                                       // B stored [N][K], k contiguous
-                const int row = f >> 3, kq = (f & 7) << 2;
-                const int gn = n0 + row, gk = k0 + kq;
-                if (gn < g.N) {
-                    const float* p = g.B + static_cast<size_t>(gn) * g.ldb + gk;
-                    if (g.vec_b && gk + 3 < kend) {
-                        ldv<4>(p, x);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (gk + j < kend) x[j] = p[j];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[row * (BK + 1) + kq + j] = x[j];
-            }
-        }
+        gemm_store_tile<ALAY, BLAY>(tid, As, Bs, ra, rb);
         __syncthreads();
+        // next tile's global loads fly while this tile is multiplied
+        if (k0 + BK < kend) gemm_load_tile<ALAY, BLAY>(g, tid, m0, n0, k0 + BK, kend, ra, rb);
 
         // ---- 16 k-steps of 2; 4 MFMAs per step per wave ----
 #pragma unroll
@@ -239,7 +283,11 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
     if (g.k_split_len <= 0) g.k_split_len = BK;
     g.vec_a = (lda % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
     g.vec_b = (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
-    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, slabs);
+    g.mtiles = (M + BM - 1) / BM; g.ntiles = (N + BN - 1) / BN; g.slabs = slabs;
+    if (slabs > 1) { g.groups = slabs; g.members = g.mtiles * g.ntiles; }
+    else { g.groups = g.mtiles; g.members = g.ntiles; }
+    const int padded_groups = ((g.groups + 7) / 8) * 8;
+    dim3 grid(padded_groups * g.members);
     dim3 block(256);
     if (a_layout == 0 && b_layout == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 0>), grid, block, 0, s, g);
     else if (a_layout == 0 && b_layout == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 1>), grid, block, 0, s, g);

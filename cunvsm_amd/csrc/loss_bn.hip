@@ -126,7 +126,8 @@ void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* i
 // A block of 4 waves walks kExamplesPerWave examples per wave so that the column statistics need one
 // fp64 atomic per column per 64 examples.
 // =============================================================================================
-constexpr int kExamplesPerWave = 16;
+constexpr int kExamplesPerWave = 8;
+constexpr int kRowGroup = 4;
 
 template <int V, int NITER>
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
@@ -182,52 +183,74 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
         if (a.rebalance) w = w * a.neg_scale;                       // objective.cu:268-274
         const float w_pos = a.rebalance ? w * static_cast<float>(a.k) : w;   // :282-290
 
-        // software-pipelined stream of the R document rows
-        float e_next[NITER][V];
-        {
-            const size_t id = static_cast<size_t>(a.ids[b * R]);
+        // Stream the R document rows in groups of kRowGroup: while one group is being reduced the next
+        // group's kRowGroup independent 1 KB loads are already in flight.
+        float e_next[kRowGroup][NITER][V];
 #pragma unroll
-            for (int it = 0; it < NITER; ++it) {
-#pragma unroll
-                for (int i = 0; i < V; ++i) e_next[it][i] = 0.f;
-                if (valid[it]) ldv<V>(a.E + id * de + (it * 64 + lane) * V, e_next[it]);
-            }
-        }
-        for (int r = 0; r < R; ++r) {
-            float e[NITER][V];
+        for (int u = 0; u < kRowGroup; ++u) {
 #pragma unroll
             for (int it = 0; it < NITER; ++it)
 #pragma unroll
-                for (int i = 0; i < V; ++i) e[it][i] = e_next[it][i];
-            if (r + 1 < R) {
-                const size_t id = static_cast<size_t>(a.ids[b * R + r + 1]);
+                for (int i = 0; i < V; ++i) e_next[u][it][i] = 0.f;
+            if (u < R) {
+                const size_t id = static_cast<size_t>(a.ids[b * R + u]);
 #pragma unroll
                 for (int it = 0; it < NITER; ++it)
-                    if (valid[it]) ldv<V>(a.E + id * de + (it * 64 + lane) * V, e_next[it]);
+                    if (valid[it]) ldv<V>(a.E + id * de + (it * 64 + lane) * V, e_next[u][it]);
             }
-            float dot = 0.f;
+        }
+        for (int r0 = 0; r0 < R; r0 += kRowGroup) {
+            float e[kRowGroup][NITER][V];
 #pragma unroll
-            for (int it = 0; it < NITER; ++it)
+            for (int u = 0; u < kRowGroup; ++u)
 #pragma unroll
-                for (int i = 0; i < V; ++i) dot += out[it][i] * e[it][i];
-            dot = wave_sum(dot);
-            const float sign = (r == 0) ? 1.f : -1.f;                // objective.cu:184-187
-            const float sx = sign * dot;
-            float p = (sx >= 0.f) ? 1.f / (1.f + expf(-sx)) : expf(sx) / (1.f + expf(sx));   // cuda_utils.h:205-207
-            p = fminf(fmaxf(p, a.sig_eps), a.sig_hi);                // :209
-            const float wj = (r == 0) ? w_pos : w;
-            wave_loss += logf(p) * wj;                               // objective.cu:250-305
-            const float d = (static_cast<double>(p) >= a.d_hi || p <= a.d_eps) ? 0.f : 1.f - p;   // cuda_utils.h:229-231
-            const float m = wj * (d * a.inv_batch);                  // objective.cu:357-371
-            const float cf = sign * m;
-            if (lane == 0) {
-                a.coef[b * R + r] = cf;
-                a.probs[b * R + r] = p;
+                for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                    for (int i = 0; i < V; ++i) e[u][it][i] = e_next[u][it][i];
+#pragma unroll
+            for (int u = 0; u < kRowGroup; ++u) {
+                const int rn = r0 + kRowGroup + u;
+                if (rn < R) {
+                    const size_t id = static_cast<size_t>(a.ids[b * R + rn]);
+#pragma unroll
+                    for (int it = 0; it < NITER; ++it)
+                        if (valid[it]) ldv<V>(a.E + id * de + (it * 64 + lane) * V, e_next[u][it]);
+                }
+            }
+            float dot[kRowGroup];
+#pragma unroll
+            for (int u = 0; u < kRowGroup; ++u) {
+                float d = 0.f;
+#pragma unroll
+                for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                    for (int i = 0; i < V; ++i) d += out[it][i] * e[u][it][i];
+                dot[u] = d;
             }
 #pragma unroll
-            for (int it = 0; it < NITER; ++it)
+            for (int u = 0; u < kRowGroup; ++u) dot[u] = wave_sum(dot[u]);
 #pragma unroll
-                for (int i = 0; i < V; ++i) gp[it][i] += cf * e[it][i];   // fold_columns, :420-425
+            for (int u = 0; u < kRowGroup; ++u) {
+                const int r = r0 + u;
+                if (r >= R) break;
+                const float sign = (r == 0) ? 1.f : -1.f;                // objective.cu:184-187
+                const float sx = sign * dot[u];
+                float p = (sx >= 0.f) ? 1.f / (1.f + expf(-sx)) : expf(sx) / (1.f + expf(sx));   // cuda_utils.h:205-207
+                p = fminf(fmaxf(p, a.sig_eps), a.sig_hi);                // :209
+                const float wj = (r == 0) ? w_pos : w;
+                wave_loss += logf(p) * wj;                               // objective.cu:250-305
+                const float d = (static_cast<double>(p) >= a.d_hi || p <= a.d_eps) ? 0.f : 1.f - p;   // cuda_utils.h:229-231
+                const float m = wj * (d * a.inv_batch);                  // objective.cu:357-371
+                const float cf = sign * m;
+                if (lane == 0) {
+                    a.coef[b * R + r] = cf;
+                    a.probs[b * R + r] = p;
+                }
+#pragma unroll
+                for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                    for (int i = 0; i < V; ++i) gp[it][i] += cf * e[u][it][i];   // fold_columns, :420-425
+            }
         }
 
         // nonlinearity' on the OUTPUT (params.cu:474-491) and column statistics

@@ -105,6 +105,7 @@ struct ProfScope {
     ~ProfScope() { p.end(s); }
 };
 #define PROF(name) ProfScope _prof_scope(prof, name, stream_)
+#define PROF_ON(name, strm) ProfScope _prof_scope(prof, name, strm)
 
 // ---------------------------------------------------------------------------------------------
 static int bits_for(int64_t n) {
@@ -165,6 +166,9 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     NVSM_HIP_CHECK(hipSetDevice(cfg.device));
     NVSM_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     own_stream_ = true;
+    NVSM_HIP_CHECK(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
+    NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, hipEventDisableTiming));
+    NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, hipEventDisableTiming));
 
     const int dw = cfg.word_repr_size, de = cfg.entity_repr_size, w = cfg.window_size;
     const int64_t N = B * R_;
@@ -191,6 +195,9 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
 
 Model::~Model() {
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
+    if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
+    if (ev_csr_) (void)hipEventDestroy(ev_csr_);
     if (comm_ && rccl_) rccl_->CommDestroy(comm_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
@@ -202,7 +209,10 @@ void Model::set_stream(hipStream_t s) {
     else { NVSM_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); own_stream_ = true; }
 }
 
-void Model::synchronize() { NVSM_HIP_CHECK(hipStreamSynchronize(stream_)); }
+void Model::synchronize() {
+    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    NVSM_HIP_CHECK(hipStreamSynchronize(aux_stream_));
+}
 
 // ModelBase::initialize (cpp/model.cu:37-43) with init_matrix_glorot (include/cuNVSM/cuda_utils.h:35-56):
 // same generator, same draw order (words → entities → transform), same float expression.
@@ -343,6 +353,13 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         }
     }
     ++step_count_;
+
+    // Row-order (CSR) of both tables for the update, on the side stream: needs only the indices.
+    NVSM_HIP_CHECK(hipEventRecord(ev_inputs_, stream_));
+    NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_inputs_, 0));
+    { PROF_ON("csr_entities", aux_stream_); build_csr(ents_, ids_.p, N); }
+    { PROF_ON("csr_words", aux_stream_); build_csr(words_, widx_.p, B * w); }
+    NVSM_HIP_CHECK(hipEventRecord(ev_csr_, aux_stream_));
 
     // F3: phrase representations (objective.cu:126-130)
     { PROF("gather_mean_words"); launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, phrase_.p, stream_); }
@@ -486,8 +503,8 @@ Csr Model::csr_of(TableState& t, int64_t n) {
 }
 
 void Model::build_csr(TableState& t, const int* keys, int64_t n) {
-    sort_pairs(t.sort_temp.p, t.sort_temp_bytes, keys, t.sorted_key.p, iota_.p, t.sorted_entry.p, n, t.sort_bits, stream_);
-    launch_csr_build(csr_of(t, n), stream_);
+    sort_pairs(t.sort_temp.p, t.sort_temp_bytes, keys, t.sorted_key.p, iota_.p, t.sorted_entry.p, n, t.sort_bits, aux_stream_);
+    launch_csr_build(csr_of(t, n), aux_stream_);
 }
 
 static void fill_adam_consts(RowPassArgs& a, float bc, float sl) {
@@ -505,7 +522,6 @@ void Model::update_entities(float lr, float sl) {
     const int64_t N = B_ * R_;
     const int de = cfg_.entity_repr_size;
     TableState& t = ents_;
-    { PROF("csr_entities"); build_csr(t, ids_.p, N); }
     Csr c = csr_of(t, N);
     RowPassArgs a{};
     a.table = 1; a.X = proj_.p; a.coefs = coef_.p; a.sq_src = pp_.p; a.div = static_cast<uint32_t>(R_);
@@ -535,7 +551,6 @@ void Model::update_words(float lr, float sl) {
     const int dw = cfg_.word_repr_size, w = cfg_.window_size;
     const int64_t n = B_ * w;
     TableState& t = words_;
-    { PROF("csr_words"); build_csr(t, widx_.p, n); }
     Csr c = csr_of(t, n);
     RowPassArgs a{};
     a.table = 0; a.X = gphrase_.p; a.wts = wwts_; a.div = static_cast<uint32_t>(w);
@@ -616,6 +631,7 @@ void Model::update(float lr, float scaled_lambda) {
     if (!have_grads_) throw Error(NVSM_ERR_STATE, "update requires compute_gradients");
     if (lr < 0.f || scaled_lambda < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");   // storage.cu:62-63
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));     // join the side-stream CSR builds
     update_entities(lr, scaled_lambda);
     update_words(lr, scaled_lambda);
     update_transform(lr, scaled_lambda);

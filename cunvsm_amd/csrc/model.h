@@ -135,6 +135,10 @@ class Model {
     int R_;
     hipStream_t stream_ = nullptr;
     bool own_stream_ = false;
+    // The batch → CSR builds depend only on the indices, so they run on a side stream concurrently with the
+    // forward / backward kernels and are joined right before the row passes.
+    hipStream_t aux_stream_ = nullptr;
+    hipEvent_t ev_inputs_ = nullptr, ev_csr_ = nullptr;
     std::minstd_rand0 rng_;           // include/cuNVSM/base.h:36
     uint64_t device_seed_ = 1, step_count_ = 0;
 

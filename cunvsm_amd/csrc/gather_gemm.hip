@@ -75,77 +75,75 @@ struct GemmArgs {
     size_t c_split_stride;
     float alpha;
     const float* bias_n;
-    int vec_a, vec_b;
     int mtiles, ntiles, slabs, groups, members;   // see gemm_decode_block
 };
 
-// Global → register staging of one K tile (8 float4 per thread: 4 of A, 4 of B), bounds-checked, zero-filled.
-template <int ALAY, int BLAY>
+// Global → register staging of one K tile (8 float4 per thread: 4 of A, 4 of B), zero-filled outside the
+// matrix. FAST (every float4 is wholly inside or wholly outside: base 16 B aligned, leading dimensions and
+// the contiguous extents multiples of 4): branch-free — the address is clamped to the matrix origin and the
+// value selected to zero, so the eight loads issue back to back and stay in flight across the MFMA loop.
+// !FAST: element-wise guarded loads (odd sizes in the tests).
+template <int ALAY, int BLAY, bool FAST>
 __device__ __forceinline__ void gemm_load_tile(const GemmArgs& g, int tid, int m0, int n0, int k0, int kend,
-                                               float (&ra)[4][4], float (&rb)[4][4]) {
+                                               float (&ra)[4][4], float (&rb)[4][4], unsigned& okmask) {
+    okmask = 0;   // FAST: bit it (A) / bit 4+it (B) = this float4 lies inside the matrix; zeroing is deferred to
+                  // gemm_store_tile so that nothing consumes the loads before the MFMA loop has run
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int f = tid + 256 * it;
+        // ---- A ----
+        {
+            int r_, c_, rlim, clim;     // r_: index along the strided axis, c_: along the contiguous axis
+            if constexpr (ALAY == 0) { r_ = m0 + (f >> 3); c_ = k0 + ((f & 7) << 2); rlim = g.M; clim = kend; }
+            else                     { r_ = k0 + (f >> 5); c_ = m0 + ((f & 31) << 2); rlim = kend; clim = g.M; }
+            if constexpr (FAST) {
+                const bool ok = (r_ < rlim) && (c_ < clim);
+                const size_t off = ok ? static_cast<size_t>(r_) * g.lda + c_ : 0;
+                ldv<4>(g.A + off, ra[it]);
+                okmask |= (ok ? 1u : 0u) << it;
+            } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ra[it][j] = 0.f; rb[it][j] = 0.f; }
-        if constexpr (ALAY == 0) {                     // A[M][K], k contiguous
-            const int row = f >> 3, kq = (f & 7) << 2;
-            const int gm = m0 + row, gk = k0 + kq;
-            if (gm < g.M) {
-                const float* p = g.A + static_cast<size_t>(gm) * g.lda + gk;
-                if (g.vec_a && gk + 3 < kend) {
-                    ldv<4>(p, ra[it]);
-                } else {
+                for (int j = 0; j < 4; ++j) ra[it][j] = 0.f;
+                if (r_ < rlim) {
+                    const float* p = g.A + static_cast<size_t>(r_) * g.lda + c_;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (gk + j < kend) ra[it][j] = p[j];
-                }
-            }
-        } else {                                       // A stored [K][M], m contiguous
-            const int kk = f >> 5, mq = (f & 31) << 2;
-            const int gk = k0 + kk, gm = m0 + mq;
-            if (gk < kend) {
-                const float* p = g.A + static_cast<size_t>(gk) * g.lda + gm;
-                if (g.vec_a && gm + 3 < g.M) {
-                    ldv<4>(p, ra[it]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (gm + j < g.M) ra[it][j] = p[j];
+                    for (int j = 0; j < 4; ++j) if (c_ + j < clim) ra[it][j] = p[j];
                 }
             }
         }
-        if constexpr (BLAY == 0) {                     // B[K][N], n contiguous
-            const int kk = f >> 5, nq = (f & 31) << 2;
-            const int gk = k0 + kk, gn = n0 + nq;
-            if (gk < kend) {
-                const float* p = g.B + static_cast<size_t>(gk) * g.ldb + gn;
-                if (g.vec_b && gn + 3 < g.N) {
-                    ldv<4>(p, rb[it]);
-                } else {
+        // ---- B ----
+        {
+            int r_, c_, rlim, clim;
+            if constexpr (BLAY == 0) { r_ = k0 + (f >> 5); c_ = n0 + ((f & 31) << 2); rlim = kend; clim = g.N; }
+            else                     { r_ = n0 + (f >> 3); c_ = k0 + ((f & 7) << 2); rlim = g.N; clim = kend; }
+            if constexpr (FAST) {
+                const bool ok = (r_ < rlim) && (c_ < clim);
+                const size_t off = ok ? static_cast<size_t>(r_) * g.ldb + c_ : 0;
+                ldv<4>(g.B + off, rb[it]);
+                okmask |= (ok ? 1u : 0u) << (4 + it);
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (gn + j < g.N) rb[it][j] = p[j];
-                }
-            }
-        } else {                                       // B stored [N][K], k contiguous
-            const int row = f >> 3, kq = (f & 7) << 2;
-            const int gn = n0 + row, gk = k0 + kq;
-            if (gn < g.N) {
-                const float* p = g.B + static_cast<size_t>(gn) * g.ldb + gk;
-                if (g.vec_b && gk + 3 < kend) {
-                    ldv<4>(p, rb[it]);
-                } else {
+                for (int j = 0; j < 4; ++j) rb[it][j] = 0.f;
+                if (r_ < rlim) {
+                    const float* p = g.B + static_cast<size_t>(r_) * g.ldb + c_;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (gk + j < kend) rb[it][j] = p[j];
+                    for (int j = 0; j < 4; ++j) if (c_ + j < clim) rb[it][j] = p[j];
                 }
             }
         }
     }
 }
 
-template <int ALAY, int BLAY>
-__device__ __forceinline__ void gemm_store_tile(int tid, float* As, float* Bs, const float (&ra)[4][4], const float (&rb)[4][4]) {
+template <int ALAY, int BLAY, bool FAST>
+__device__ __forceinline__ void gemm_store_tile(int tid, float* As, float* Bs, float (&ra)[4][4], float (&rb)[4][4], unsigned okmask) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int f = tid + 256 * it;
+        if constexpr (FAST) {
+            const bool oka = (okmask >> it) & 1u, okb = (okmask >> (4 + it)) & 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ra[it][j] = oka ? ra[it][j] : 0.f; rb[it][j] = okb ? rb[it][j] : 0.f; }
+        }
         if constexpr (ALAY == 0) {
             const int row = f >> 3, kq = (f & 7) << 2;
 #pragma unroll
@@ -183,7 +181,7 @@ __device__ __forceinline__ bool gemm_decode_block(const GemmArgs& g, int& mt, in
     return true;
 }
 
-template <int ALAY, int BLAY>
+template <int ALAY, int BLAY, bool FAST>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int A_ELEMS = (ALAY == 0) ? BM * (BK + 1) : BK * BM;
     constexpr int B_ELEMS = (BLAY == 0) ? BK * BN : BN * (BK + 1);
@@ -210,13 +208,24 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // per-column bias of this lane's two accumulator columns, fetched before the main loop
+    float bias[2] = {0.f, 0.f};
+    if (g.bias_n) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + l31;
+            bias[j] = g.bias_n[col < g.N ? col : 0];
+        }
+    }
+
     float ra[4][4], rb[4][4];
-    gemm_load_tile<ALAY, BLAY>(g, tid, m0, n0, kbeg, kend, ra, rb);
+    unsigned okmask;
+    gemm_load_tile<ALAY, BLAY, FAST>(g, tid, m0, n0, kbeg, kend, ra, rb, okmask);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        gemm_store_tile<ALAY, BLAY>(tid, As, Bs, ra, rb);
+        gemm_store_tile<ALAY, BLAY, FAST>(tid, As, Bs, ra, rb, okmask);
         __syncthreads();
         // next tile's global loads fly while this tile is multiplied
-        if (k0 + BK < kend) gemm_load_tile<ALAY, BLAY>(g, tid, m0, n0, k0 + BK, kend, ra, rb);
+        if (k0 + BK < kend) gemm_load_tile<ALAY, BLAY, FAST>(g, tid, m0, n0, k0 + BK, kend, ra, rb, okmask);
 
         // ---- 16 k-steps of 2; 4 MFMAs per step per wave ----
 #pragma unroll
@@ -243,19 +252,33 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+    // Interior tiles store unguarded: a per-row bounds branch would put an s_waitcnt vmcnt(0) (stores count in
+    // vmcnt on CDNA4) between every pair of the 64 stores of a lane.
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + j * 32 + l31;
-            if (col >= g.N) continue;
-            const float bias = g.bias_n ? g.bias_n[col] : 0.f;
+            for (int j = 0; j < 2; ++j) {
+                float* cp = C + static_cast<size_t>(m0 + wr * 64 + i * 32 + 4 * lk) * g.ldc + (n0 + wc * 64 + j * 32 + l31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < g.M) C[static_cast<size_t>(row) * g.ldc + col] = g.alpha * acc[i][j][r] + bias;
+                for (int r = 0; r < 16; ++r)
+                    cp[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * g.ldc] = g.alpha * acc[i][j][r] + bias[j];
             }
-        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wc * 64 + j * 32 + l31;
+                if (col >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (row < g.M) C[static_cast<size_t>(row) * g.ldc + col] = g.alpha * acc[i][j][r] + bias[j];
+                }
+            }
+    }
 }
 
 int gemm_split_k_slabs(int K, int want) {
@@ -281,18 +304,23 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
         slabs = (K + len - 1) / len;
     }
     if (g.k_split_len <= 0) g.k_split_len = BK;
-    g.vec_a = (lda % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
-    g.vec_b = (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
+    const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
+                         (reinterpret_cast<uintptr_t>(B) % 16 == 0);
+    const int a_contig = a_layout == 0 ? K : M, b_contig = b_layout == 0 ? N : K;
+    const bool fast = aligned && (a_contig % 4 == 0) && (b_contig % 4 == 0);
     g.mtiles = (M + BM - 1) / BM; g.ntiles = (N + BN - 1) / BN; g.slabs = slabs;
     if (slabs > 1) { g.groups = slabs; g.members = g.mtiles * g.ntiles; }
     else { g.groups = g.mtiles; g.members = g.ntiles; }
     const int padded_groups = ((g.groups + 7) / 8) * 8;
     dim3 grid(padded_groups * g.members);
     dim3 block(256);
-    if (a_layout == 0 && b_layout == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 0>), grid, block, 0, s, g);
-    else if (a_layout == 0 && b_layout == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 1>), grid, block, 0, s, g);
-    else if (a_layout == 1 && b_layout == 0) hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 0>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<1, 1>), grid, block, 0, s, g);
+#define NVSM_GEMM_CASE(AL, BL)                                                                              \
+    if (a_layout == AL && b_layout == BL) {                                                                 \
+        if (fast) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AL, BL, true>), grid, block, 0, s, g);           \
+        else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AL, BL, false>), grid, block, 0, s, g);               \
+    }
+    NVSM_GEMM_CASE(0, 0) NVSM_GEMM_CASE(0, 1) NVSM_GEMM_CASE(1, 0) NVSM_GEMM_CASE(1, 1)
+#undef NVSM_GEMM_CASE
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int slabs, size_t stride,

@@ -1,0 +1,425 @@
+// Experiment harness (not product code): loss-kernel variants timed on synthetic NVSM-config data.
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I cunvsm_amd/csrc tools/exp/loss_exp.hip -o tools/exp/loss_exp.out
+#include "../../cunvsm_amd/csrc/loss_bn.hip"
+#include <cstdio>
+#include <vector>
+#include <cmath>
+using namespace cunvsm;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+__global__ void fill_rand(float* p, size_t n, uint32_t seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        p[i] = ((h & 0xffffff) / 16777216.0f - 0.5f) * 2.f * scale;
+    }
+}
+__global__ void fill_ids(int* p, size_t n, uint32_t seed, int mod) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        p[i] = h % mod;
+    }
+}
+
+// ---- K1: pure gather bound ----
+template <int RB>
+__global__ __launch_bounds__(256) void gather_only_kernel(LossArgs a) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int de = a.de, R = a.R;
+    const int c = lane * 4;
+    const int64_t e0 = (static_cast<int64_t>(blockIdx.x) * 4 + wid) * kExamplesPerWave;
+    const int64_t e1 = min(a.B, e0 + kExamplesPerWave);
+    for (int64_t b = e0; b < e1; ++b) {
+        const int myid = (lane < R) ? a.ids[b * R + lane] : 0;
+        float acc[4] = {0, 0, 0, 0};
+        for (int r0 = 0; r0 < R; r0 += RB) {
+            float e[RB][4];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                e[u][0] = e[u][1] = e[u][2] = e[u][3] = 0.f;
+                if (r0 + u < R) {
+                    const size_t id = static_cast<size_t>(__builtin_amdgcn_readlane(myid, r0 + u));
+                    ldv<4>(a.E + id * de + c, e[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += e[u][i];
+        }
+        stv<4>(a.dy + b * de + c, acc);
+    }
+}
+
+// ---- K2: all rows of an example in flight, lane-parallel sigmoid/log ----
+template <int RB>
+__global__ __launch_bounds__(256) void loss_kernel_v2(LossArgs a) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int de = a.de, R = a.R;
+    const int c = lane * 4;
+    const bool valid = c < de;
+    const int64_t e0 = (static_cast<int64_t>(blockIdx.x) * 4 + wid) * kExamplesPerWave;
+    const int64_t e1 = min(a.B, e0 + kExamplesPerWave);
+
+    float sdy[4] = {0, 0, 0, 0}, sdyx[4] = {0, 0, 0, 0};
+    float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1}, beta[4] = {0, 0, 0, 0};
+    if (a.bn && valid) { ldv<4>(a.bn_mean + c, mu); ldv<4>(a.bn_inv_std + c, is); ldv<4>(a.bias + c, beta); }
+    float lane_loss = 0.f;
+
+    float xn[4] = {0, 0, 0, 0};
+    int idn = 0;
+    float wn = 1.f;
+    if (e0 < e1) {
+        if (valid) ldv<4>(a.pre + e0 * de + c, xn);
+        if (lane < R) idn = a.ids[e0 * R + lane];
+        if (a.inst_w) wn = a.inst_w[e0];
+    }
+    for (int64_t b = e0; b < e1; ++b) {
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = xn[i];
+        const int myid = idn;
+        float w = wn;
+
+        float e[RB][4];
+        // first batch of row loads
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            e[u][0] = e[u][1] = e[u][2] = e[u][3] = 0.f;
+            if (u < R) {
+                const size_t id = static_cast<size_t>(__builtin_amdgcn_readlane(myid, u));
+                if (valid) ldv<4>(a.E + id * de + c, e[u]);
+            }
+        }
+        // prefetch the next example's inputs behind them
+        if (b + 1 < e1) {
+            if (valid) ldv<4>(a.pre + (b + 1) * de + c, xn);
+            if (lane < R) idn = a.ids[(b + 1) * R + lane];
+            if (a.inst_w) wn = a.inst_w[b + 1];
+        }
+
+        float out[4] = {0, 0, 0, 0}, xhat[4] = {0, 0, 0, 0}, gp[4] = {0, 0, 0, 0};
+        float ssq = 0.f;
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float y = x[i];
+                if (a.bn) { xhat[i] = (x[i] - mu[i]) * is[i]; y = xhat[i] + beta[i]; }
+                y = (a.nonlinearity == 0) ? tanhf(y) : fminf(fmaxf(y, a.clip_min), a.clip_max);
+                out[i] = y;
+                ssq += y * y;
+            }
+            stv<4>(a.proj + b * de + c, out);
+        }
+        ssq = wave_sum(ssq);
+        if (lane == 0) a.pp[b] = ssq * a.inv_de;
+
+        if (a.rebalance) w = w * a.neg_scale;
+        const float w_pos = a.rebalance ? w * static_cast<float>(a.k) : w;
+
+        for (int r0 = 0; r0 < R; r0 += RB) {
+            if (r0 > 0) {
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    e[u][0] = e[u][1] = e[u][2] = e[u][3] = 0.f;
+                    if (r0 + u < R) {
+                        const size_t id = static_cast<size_t>(__builtin_amdgcn_readlane(myid, r0 + u));
+                        if (valid) ldv<4>(a.E + id * de + c, e[u]);
+                    }
+                }
+            }
+            float dot[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d += out[i] * e[u][i];
+                dot[u] = d;
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) dot[u] = wave_sum(dot[u]);
+            float dv = 0.f;
+#pragma unroll
+            for (int u = 0; u < RB; ++u) dv = (lane == u) ? dot[u] : dv;
+            const int r = r0 + lane;
+            const bool rv = (lane < RB) && (r < R);
+            const float sign = (r == 0) ? 1.f : -1.f;
+            const float sx = sign * dv;
+            float p = (sx >= 0.f) ? 1.f / (1.f + expf(-sx)) : expf(sx) / (1.f + expf(sx));
+            p = fminf(fmaxf(p, a.sig_eps), a.sig_hi);
+            const float wj = (r == 0) ? w_pos : w;
+            if (rv) lane_loss += logf(p) * wj;
+            const float d = (static_cast<double>(p) >= a.d_hi || p <= a.d_eps) ? 0.f : 1.f - p;
+            const float m = wj * (d * a.inv_batch);
+            const float cf = rv ? sign * m : 0.f;
+            if (rv) { a.coef[b * R + r] = cf; a.probs[b * R + r] = p; }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const float cu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cf), u));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gp[i] += cu * e[u][i];
+            }
+        }
+        if (valid) {
+            float g[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float y = out[i];
+                const float dd = (a.nonlinearity == 0) ? (1.f - y * y) : ((y > a.clip_min && y < a.clip_max) ? 1.f : 0.f);
+                g[i] = dd * gp[i];
+                sdy[i] += g[i];
+                sdyx[i] += g[i] * xhat[i];
+            }
+            stv<4>(a.dy + b * de + c, g);
+        }
+    }
+    const float wave_loss = wave_sum(lane_loss);
+    float* s_dy = lds; float* s_dyx = lds + 4 * de; float* s_loss = lds + 8 * de;
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s_dy[wid * de + c + i] = sdy[i]; s_dyx[wid * de + c + i] = sdyx[i]; }
+    }
+    if (lane == 0) s_loss[wid] = wave_loss;
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < de; cc += blockDim.x) {
+        const float t0 = (s_dy[cc] + s_dy[de + cc]) + (s_dy[2 * de + cc] + s_dy[3 * de + cc]);
+        atomic_add_f64(a.colstats + cc, static_cast<double>(t0));
+        if (a.bn) {
+            const float t1 = (s_dyx[cc] + s_dyx[de + cc]) + (s_dyx[2 * de + cc] + s_dyx[3 * de + cc]);
+            atomic_add_f64(a.colstats + de + cc, static_cast<double>(t1));
+        }
+    }
+    if (threadIdx.x == 0) atomic_add_f64(a.loss_acc, static_cast<double>((s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3])));
+}
+
+// ---- K3: K2 made branch-free (clamped columns / rows), scalar row base + 32-bit lane offset, balanced grid ----
+template <int RB>
+__global__ __launch_bounds__(256) void loss_kernel_v3(LossArgs a, int ex_per_wave) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int de = a.de, R = a.R;
+    const int c = lane * 4;
+    const bool valid = c < de;
+    const uint32_t coff = valid ? static_cast<uint32_t>(c) * 4u : 0u;      // byte offset inside a row (clamped: harmless re-read)
+    const int64_t e0 = (static_cast<int64_t>(blockIdx.x) * 4 + wid) * ex_per_wave;
+    const int64_t e1 = min(a.B, e0 + ex_per_wave);
+
+    float sdy[4] = {0, 0, 0, 0}, sdyx[4] = {0, 0, 0, 0};
+    float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1}, beta[4] = {0, 0, 0, 0};
+    if (a.bn) {
+        ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.bn_mean) + coff), mu);
+        ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.bn_inv_std) + coff), is);
+        ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.bias) + coff), beta);
+    }
+    float lane_loss = 0.f;
+    const int lane_r = lane < R ? lane : R - 1;
+
+    float xn[4] = {0, 0, 0, 0};
+    int idn = 0;
+    float wn = 1.f;
+    if (e0 < e1) {
+        ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.pre + e0 * de) + coff), xn);
+        idn = a.ids[e0 * R + lane_r];
+        if (a.inst_w) wn = a.inst_w[e0];
+    }
+    for (int64_t b = e0; b < e1; ++b) {
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = xn[i];
+        const int myid = idn;
+        float w = wn;
+
+        float e[RB][4];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int r = min(u, R - 1);
+            const size_t id = static_cast<size_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(myid, r)));
+            const char* rowp = reinterpret_cast<const char*>(a.E + id * de);
+            ldv<4>(reinterpret_cast<const float*>(rowp + coff), e[u]);
+        }
+        if (b + 1 < e1) {
+            ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.pre + (b + 1) * de) + coff), xn);
+            idn = a.ids[(b + 1) * R + lane_r];
+            if (a.inst_w) wn = a.inst_w[b + 1];
+        }
+
+        float out[4], xhat[4] = {0, 0, 0, 0}, gp[4] = {0, 0, 0, 0};
+        float ssq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float y = x[i];
+            if (a.bn) { xhat[i] = (x[i] - mu[i]) * is[i]; y = xhat[i] + beta[i]; }
+            y = (a.nonlinearity == 0) ? tanhf(y) : fminf(fmaxf(y, a.clip_min), a.clip_max);
+            y = valid ? y : 0.f;
+            out[i] = y;
+            ssq += y * y;
+        }
+        if (valid) stv<4>(a.proj + b * de + c, out);
+        ssq = wave_sum(ssq);
+        if (lane == 0) a.pp[b] = ssq * a.inv_de;
+
+        if (a.rebalance) w = w * a.neg_scale;
+        const float w_pos = a.rebalance ? w * static_cast<float>(a.k) : w;
+
+        for (int r0 = 0; r0 < R; r0 += RB) {
+            if (r0 > 0) {
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int r = min(r0 + u, R - 1);
+                    const size_t id = static_cast<size_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(myid, r)));
+                    const char* rowp = reinterpret_cast<const char*>(a.E + id * de);
+                    ldv<4>(reinterpret_cast<const float*>(rowp + coff), e[u]);
+                }
+            }
+            float dot[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d += out[i] * e[u][i];
+                dot[u] = d;
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) dot[u] = wave_sum(dot[u]);
+            float dv = 0.f;
+#pragma unroll
+            for (int u = 0; u < RB; ++u) dv = (lane == u) ? dot[u] : dv;
+            const int r = r0 + lane;
+            const bool rv = (lane < RB) && (r < R);
+            const float sign = (r == 0) ? 1.f : -1.f;
+            const float sx = sign * dv;
+            float p = (sx >= 0.f) ? 1.f / (1.f + expf(-sx)) : expf(sx) / (1.f + expf(sx));
+            p = fminf(fmaxf(p, a.sig_eps), a.sig_hi);
+            const float wj = (r == 0) ? w_pos : w;
+            lane_loss += rv ? logf(p) * wj : 0.f;
+            const float d = (static_cast<double>(p) >= a.d_hi || p <= a.d_eps) ? 0.f : 1.f - p;
+            const float m = wj * (d * a.inv_batch);
+            const float cf = rv ? sign * m : 0.f;
+            if (rv) { a.coef[b * R + r] = cf; a.probs[b * R + r] = p; }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const float cu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cf), u));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gp[i] += cu * e[u][i];
+            }
+        }
+        float g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float y = out[i];
+            const float dd = (a.nonlinearity == 0) ? (1.f - y * y) : ((y > a.clip_min && y < a.clip_max) ? 1.f : 0.f);
+            g[i] = valid ? dd * gp[i] : 0.f;
+            sdy[i] += g[i];
+            sdyx[i] += g[i] * xhat[i];
+        }
+        if (valid) stv<4>(a.dy + b * de + c, g);
+    }
+    const float wave_loss = wave_sum(lane_loss);
+    float* s_dy = lds; float* s_dyx = lds + 4 * de; float* s_loss = lds + 8 * de;
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s_dy[wid * de + c + i] = sdy[i]; s_dyx[wid * de + c + i] = sdyx[i]; }
+    }
+    if (lane == 0) s_loss[wid] = wave_loss;
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < de; cc += blockDim.x) {
+        const float t0 = (s_dy[cc] + s_dy[de + cc]) + (s_dy[2 * de + cc] + s_dy[3 * de + cc]);
+        atomic_add_f64(a.colstats + cc, static_cast<double>(t0));
+        if (a.bn) {
+            const float t1 = (s_dyx[cc] + s_dyx[de + cc]) + (s_dyx[2 * de + cc] + s_dyx[3 * de + cc]);
+            atomic_add_f64(a.colstats + de + cc, static_cast<double>(t1));
+        }
+    }
+    if (threadIdx.x == 0) atomic_add_f64(a.loss_acc, static_cast<double>((s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3])));
+}
+
+int main(int argc, char** argv) {
+    const int64_t B = 51200; const int de = 256, R = 17, k = 16; const int64_t nD = argc > 1 ? atol(argv[1]) : 100000;
+    float *E, *pre, *proj, *dy, *coef, *probs, *pp, *mean, *istd, *bias;
+    float *proj2, *dy2, *coef2, *probs2, *pp2;
+    int* ids; double *stats, *stats2;
+    CK(hipMalloc(&E, nD * de * 4)); CK(hipMalloc(&pre, B * de * 4)); CK(hipMalloc(&proj, B * de * 4)); CK(hipMalloc(&dy, B * de * 4));
+    CK(hipMalloc(&proj2, B * de * 4)); CK(hipMalloc(&dy2, B * de * 4));
+    CK(hipMalloc(&coef, B * R * 4)); CK(hipMalloc(&probs, B * R * 4)); CK(hipMalloc(&pp, B * 4));
+    CK(hipMalloc(&coef2, B * R * 4)); CK(hipMalloc(&probs2, B * R * 4)); CK(hipMalloc(&pp2, B * 4));
+    CK(hipMalloc(&mean, de * 4)); CK(hipMalloc(&istd, de * 4)); CK(hipMalloc(&bias, de * 4));
+    CK(hipMalloc(&ids, B * R * 4)); CK(hipMalloc(&stats, (1 + 2 * de) * 8)); CK(hipMalloc(&stats2, (1 + 2 * de) * 8));
+    fill_rand<<<2048, 256>>>(E, nD * de, 1, 0.13f);
+    fill_rand<<<2048, 256>>>(pre, B * de, 2, 1.5f);
+    fill_rand<<<1, 256>>>(mean, de, 3, 0.1f);
+    fill_rand<<<1, 256>>>(bias, de, 5, 0.1f);
+    CK(hipMemset(istd, 0, de * 4));
+    { std::vector<float> h(de, 1.1f); CK(hipMemcpy(istd, h.data(), de * 4, hipMemcpyHostToDevice)); }
+    fill_ids<<<2048, 256>>>(ids, B * R, 7, (int)nD);
+    CK(hipDeviceSynchronize());
+
+    LossArgs a{};
+    a.pre = pre; a.bn_mean = mean; a.bn_inv_std = istd; a.bias = bias; a.E = E; a.ids = ids; a.inst_w = nullptr;
+    a.proj = proj; a.dy = dy; a.coef = coef; a.probs = probs; a.pp = pp; a.loss_acc = stats; a.colstats = stats + 1;
+    a.B = B; a.de = de; a.R = R; a.k = k; a.bn = 1; a.nonlinearity = 1; a.rebalance = 1;
+    a.sig_eps = 1e-7f; a.sig_hi = (float)(1.0 - 1e-7); a.d_eps = 1e-6f; a.d_hi = 1.0 - 1e-6;
+    a.inv_batch = (float)std::exp(-std::log((double)B)); a.neg_scale = (float)((k + 1.0) / (2.0 * k));
+    a.clip_min = std::nextafter(-1.0f, -2.f); a.clip_max = std::nextafter(1.0f, 2.f); a.inv_de = 1.f / de;
+    LossArgs a2 = a; a2.proj = proj2; a2.dy = dy2; a2.coef = coef2; a2.probs = probs2; a2.pp = pp2; a2.loss_acc = stats2; a2.colstats = stats2 + 1;
+
+    hipStream_t s; CK(hipStreamCreate(&s));
+    hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
+    const int grid = ceil_div(B, 4 * kExamplesPerWave);
+    const size_t shmem = (8 * (size_t)de + 4) * sizeof(float);
+    const double bytes = (double)B * R * de * 4 + 3.0 * B * de * 4;
+    auto timeit = [&](const char* name, auto fn) {
+        for (int i = 0; i < 3; ++i) fn();
+        CK(hipStreamSynchronize(s));
+        float best = 1e9, tot = 0;
+        for (int rep = 0; rep < 5; ++rep) {
+            CK(hipEventRecord(ev0, s));
+            for (int i = 0; i < 10; ++i) fn();
+            CK(hipEventRecord(ev1, s));
+            CK(hipEventSynchronize(ev1));
+            float ms; CK(hipEventElapsedTime(&ms, ev0, ev1)); ms /= 10;
+            best = std::min(best, ms); tot += ms;
+        }
+        printf("%-28s avg %.1f us  best %.1f us  -> %.0f GB/s (best)\n", name, tot / 5 * 1e3, best * 1e3, bytes / (best * 1e-3) / 1e9);
+    };
+    timeit("K0 production", [&] { launch_loss(a, s); });
+    timeit("K1 gather-only RB=17", [&] { hipLaunchKernelGGL((gather_only_kernel<17>), dim3(grid), dim3(256), 0, s, a2); });
+    for (int kb : {32, 40, 52, 80}) {   // LDS per block (KB) -> blocks per CU = 160/kb
+        char nm[64]; snprintf(nm, 64, "K1 RB=9 lds=%dKB (%d blk/CU)", kb, 160 / kb);
+        CK(hipFuncSetAttribute((const void*)gather_only_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024));
+        timeit(nm, [&] { hipLaunchKernelGGL((gather_only_kernel<9>), dim3(grid), dim3(256), kb * 1024, s, a2); });
+    }
+    timeit("K1 gather-only RB=9", [&] { hipLaunchKernelGGL((gather_only_kernel<9>), dim3(grid), dim3(256), 0, s, a2); });
+    timeit("K1 gather-only RB=4", [&] { hipLaunchKernelGGL((gather_only_kernel<4>), dim3(grid), dim3(256), 0, s, a2); });
+    timeit("K2 v2 RB=17", [&] { hipLaunchKernelGGL((loss_kernel_v2<17>), dim3(grid), dim3(256), shmem, s, a2); });
+    timeit("K2 v2 RB=9", [&] { hipLaunchKernelGGL((loss_kernel_v2<9>), dim3(grid), dim3(256), shmem, s, a2); });
+    for (int epw : {8, 13, 10, 7}) {
+        const int g3 = ceil_div(B, 4 * epw);
+        char nm[64];
+        snprintf(nm, 64, "K3 v3 RB=9 epw=%d grid=%d", epw, g3);
+        timeit(nm, [&] { hipLaunchKernelGGL((loss_kernel_v3<9>), dim3(g3), dim3(256), shmem, s, a2, epw); });
+        snprintf(nm, 64, "K3 v3 RB=6 epw=%d grid=%d", epw, g3);
+        timeit(nm, [&] { hipLaunchKernelGGL((loss_kernel_v3<6>), dim3(g3), dim3(256), shmem, s, a2, epw); });
+        snprintf(nm, 64, "K3 v3 RB=17 epw=%d grid=%d", epw, g3);
+        timeit(nm, [&] { hipLaunchKernelGGL((loss_kernel_v3<17>), dim3(g3), dim3(256), shmem, s, a2, epw); });
+    }
+    timeit("K2 v2 RB=6", [&] { hipLaunchKernelGGL((loss_kernel_v2<6>), dim3(grid), dim3(256), shmem, s, a2); });
+
+    // correctness: K0 vs K2 RB=17
+    CK(hipMemsetAsync(stats, 0, (1 + 2 * de) * 8, s)); CK(hipMemsetAsync(stats2, 0, (1 + 2 * de) * 8, s));
+    launch_loss(a, s);
+    hipLaunchKernelGGL((loss_kernel_v3<9>), dim3(ceil_div(B, 4 * 13)), dim3(256), shmem, s, a2, 13);
+    CK(hipStreamSynchronize(s));
+    auto cmp = [&](const char* nm, const float* x, const float* y, size_t n) {
+        std::vector<float> hx(n), hy(n);
+        CK(hipMemcpy(hx.data(), x, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hy.data(), y, n * 4, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0; for (size_t i = 0; i < n; ++i) { md = std::max(md, (double)std::fabs(hx[i] - hy[i])); mx = std::max(mx, (double)std::fabs(hx[i])); }
+        printf("  %-6s max|diff| %.3e (max|x| %.3e)\n", nm, md, mx);
+    };
+    cmp("proj", proj, proj2, B * de); cmp("dy", dy, dy2, B * de); cmp("coef", coef, coef2, B * R); cmp("probs", probs, probs2, B * R); cmp("pp", pp, pp2, B);
+    std::vector<double> h1(1 + 2 * de), h2(1 + 2 * de);
+    CK(hipMemcpy(h1.data(), stats, h1.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), stats2, h2.size() * 8, hipMemcpyDeviceToHost));
+    double md = 0; for (size_t i = 0; i < h1.size(); ++i) md = std::max(md, std::fabs(h1[i] - h2[i]) / (std::fabs(h1[i]) + 1e-30));
+    printf("  stats max rel diff %.3e, loss %.9g vs %.9g\n", md, h1[0], h2[0]);
+    return 0;
+}

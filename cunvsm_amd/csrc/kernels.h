@@ -83,16 +83,21 @@ struct Csr {
     int* sorted_entry;    // [n]  entry ids ordered by row (stable)
     int* row_begin;       // [rows]
     int* row_end;         // [rows]
-    int* chunk_base;      // [rows]  first chunk of a long row
+    int* chunk_base;      // [rows]  first level-1 chunk of a long row
     int* chunk_desc;      // [max_chunks][3] row, begin, end
-    int* num_chunks;      // [1]
+    int* chunk2_base;     // [rows]  first level-2 chunk of a very long row
+    int* chunk2_desc;     // [max_chunks2][2] first, last (exclusive) level-1 chunk
+    int* num_chunks;      // [2]  level-1 / level-2 chunks in use
     float* partial;       // [max_chunks][dim]
     float* partial_q;     // [max_chunks]
+    float* partial2;      // [max_chunks2][dim]
+    float* partial2_q;    // [max_chunks2]
     int64_t n;            // entries
     int64_t rows;
-    int max_chunks;
+    int max_chunks, max_chunks2;
 };
-constexpr int kChunk = 128;   // entries per chunk of a long row
+constexpr int kChunk = 64;    // entries per level-1 chunk of a long row
+constexpr int kFan = 64;      // level-1 partials per level-2 chunk
 void launch_csr_build(const Csr& c, hipStream_t s);   // bounds + long-row chunk list, from sorted_key
 
 // ---- row passes: gather Σ coef·X[src] per table row, then the optimiser's row-local formula --------
@@ -114,6 +119,7 @@ struct RowPassArgs {
     const float* sq_src;       // words: msq[src]; entities: pp[src]
     const float* src_scale;    // optional per-src scale (Adagrad, window > 1)
     uint32_t div;              // window (words) or R (entities)
+    uint64_t div_magic;        // floor(2^37 / div) + 1: src = (entry * div_magic) >> 37, exact for entry < 2^26, div <= 2048
     float* P; float* m; float* v;   // table, first moment [rows][dim], per-element second moment (ROW_ADAM_FULL only)
     const float* sc_in;        // per-row scalar state in  (Adam v / Adagrad a, [rows]); ping-pong with sc_out because
     float* sc_out;             //   every lane of a row's thread group reads the old value

@@ -129,9 +129,14 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
     t.row_begin.alloc(rows, true); t.row_end.alloc(rows, true); t.chunk_base.alloc(rows, true);
     t.max_chunks = static_cast<int>(2 * max_entries / kChunk + 2);
     t.chunk_desc.alloc(static_cast<size_t>(t.max_chunks) * 3, true);
-    t.num_chunks.alloc(1, true);
+    t.num_chunks.alloc(2, true);
     t.partial.alloc(static_cast<size_t>(t.max_chunks) * dim);
     t.partial_q.alloc(t.max_chunks, true);
+    t.chunk2_base.alloc(rows, true);
+    t.max_chunks2 = static_cast<int>(2 * max_entries / (static_cast<int64_t>(kChunk) * kFan) + 2);
+    t.chunk2_desc.alloc(static_cast<size_t>(t.max_chunks2) * 2, true);
+    t.partial2.alloc(static_cast<size_t>(t.max_chunks2) * dim);
+    t.partial2_q.alloc(t.max_chunks2, true);
     t.sort_bits = bits_for(rows);
     t.sort_temp_bytes = sort_pairs_temp_bytes(max_entries, t.sort_bits);
     t.sort_temp.alloc(t.sort_temp_bytes + 16);
@@ -155,6 +160,8 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     if (cfg.word_repr_size > 4096) throw Error(NVSM_ERR_UNSUPPORTED, "word_repr_size must be <= 4096");
     if (cfg.world_size < 1 || cfg.rank < 0 || cfg.rank >= cfg.world_size) bad("bad world_size / rank");
     const int64_t B = cfg.max_batch_size;
+    if (cfg.window_size > 2048 || R_ > 2048 || B * std::max<int64_t>(cfg.window_size, R_) >= (int64_t(1) << 26))
+        bad("window_size and num_random_entities + 1 must be <= 2048 and max_batch_size x max(window, negatives + 1) < 2^26");
     if (B * std::max<int64_t>(cfg.word_repr_size, cfg.entity_repr_size) >= (int64_t(1) << 32) ||
         B * R_ * cfg.entity_repr_size >= (int64_t(1) << 40))
         bad("max_batch_size too large for 32-bit work indexing");
@@ -498,7 +505,9 @@ Csr Model::csr_of(TableState& t, int64_t n) {
     c.row_begin = t.row_begin.p; c.row_end = t.row_end.p; c.chunk_base = t.chunk_base.p;
     c.chunk_desc = t.chunk_desc.p; c.num_chunks = t.num_chunks.p;
     c.partial = t.partial.p; c.partial_q = t.partial_q.p;
-    c.n = n; c.rows = t.rows; c.max_chunks = t.max_chunks;
+    c.chunk2_base = t.chunk2_base.p; c.chunk2_desc = t.chunk2_desc.p;
+    c.partial2 = t.partial2.p; c.partial2_q = t.partial2_q.p;
+    c.n = n; c.rows = t.rows; c.max_chunks = t.max_chunks; c.max_chunks2 = t.max_chunks2;
     return c;
 }
 
@@ -525,6 +534,7 @@ void Model::update_entities(float lr, float sl) {
     Csr c = csr_of(t, N);
     RowPassArgs a{};
     a.table = 1; a.X = proj_.p; a.coefs = coef_.p; a.sq_src = pp_.p; a.div = static_cast<uint32_t>(R_);
+    a.div_magic = (uint64_t(1) << 37) / a.div + 1;
     a.P = t.P.p; a.m = t.m.p; a.v = t.vfull.p; a.dim = de;
     a.lr = lr; a.lambda = sl; a.eps = 1e-6f;
     a.decay = sl > 0.f ? static_cast<float>(1.0 - static_cast<double>(sl) * static_cast<double>(lr)) : 1.f;
@@ -554,6 +564,7 @@ void Model::update_words(float lr, float sl) {
     Csr c = csr_of(t, n);
     RowPassArgs a{};
     a.table = 0; a.X = gphrase_.p; a.wts = wwts_; a.div = static_cast<uint32_t>(w);
+    a.div_magic = (uint64_t(1) << 37) / a.div + 1;
     a.P = t.P.p; a.m = t.m.p; a.v = t.vfull.p; a.dim = dw;
     a.lr = lr; a.lambda = sl; a.eps = 1e-6f;
     a.decay = sl > 0.f ? static_cast<float>(1.0 - static_cast<double>(sl) * static_cast<double>(lr)) : 1.f;

@@ -79,12 +79,12 @@ struct TableState {           // one embedding table + its optimiser state + its
     int sc_cur = 0;
     uint64_t t = 1;           // Adam step counter (cpp/updates_adam.cu:130)
     // CSR workspace
-    DevBuf<int> sorted_key, sorted_entry, row_begin, row_end, chunk_base, chunk_desc, num_chunks;
-    DevBuf<float> partial, partial_q;
+    DevBuf<int> sorted_key, sorted_entry, row_begin, row_end, chunk_base, chunk_desc, chunk2_base, chunk2_desc, num_chunks;
+    DevBuf<float> partial, partial_q, partial2, partial2_q;
     DevBuf<char> sort_temp;
     size_t sort_temp_bytes = 0;
     int sort_bits = 1;
-    int max_chunks = 0;
+    int max_chunks = 0, max_chunks2 = 0;
     int64_t max_entries = 0;
 };
 

@@ -26,10 +26,14 @@ __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* _
     }
 }
 
-// rows with more than kChunk entries (hot words) are cut into chunks that are reduced in parallel
+// Rows with more than kChunk entries (hot words) are cut into chunks of kChunk entries that are reduced in
+// parallel (level 1); rows with more than kFan level-1 chunks additionally get level-2 chunks, each the ordered
+// sum of kFan level-1 partials, so that no thread group ever walks more than max(kChunk, kFan) items serially
+// (until a row exceeds kChunk·kFan² entries) and every sum has a fixed order: results are run-to-run deterministic.
 __global__ void csr_chunks_kernel(const int* __restrict__ row_begin, const int* __restrict__ row_end, int64_t rows,
-                                  int* __restrict__ chunk_base, int* __restrict__ chunk_desc, int* __restrict__ num_chunks,
-                                  int max_chunks) {
+                                  int* __restrict__ chunk_base, int* __restrict__ chunk_desc,
+                                  int* __restrict__ chunk2_base, int* __restrict__ chunk2_desc,
+                                  int* __restrict__ num_chunks, int max_chunks, int max_chunks2) {
     for (int64_t r = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; r < rows;
          r += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int b = row_begin[r], e = row_end[r];
@@ -43,6 +47,15 @@ __global__ void csr_chunks_kernel(const int* __restrict__ row_begin, const int* 
                 chunk_desc[(base + c) * 3 + 1] = b + c * kChunk;
                 chunk_desc[(base + c) * 3 + 2] = min(e, b + (c + 1) * kChunk);
             }
+            if (nch > kFan) {
+                const int n2 = (nch + kFan - 1) / kFan;
+                const int base2 = atomicAdd(num_chunks + 1, n2);
+                chunk2_base[r] = base2;
+                for (int c = 0; c < n2 && base2 + c < max_chunks2; ++c) {
+                    chunk2_desc[(base2 + c) * 2 + 0] = base + c * kFan;
+                    chunk2_desc[(base2 + c) * 2 + 1] = base + min(nch, (c + 1) * kFan);
+                }
+            }
         }
     }
 }
@@ -50,75 +63,104 @@ __global__ void csr_chunks_kernel(const int* __restrict__ row_begin, const int* 
 void launch_csr_build(const Csr& c, hipStream_t s) {
     (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * c.rows, s);
     (void)hipMemsetAsync(c.row_end, 0, sizeof(int) * c.rows, s);
-    (void)hipMemsetAsync(c.num_chunks, 0, sizeof(int), s);
+    (void)hipMemsetAsync(c.num_chunks, 0, 2 * sizeof(int), s);
     if (c.n > 0)
         hipLaunchKernelGGL(csr_bounds_kernel, dim3(stream_grid(c.n, 256)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end);
     hipLaunchKernelGGL(csr_chunks_kernel, dim3(stream_grid(c.rows, 256)), dim3(256), 0, s, c.row_begin, c.row_end, c.rows,
-                       c.chunk_base, c.chunk_desc, c.num_chunks, c.max_chunks);
+                       c.chunk_base, c.chunk_desc, c.chunk2_base, c.chunk2_desc, c.num_chunks, c.max_chunks, c.max_chunks2);
 }
 
 // =============================================================================================
-// Segment accumulation: g = Σ coef·X[src][col..col+V), q = Σ sq, over sorted entries [begin, end)
+// Segment accumulation: g = Σ coef·X[src][col..col+V), q = Σ sq, over sorted entries [begin, end), in entry order.
+// kSegUnroll gradient rows are in flight per lane, and the entry ids of the NEXT batch are fetched while the
+// current batch's rows load, so the dependent chain per batch is one global-load latency (ids → rows would be
+// two). Out-of-range slots of the last batch re-read the segment's last entry with coefficient 0 (branch-free).
+// src = entry / div by multiply-shift: exact for entry < 2^26, div <= 2048 (checked by the host).
 // =============================================================================================
+constexpr int kSegUnroll = 8;
+
 template <int V, int TABLE, bool VEC>
 __device__ __forceinline__ void accumulate_segment(const RowPassArgs& a, const int* __restrict__ sorted_entry,
                                                    int begin, int end, int col, float (&g)[V], float& q) {
     const bool need_q = (a.sq_src != nullptr);
-    int e = begin;
-    for (; e + 4 <= end; e += 4) {
-        uint32_t src[4];
-        float cf[4];
+    const int last = end - 1;
+    int en_next[kSegUnroll];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t en = static_cast<uint32_t>(sorted_entry[e + u]);
-            src[u] = en / a.div;
-            if (TABLE == 0) {
-                cf[u] = a.wts ? a.wts[en] : 1.f;
-                if (need_q) q += cf[u] * a.sq_src[src[u]];
-                if (a.src_scale) cf[u] *= a.src_scale[src[u]];
-            } else {
-                cf[u] = a.coefs[en];
-                if (need_q) q += (cf[u] * cf[u]) * a.sq_src[src[u]];
-            }
+    for (int u = 0; u < kSegUnroll; ++u) en_next[u] = sorted_entry[min(begin + u, last)];
+    for (int e = begin; e < end; e += kSegUnroll) {
+        uint32_t en[kSegUnroll];
+#pragma unroll
+        for (int u = 0; u < kSegUnroll; ++u) en[u] = static_cast<uint32_t>(en_next[u]);
+        if (e + kSegUnroll < end) {
+#pragma unroll
+            for (int u = 0; u < kSegUnroll; ++u) en_next[u] = sorted_entry[min(e + kSegUnroll + u, last)];
         }
-        if (VEC) {
-            float x[4][V];
+        float cf[kSegUnroll], sq[kSegUnroll], x[kSegUnroll][V];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ldv<V>(a.X + static_cast<size_t>(src[u]) * a.dim + col, x[u]);
+        for (int u = 0; u < kSegUnroll; ++u) {
+            const uint32_t src = static_cast<uint32_t>((static_cast<uint64_t>(en[u]) * a.div_magic) >> 37);
+            float c;
+            if (TABLE == 0) c = a.wts ? a.wts[en[u]] : 1.f;
+            else c = a.coefs[en[u]];
+            sq[u] = need_q ? a.sq_src[src] : 0.f;
+            const float scl = (TABLE == 0 && a.src_scale) ? a.src_scale[src] : 1.f;
+            const bool ok = (e + u) < end;
+            c = ok ? c : 0.f;
+            // q uses the unscaled coefficient (cpp/updates_adagrad.cu:136-158 / updates_adam.cu:232-240)
+            sq[u] = (TABLE == 0) ? c * sq[u] : (c * c) * sq[u];
+            cf[u] = (TABLE == 0 && a.src_scale) ? c * scl : c;
+            if (VEC) ldv<V>(a.X + static_cast<size_t>(src) * a.dim + col, x[u]);
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < kSegUnroll; ++u) {
+            if (need_q) q += sq[u];
+            if (VEC) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) g[i] += cf[u] * x[u][i];
-        }
-    }
-    for (; e < end; ++e) {
-        const uint32_t en = static_cast<uint32_t>(sorted_entry[e]);
-        const uint32_t src = en / a.div;
-        float cf;
-        if (TABLE == 0) {
-            cf = a.wts ? a.wts[en] : 1.f;
-            if (need_q) q += cf * a.sq_src[src];
-            if (a.src_scale) cf *= a.src_scale[src];
-        } else {
-            cf = a.coefs[en];
-            if (need_q) q += (cf * cf) * a.sq_src[src];
-        }
-        if (VEC) {
-            float x[V];
-            ldv<V>(a.X + static_cast<size_t>(src) * a.dim + col, x);
-#pragma unroll
-            for (int i = 0; i < V; ++i) g[i] += cf * x[i];
+            }
         }
     }
 }
 
-// one thread group (nvec threads, one 16 B column each) per chunk of a long row
+// ordered sum of `count` partial vectors starting at partial[first]
+template <int V, bool VEC>
+__device__ __forceinline__ void sum_partials(const float* __restrict__ partial, const float* __restrict__ partial_q,
+                                             int first, int count, int dim, int col, float (&g)[V], float& q) {
+    int ch = 0;
+    for (; ch + 4 <= count; ch += 4) {
+        float x[4][V], pq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (VEC) ldv<V>(partial + static_cast<size_t>(first + ch + u) * dim + col, x[u]);
+            pq[u] = partial_q[first + ch + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (VEC) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) g[i] += x[u][i];
+            }
+            q += pq[u];
+        }
+    }
+    for (; ch < count; ++ch) {
+        if (VEC) {
+            float x[V];
+            ldv<V>(partial + static_cast<size_t>(first + ch) * dim + col, x);
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] += x[i];
+        }
+        q += partial_q[first + ch];
+    }
+}
+
+// level 1: one thread group (nvec threads, one 16 B column each) per chunk of a long row
 template <int V, int TABLE, bool VEC>
 __global__ __launch_bounds__(256) void chunk_pass_kernel(Csr c, RowPassArgs a, int G, int nvec) {
     const int gpb = blockDim.x / G;
     const int group = threadIdx.x / G, lig = threadIdx.x - group * G;
     if (group >= gpb) return;
-    const int nchunks = min(*c.num_chunks, c.max_chunks);
+    const int nchunks = min(c.num_chunks[0], c.max_chunks);
     for (int ci = blockIdx.x * gpb + group; ci < nchunks; ci += gridDim.x * gpb) {
         const int begin = c.chunk_desc[ci * 3 + 1], end = c.chunk_desc[ci * 3 + 2];
         for (int cv = lig; cv < nvec; cv += G) {
@@ -134,9 +176,33 @@ __global__ __launch_bounds__(256) void chunk_pass_kernel(Csr c, RowPassArgs a, i
     }
 }
 
+// level 2: ordered sum of up to kFan level-1 partials
+template <int V, bool VEC>
+__global__ __launch_bounds__(256) void chunk2_pass_kernel(Csr c, int dim, int G, int nvec) {
+    const int gpb = blockDim.x / G;
+    const int group = threadIdx.x / G, lig = threadIdx.x - group * G;
+    if (group >= gpb) return;
+    const int n2 = min(c.num_chunks[1], c.max_chunks2);
+    for (int ci = blockIdx.x * gpb + group; ci < n2; ci += gridDim.x * gpb) {
+        const int first = c.chunk2_desc[ci * 2 + 0], last = c.chunk2_desc[ci * 2 + 1];
+        for (int cv = lig; cv < nvec; cv += G) {
+            const int col = cv * V;
+            float g[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] = 0.f;
+            float q = 0.f;
+            sum_partials<V, VEC>(c.partial, c.partial_q, first, last - first, dim, col, g, q);
+            if (VEC) stv<V>(c.partial2 + static_cast<size_t>(ci) * dim + col, g);
+            if (cv == 0) c.partial2_q[ci] = q;
+        }
+    }
+}
+
 template <int V, int TABLE, int KIND>
 __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int G, int nvec) {
     constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
+    constexpr bool USES_M = (KIND == ROW_ADAM_MV || KIND == ROW_ADAM_SPARSE_ENT || KIND == ROW_ADAM_DENSE || KIND == ROW_ADAM_FULL);
+    constexpr bool USES_P = (KIND == ROW_SGD || KIND == ROW_ADAGRAD_ENT || KIND == ROW_ADAM_SPARSE_ENT || KIND == ROW_ADAM_DENSE || KIND == ROW_ADAM_FULL);
     const int rpb = blockDim.x / G;
     const int group = threadIdx.x / G, lig = threadIdx.x - group * G;
     if (group >= rpb) return;
@@ -146,54 +212,46 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
         const int begin = c.row_begin[row], end = c.row_end[row];
         const int cnt = end - begin;
         if (cnt == 0 && !a.dense) continue;
-        const bool is_long = cnt > kChunk;
-        const int cbase = is_long ? c.chunk_base[row] : 0;
-        const int nch = is_long ? (cnt + kChunk - 1) / kChunk : 0;
+        const bool touch_p = !(cnt == 0 && a.decay == 1.f);      // sparse kinds leave untouched rows alone when λ = 0
         for (int cv = lig; cv < nvec; cv += G) {
             const int col = cv * V;
+            const size_t off = static_cast<size_t>(row) * dim + col;
+            // the row's own state does not depend on the entries: fetch it first so it is in flight during the gather
+            float p[V], m[V], v[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) { p[i] = 0.f; m[i] = 0.f; v[i] = 0.f; }
+            if (USES_M) ldv<V>(a.m + off, m);
+            if (KIND == ROW_ADAM_FULL) ldv<V>(a.v + off, v);
+            if (USES_P && (touch_p || KIND == ROW_ADAM_FULL || KIND == ROW_ADAM_DENSE)) ldv<V>(a.P + off, p);
+
             float g[V];
 #pragma unroll
             for (int i = 0; i < V; ++i) g[i] = 0.f;
             float q = 0.f;
-            if (is_long) {                 // sum the chunk partials in chunk order (deterministic)
-                for (int ch = 0; ch < nch; ++ch) {
-                    if (VEC) {
-                        float x[V];
-                        ldv<V>(c.partial + static_cast<size_t>(cbase + ch) * dim + col, x);
-#pragma unroll
-                        for (int i = 0; i < V; ++i) g[i] += x[i];
-                    }
-                    q += c.partial_q[cbase + ch];
-                }
+            if (cnt > kChunk) {            // long row: ordered sum of its chunk partials
+                const int nch = (cnt + kChunk - 1) / kChunk;
+                if (nch > kFan) sum_partials<V, VEC>(c.partial2, c.partial2_q, c.chunk2_base[row], (nch + kFan - 1) / kFan, dim, col, g, q);
+                else sum_partials<V, VEC>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
             } else if (cnt > 0) {
                 accumulate_segment<V, TABLE, VEC>(a, c.sorted_entry, begin, end, col, g, q);
             }
 
-            const size_t off = static_cast<size_t>(row) * dim + col;
             if (KIND == ROW_SGD) {
-                if (cnt == 0 && a.decay == 1.f) continue;
-                float p[V];
-                ldv<V>(a.P + off, p);
+                if (!touch_p) continue;
 #pragma unroll
                 for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * g[i];
                 stv<V>(a.P + off, p);
             } else if (KIND == ROW_ADAGRAD_ENT) {
                 const float acc = a.sc_in[row] + q;
                 if (cv == 0) a.sc_out[row] = acc;
-                if (cnt == 0 && a.decay == 1.f) continue;
+                if (!touch_p) continue;
                 const float sc = 1.f / sqrtf(acc + a.eps);
-                float p[V];
-                ldv<V>(a.P + off, p);
 #pragma unroll
                 for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * (g[i] * sc);
                 stv<V>(a.P + off, p);
             } else if (KIND == ROW_SCALAR_ACC) {
                 if (cv == 0) a.sc_out[row] = a.sc_in[row] + q;
             } else if (KIND == ROW_ADAM_FULL) {
-                float p[V], m[V], v[V];
-                ldv<V>(a.P + off, p);
-                ldv<V>(a.m + off, m);
-                ldv<V>(a.v + off, v);
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
                     float mn = m[i] * a.s_m + a.one_m_b1 * g[i];      // updates_adam.cu:196-200
@@ -210,26 +268,20 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
                 stv<V>(a.P + off, p);
             } else {
                 // ROW_ADAM_MV / ROW_ADAM_SPARSE_ENT / ROW_ADAM_DENSE: v is one scalar per row (updates_adam.cu:126).
-                float m[V];
-                ldv<V>(a.m + off, m);
 #pragma unroll
                 for (int i = 0; i < V; ++i) m[i] = m[i] * a.s_m + a.one_m_b1 * g[i];
                 stv<V>(a.m + off, m);
                 const float vn = a.sc_in[row] * a.s_v + a.one_m_b2 * q;
                 if (cv == 0) a.sc_out[row] = vn;
                 if (KIND == ROW_ADAM_SPARSE_ENT) {
-                    if (cnt == 0 && a.decay == 1.f) continue;
+                    if (!touch_p) continue;
                     const float denom = sqrtf(vn) + a.eps;
                     const float fc = static_cast<float>(cnt);
-                    float p[V];
-                    ldv<V>(a.P + off, p);
 #pragma unroll
                     for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + (a.lr * fc) * ((a.bc * m[i]) / denom);
                     stv<V>(a.P + off, p);
                 } else if (KIND == ROW_ADAM_DENSE) {
                     const float denom = sqrtf(vn) + a.eps;
-                    float p[V];
-                    ldv<V>(a.P + off, p);
 #pragma unroll
                     for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + ((m[i] / denom) * a.bc) * a.lr;
                     stv<V>(a.P + off, p);
@@ -249,10 +301,14 @@ template <int V, int TABLE>
 static void chunk_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nvec, hipStream_t s) {
     const int gpb = 256 / G;
     const int grid = (c.max_chunks + gpb - 1) / gpb;
-    if (a.kind == ROW_SCALAR_ACC)
+    const int grid2 = (c.max_chunks2 + gpb - 1) / gpb;
+    if (a.kind == ROW_SCALAR_ACC) {
         hipLaunchKernelGGL((chunk_pass_kernel<V, TABLE, false>), dim3(grid), dim3(256), 0, s, c, a, G, nvec);
-    else
+        hipLaunchKernelGGL((chunk2_pass_kernel<V, false>), dim3(grid2), dim3(256), 0, s, c, a.dim, G, nvec);
+    } else {
         hipLaunchKernelGGL((chunk_pass_kernel<V, TABLE, true>), dim3(grid), dim3(256), 0, s, c, a, G, nvec);
+        hipLaunchKernelGGL((chunk2_pass_kernel<V, true>), dim3(grid2), dim3(256), 0, s, c, a.dim, G, nvec);
+    }
 }
 
 void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s) {

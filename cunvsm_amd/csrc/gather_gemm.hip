@@ -75,6 +75,7 @@ struct GemmArgs {
     size_t c_split_stride;
     float alpha;
     const float* bias_n;
+    double* colstats;        // optional [2][N]: Σ_rows C, Σ_rows C² of the stored values (batch-norm statistics, F6)
     int mtiles, ntiles, slabs, groups, members;   // see gemm_decode_block
 };
 
@@ -254,7 +255,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
     // Interior tiles store unguarded: a per-row bounds branch would put an s_waitcnt vmcnt(0) (stores count in
     // vmcnt on CDNA4) between every pair of the 64 stores of a lane.
+    // With colstats the per-column Σ and Σ² of the stored values ride along: per-lane fp32 sums over the lane's 32
+    // rows, the two 32-lane halves folded by a cross-lane read, the two row-waves folded through LDS, then one fp64
+    // atomic per column per block (replaces the separate column-statistics pass over the GEMM output).
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
     if (interior) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -262,8 +267,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
             for (int j = 0; j < 2; ++j) {
                 float* cp = C + static_cast<size_t>(m0 + wr * 64 + i * 32 + 4 * lk) * g.ldc + (n0 + wc * 64 + j * 32 + l31);
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    cp[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * g.ldc] = g.alpha * acc[i][j][r] + bias[j];
+                for (int r = 0; r < 16; ++r) {
+                    const float v = g.alpha * acc[i][j][r] + bias[j];
+                    cp[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * g.ldc] = v;
+                    cs[j] += v; cs2[j] += v * v;
+                }
             }
     } else {
 #pragma unroll
@@ -275,9 +283,30 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (row < g.M) C[static_cast<size_t>(row) * g.ldc + col] = g.alpha * acc[i][j][r] + bias[j];
+                    if (row < g.M) {
+                        const float v = g.alpha * acc[i][j][r] + bias[j];
+                        C[static_cast<size_t>(row) * g.ldc + col] = v;
+                        cs[j] += v; cs2[j] += v * v;
+                    }
                 }
             }
+    }
+    if (g.colstats) {
+        float* red = lds;                 // [2 (Σ, Σ²)][2 (wr)][BN]; the operand tiles are dead (loop ended on a barrier)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            cs[j] += __shfl_xor(cs[j], 32);
+            cs2[j] += __shfl_xor(cs2[j], 32);
+            if (lk == 0) {
+                red[(0 * 2 + wr) * BN + wc * 64 + j * 32 + l31] = cs[j];
+                red[(1 * 2 + wr) * BN + wc * 64 + j * 32 + l31] = cs2[j];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.N) {
+            atomic_add_f64(g.colstats + n0 + tid, static_cast<double>(red[tid] + red[BN + tid]));
+            atomic_add_f64(g.colstats + g.N + n0 + tid, static_cast<double>(red[2 * BN + tid] + red[3 * BN + tid]));
+        }
     }
 }
 
@@ -290,9 +319,10 @@ int gemm_split_k_slabs(int K, int want) {
 
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
-                 hipStream_t s) {
+                 hipStream_t s, double* colstats) {
     if (M <= 0 || N <= 0) return;
     GemmArgs g;
+    g.colstats = (split_k > 1) ? nullptr : colstats;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = alpha; g.bias_n = bias_n; g.c_split_stride = c_split_stride;
     int slabs = 1;

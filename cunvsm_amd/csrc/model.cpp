@@ -372,10 +372,13 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     { PROF("gather_mean_words"); launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, phrase_.p, stream_); }
 
     // F5: projection GEMM  pre[B][de] = phrase[B][dw] · Tt[dw][de] (+ b when no BN)   (params.cu:417-421)
+    // F6 (first half): with batch-norm the column sums Σx, Σx² of the projection ride in the GEMM epilogue
     {
         PROF("gemm_fwd");
+        if (cfg_.batch_normalization) NVSM_HIP_CHECK(hipMemsetAsync(stats_fwd_.p, 0, stats_fwd_.n * sizeof(double), stream_));
         launch_gemm(0, 0, phrase_.p, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
-                    cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_);
+                    cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_,
+                    cfg_.batch_normalization ? stats_fwd_.p : nullptr);
     }
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
@@ -383,8 +386,6 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // F6: batch statistics (cudnn_utils.cu:107-124), ε = 1e-4 (objective.cu:114)
     if (cfg_.batch_normalization) {
         PROF("bn_stats");
-        NVSM_HIP_CHECK(hipMemsetAsync(stats_fwd_.p, 0, stats_fwd_.n * sizeof(double), stream_));
-        launch_bn_colstats(pre_.p, B, de, stats_fwd_.p, stream_);
         if (cfg_.world_size > 1 && cfg_.sync_batch_norm) allreduce_f64(stats_fwd_.p, 2 * de);
         launch_bn_finalize(stats_fwd_.p, de, bn_n, 1e-4f, bn_mean_.p, bn_inv_std_.p, stream_);
     }

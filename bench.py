@@ -66,6 +66,29 @@ def algorithmic_bytes(kernel, wl, method):
     return table.get(kernel)
 
 
+# kernel group (engine profiler name) -> rocprofv3 kernel name prefix, for the PMC traffic figures kept under profiles/
+PMC_KERNEL = {"loss_fused": "loss_rows_kernel", "row_pass_entities": "row_pass_kernel<4, 1, 3>",
+              "row_pass_words_mv": "row_pass_kernel<4, 0, 2>", "row_pass_words_u": "row_pass_kernel<4, 0, 0>",
+              "gather_mean_words": "gather_mean_kernel", "adam_u_words": "adam_u_kernel"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_hbm_pmc.json,
+    written by tools/profile_round.sh from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
+    Counters cannot be read from inside the process; None when no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")))
+    pref = PMC_KERNEL.get(kernel)
+    if not files or not pref:
+        return None, None
+    with open(files[-1]) as f:
+        ks = json.load(f)["kernels"]
+    for name, e in ks.items():
+        if name.startswith(pref):
+            return int(e["fetch_bytes_corrected"] + e["write_bytes"]), os.path.basename(files[-1])
+    return None, None
+
+
 def gemm_flops(wl):
     return 2.0 * wl["batch"] * wl["word_dim"] * wl["entity_dim"]
 
@@ -225,8 +248,9 @@ def main():
             ab = algorithmic_bytes(dom, wl, method)
             avg = breakdown[dom]["avg_ms"]
             ach = ab / (avg * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(dom)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg}
         out = {
             "metric": "n-gram windows/sec (batch=51200, NVSM config)", "value": round(value, 1), "unit": "windows/s",

@@ -126,10 +126,9 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
         else { t.sc[0].alloc(rows, true); t.sc[1].alloc(rows, true); }
     }
     t.sorted_key.alloc(max_entries); t.sorted_entry.alloc(max_entries);
-    t.row_begin.alloc(rows, true); t.row_end.alloc(rows, true); t.chunk_base.alloc(rows, true);
+    t.csr_zeroed.alloc(2 * rows + 2, true); t.chunk_base.alloc(rows, true);
     t.max_chunks = static_cast<int>(2 * max_entries / kChunk + 2);
     t.chunk_desc.alloc(static_cast<size_t>(t.max_chunks) * 3, true);
-    t.num_chunks.alloc(2, true);
     t.partial.alloc(static_cast<size_t>(t.max_chunks) * dim);
     t.partial_q.alloc(t.max_chunks, true);
     t.chunk2_base.alloc(rows, true);
@@ -192,7 +191,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     coef_.alloc(N); probs_.alloc(N); pp_.alloc(B); msq_w_.alloc(B);
     if (cfg.update_method == NVSM_ADAM && cfg.adam_mode <= NVSM_ADAM_SPARSE) U_.alloc(B * dw);
     if (cfg.update_method == NVSM_ADAGRAD) scale_w_.alloc(B);
-    stats_fwd_.alloc(2 * de, true); stats_bwd_.alloc(1 + 2 * de, true);
+    stats_.alloc(4 * de + 1, true); stats_fwd_ = stats_.p; stats_bwd_ = stats_.p + 2 * de;
     bn_mean_.alloc(de, true); bn_inv_std_.alloc(de, true); dbeta_.alloc(de, true); dgamma_.alloc(de, true);
     gT_.alloc(static_cast<size_t>(de) * dw, true); gb_.alloc(de, true);
     const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
@@ -305,6 +304,8 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     have_forward_ = have_grads_ = false;
     cost_valid_ = false;
 
+    NVSM_HIP_CHECK(hipMemsetAsync(stats_.p, 0, stats_.n * sizeof(double), stream_));   // Σx Σx² | loss Σdy Σdy·x̂
+
     // F1: batch → HBM (objective.cu:36-61)
     const int64_t* words_dev;
     {
@@ -375,10 +376,9 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // F6 (first half): with batch-norm the column sums Σx, Σx² of the projection ride in the GEMM epilogue
     {
         PROF("gemm_fwd");
-        if (cfg_.batch_normalization) NVSM_HIP_CHECK(hipMemsetAsync(stats_fwd_.p, 0, stats_fwd_.n * sizeof(double), stream_));
         launch_gemm(0, 0, phrase_.p, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
                     cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_,
-                    cfg_.batch_normalization ? stats_fwd_.p : nullptr);
+                    cfg_.batch_normalization ? stats_fwd_ : nullptr);
     }
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
@@ -386,19 +386,18 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // F6: batch statistics (cudnn_utils.cu:107-124), ε = 1e-4 (objective.cu:114)
     if (cfg_.batch_normalization) {
         PROF("bn_stats");
-        if (cfg_.world_size > 1 && cfg_.sync_batch_norm) allreduce_f64(stats_fwd_.p, 2 * de);
-        launch_bn_finalize(stats_fwd_.p, de, bn_n, 1e-4f, bn_mean_.p, bn_inv_std_.p, stream_);
+        if (cfg_.world_size > 1 && cfg_.sync_batch_norm) allreduce_f64(stats_fwd_, 2 * de);
+        launch_bn_finalize(stats_fwd_, de, bn_n, 1e-4f, bn_mean_.p, bn_inv_std_.p, stream_);
     }
 
     // F7–F16 + B1–B4: fused loss
     {
         PROF("loss_fused");
-        NVSM_HIP_CHECK(hipMemsetAsync(stats_bwd_.p, 0, stats_bwd_.n * sizeof(double), stream_));
         LossArgs a;
         a.pre = pre_.p; a.bn_mean = bn_mean_.p; a.bn_inv_std = bn_inv_std_.p; a.bias = b_.p;
         a.E = ents_.P.p; a.ids = ids_.p; a.inst_w = instw_;
         a.proj = proj_.p; a.dy = dy_.p; a.coef = coef_.p; a.probs = probs_.p; a.pp = pp_.p;
-        a.loss_acc = stats_bwd_.p; a.colstats = stats_bwd_.p + 1;
+        a.loss_acc = stats_bwd_; a.colstats = stats_bwd_ + 1;
         a.B = B; a.de = de; a.R = R_; a.k = k;
         a.bn = cfg_.batch_normalization; a.nonlinearity = cfg_.nonlinearity;
         a.rebalance = (!cfg_.bias_negative_samples && k > 1);                                 // objective.cu:268
@@ -433,17 +432,17 @@ void Model::compute_gradients() {
         PROF("bn_backward");
         if (cfg_.batch_normalization) {
             if (dp && cfg_.sync_batch_norm) {
-                allreduce_f64(stats_bwd_.p, 1 + 2 * de);
-                launch_bn_bwd_finalize(stats_bwd_.p + 1, de, dbeta_.p, dgamma_.p, gb_.p, stream_);
+                allreduce_f64(stats_bwd_, 1 + 2 * de);
+                launch_bn_bwd_finalize(stats_bwd_ + 1, de, dbeta_.p, dgamma_.p, gb_.p, stream_);
                 launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, dbeta_.p, dgamma_.p, B_global, B, de, stream_);
             } else {
-                launch_bn_bwd_finalize(stats_bwd_.p + 1, de, dbeta_.p, dgamma_.p, gb_.p, stream_);
+                launch_bn_bwd_finalize(stats_bwd_ + 1, de, dbeta_.p, dgamma_.p, gb_.p, stream_);
                 launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, dbeta_.p, dgamma_.p, static_cast<double>(B), B, de, stream_);
-                if (dp) { allreduce_f64(stats_bwd_.p, 1 + 2 * de); launch_colsum_finalize(stats_bwd_.p + 1, de, gb_.p, stream_); }
+                if (dp) { allreduce_f64(stats_bwd_, 1 + 2 * de); launch_colsum_finalize(stats_bwd_ + 1, de, gb_.p, stream_); }
             }
         } else {
-            if (dp) allreduce_f64(stats_bwd_.p, 1 + de);
-            launch_colsum_finalize(stats_bwd_.p + 1, de, gb_.p, stream_);
+            if (dp) allreduce_f64(stats_bwd_, 1 + de);
+            launch_colsum_finalize(stats_bwd_ + 1, de, gb_.p, stream_);
         }
     }
     // B7 + B9: gphrase[B][dw] = dx[B][de] · T (stored [dw][de]) / w   (objective.cu:447-476)
@@ -483,7 +482,7 @@ float Model::get_cost() {
         if (cfg_.world_size > 1 && !have_grads_) {
             // before compute_gradients the loss word has not been all-reduced yet: local contribution only
         }
-        NVSM_HIP_CHECK(hipMemcpyAsync(&s, stats_bwd_.p, sizeof(double), hipMemcpyDeviceToHost, stream_));
+        NVSM_HIP_CHECK(hipMemcpyAsync(&s, stats_bwd_, sizeof(double), hipMemcpyDeviceToHost, stream_));
         NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
         const double Bg = static_cast<double>(B_) * (cfg_.world_size > 1 ? cfg_.world_size : 1);
         cost_ = -(s / Bg);
@@ -503,8 +502,8 @@ float Model::adam_bc(uint64_t t) const {
 Csr Model::csr_of(TableState& t, int64_t n) {
     Csr c;
     c.sorted_key = t.sorted_key.p; c.sorted_entry = t.sorted_entry.p;
-    c.row_begin = t.row_begin.p; c.row_end = t.row_end.p; c.chunk_base = t.chunk_base.p;
-    c.chunk_desc = t.chunk_desc.p; c.num_chunks = t.num_chunks.p;
+    c.row_begin = t.csr_zeroed.p; c.row_end = t.csr_zeroed.p + t.rows; c.chunk_base = t.chunk_base.p;
+    c.chunk_desc = t.chunk_desc.p; c.num_chunks = t.csr_zeroed.p + 2 * t.rows;
     c.partial = t.partial.p; c.partial_q = t.partial_q.p;
     c.chunk2_base = t.chunk2_base.p; c.chunk2_desc = t.chunk2_desc.p;
     c.partial2 = t.partial2.p; c.partial2_q = t.partial2_q.p;

@@ -79,7 +79,8 @@ struct TableState {           // one embedding table + its optimiser state + its
     int sc_cur = 0;
     uint64_t t = 1;           // Adam step counter (cpp/updates_adam.cu:130)
     // CSR workspace
-    DevBuf<int> sorted_key, sorted_entry, row_begin, row_end, chunk_base, chunk_desc, chunk2_base, chunk2_desc, num_chunks;
+    DevBuf<int> sorted_key, sorted_entry, chunk_base, chunk_desc, chunk2_base, chunk2_desc;
+    DevBuf<int> csr_zeroed;   // [row_begin (rows) | row_end (rows) | num_chunks (2)]: one memset per step clears all three
     DevBuf<float> partial, partial_q, partial2, partial2_q;
     DevBuf<char> sort_temp;
     size_t sort_temp_bytes = 0;
@@ -158,7 +159,9 @@ class Model {
 
     // intermediates
     DevBuf<float> phrase_, pre_, proj_, dy_, gphrase_, coef_, probs_, pp_, msq_w_, U_, scale_w_, grad_entity_;
-    DevBuf<double> stats_fwd_, stats_bwd_;   // [2 de], [1 + 2 de] = loss | Σdy | Σdy·x̂
+    DevBuf<double> stats_;                   // [2 de | 1 + 2 de] = Σx Σx² | loss Σdy Σdy·x̂ — cleared by one memset per step
+    double* stats_fwd_ = nullptr;
+    double* stats_bwd_ = nullptr;
     DevBuf<float> bn_mean_, bn_inv_std_, dbeta_, dgamma_;
     DevBuf<float> gT_, gb_, gT_partial_;
     int gemm_slabs_want_ = 128;

@@ -30,44 +30,61 @@ __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* _
 // parallel (level 1); rows with more than kFan level-1 chunks additionally get level-2 chunks, each the ordered
 // sum of kFan level-1 partials, so that no thread group ever walks more than max(kChunk, kFan) items serially
 // (until a row exceeds kChunk·kFan² entries) and every sum has a fixed order: results are run-to-run deterministic.
+// csr_chunks_kernel only reserves the chunk ranges of the long rows; the descriptors are written by
+// csr_chunk_fill_kernel, one thread per entry (a row-serial fill took 94 us for the Zipf head word).
 __global__ void csr_chunks_kernel(const int* __restrict__ row_begin, const int* __restrict__ row_end, int64_t rows,
-                                  int* __restrict__ chunk_base, int* __restrict__ chunk_desc,
-                                  int* __restrict__ chunk2_base, int* __restrict__ chunk2_desc,
-                                  int* __restrict__ num_chunks, int max_chunks, int max_chunks2) {
+                                  int* __restrict__ chunk_base, int* __restrict__ chunk2_base, int* __restrict__ num_chunks) {
     for (int64_t r = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; r < rows;
          r += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int b = row_begin[r], e = row_end[r];
-        const int cnt = e - b;
+        const int cnt = row_end[r] - row_begin[r];
         if (cnt > kChunk) {
             const int nch = (cnt + kChunk - 1) / kChunk;
-            const int base = atomicAdd(num_chunks, nch);
-            chunk_base[r] = base;
-            for (int c = 0; c < nch && base + c < max_chunks; ++c) {
-                chunk_desc[(base + c) * 3 + 0] = static_cast<int>(r);
-                chunk_desc[(base + c) * 3 + 1] = b + c * kChunk;
-                chunk_desc[(base + c) * 3 + 2] = min(e, b + (c + 1) * kChunk);
-            }
-            if (nch > kFan) {
-                const int n2 = (nch + kFan - 1) / kFan;
-                const int base2 = atomicAdd(num_chunks + 1, n2);
-                chunk2_base[r] = base2;
-                for (int c = 0; c < n2 && base2 + c < max_chunks2; ++c) {
-                    chunk2_desc[(base2 + c) * 2 + 0] = base + c * kFan;
-                    chunk2_desc[(base2 + c) * 2 + 1] = base + min(nch, (c + 1) * kFan);
-                }
+            chunk_base[r] = atomicAdd(num_chunks, nch);
+            if (nch > kFan) chunk2_base[r] = atomicAdd(num_chunks + 1, (nch + kFan - 1) / kFan);
+        }
+    }
+}
+
+__global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, const int* __restrict__ row_begin,
+                                      const int* __restrict__ row_end, const int* __restrict__ chunk_base,
+                                      const int* __restrict__ chunk2_base, int* __restrict__ chunk_desc,
+                                      int* __restrict__ chunk2_desc, int max_chunks, int max_chunks2) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int r = key[i];
+        const int b = row_begin[r], e = row_end[r];
+        const int cnt = e - b;
+        const int rel = static_cast<int>(i) - b;
+        if (cnt <= kChunk || rel % kChunk != 0) continue;
+        const int c = rel / kChunk;                       // this entry opens level-1 chunk c of row r
+        const int nch = (cnt + kChunk - 1) / kChunk;
+        const int base = chunk_base[r];
+        if (base + c < max_chunks) {
+            chunk_desc[(base + c) * 3 + 0] = r;
+            chunk_desc[(base + c) * 3 + 1] = static_cast<int>(i);
+            chunk_desc[(base + c) * 3 + 2] = min(e, static_cast<int>(i) + kChunk);
+        }
+        if (nch > kFan && c % kFan == 0) {                // ... and level-2 chunk c / kFan
+            const int c2 = c / kFan;
+            const int base2 = chunk2_base[r];
+            if (base2 + c2 < max_chunks2) {
+                chunk2_desc[(base2 + c2) * 2 + 0] = base + c;
+                chunk2_desc[(base2 + c2) * 2 + 1] = base + min(nch, c + kFan);
             }
         }
     }
 }
 
 void launch_csr_build(const Csr& c, hipStream_t s) {
-    (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * c.rows, s);
-    (void)hipMemsetAsync(c.row_end, 0, sizeof(int) * c.rows, s);
-    (void)hipMemsetAsync(c.num_chunks, 0, 2 * sizeof(int), s);
+    // row_begin | row_end | num_chunks are one allocation (model.cpp): a single memset clears all three
+    (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * (2 * c.rows + 2), s);
     if (c.n > 0)
         hipLaunchKernelGGL(csr_bounds_kernel, dim3(stream_grid(c.n, 256)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end);
     hipLaunchKernelGGL(csr_chunks_kernel, dim3(stream_grid(c.rows, 256)), dim3(256), 0, s, c.row_begin, c.row_end, c.rows,
-                       c.chunk_base, c.chunk_desc, c.chunk2_base, c.chunk2_desc, c.num_chunks, c.max_chunks, c.max_chunks2);
+                       c.chunk_base, c.chunk2_base, c.num_chunks);
+    if (c.n > 0)
+        hipLaunchKernelGGL(csr_chunk_fill_kernel, dim3(stream_grid(c.n, 256)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin,
+                           c.row_end, c.chunk_base, c.chunk2_base, c.chunk_desc, c.chunk2_desc, c.max_chunks, c.max_chunks2);
 }
 
 // =============================================================================================

@@ -91,7 +91,9 @@ def lib():
         "nvsm_last_error": (cp, []), "nvsm_version": (cp, []), "nvsm_device_count": (C.c_int, []),
         "nvsm_config_default": (None, [P(NvsmConfig)]),
         "nvsm_create": (C.c_int, [P(NvsmConfig), P(vp)]), "nvsm_destroy": (None, [vp]),
-        "nvsm_initialize": (C.c_int, [vp, C.c_uint64]),
+        "nvsm_initialize": (C.c_int, [vp, C.c_uint64]), "nvsm_initialize_from_rng_state": (C.c_int, [vp]),
+        "nvsm_host_alloc": (C.c_int, [C.c_size_t, P(vp)]), "nvsm_host_free": (C.c_int, [vp]),
+        "nvsm_comm_selftest": (C.c_int, [C.c_int]),
         "nvsm_rng_get_state": (C.c_int, [vp, P(C.c_uint64)]), "nvsm_rng_set_state": (C.c_int, [vp, C.c_uint64]),
         "nvsm_param_size": (C.c_int, [vp, cp, P(i64)]),
         "nvsm_get_param": (C.c_int, [vp, cp, vp, i64]), "nvsm_set_param": (C.c_int, [vp, cp, vp, i64]),

@@ -7,6 +7,7 @@
 
 namespace cunvsm {
 void rccl_unique_id(char id[128]);
+void rccl_selftest(int device);
 }
 
 using cunvsm::Error;
@@ -79,6 +80,13 @@ void nvsm_destroy(nvsm_model* m) {
 }
 
 int nvsm_initialize(nvsm_model* m, uint64_t seed) { NVSM_REQUIRE(m); return guarded([&] { m->impl.initialize(seed); }); }
+int nvsm_initialize_from_rng_state(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.initialize_from_rng_state(); }); }
+int nvsm_host_alloc(size_t bytes, void** out) {
+    NVSM_REQUIRE(out);
+    *out = nullptr;
+    return guarded([&] { NVSM_HIP_CHECK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault)); });
+}
+int nvsm_host_free(void* p) { return guarded([&] { if (p) NVSM_HIP_CHECK(hipHostFree(p)); }); }
 int nvsm_rng_get_state(nvsm_model* m, uint64_t* state) { NVSM_REQUIRE(m); NVSM_REQUIRE(state); return guarded([&] { *state = m->impl.rng_get_state(); }); }
 int nvsm_rng_set_state(nvsm_model* m, uint64_t state) { NVSM_REQUIRE(m); return guarded([&] { m->impl.rng_set_state(state); }); }
 
@@ -122,6 +130,7 @@ int nvsm_synchronize(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->i
 
 int nvsm_comm_unique_id(char id[128]) { NVSM_REQUIRE(id); return guarded([&] { cunvsm::rccl_unique_id(id); }); }
 int nvsm_comm_init(nvsm_model* m, const char id[128]) { NVSM_REQUIRE(m); NVSM_REQUIRE(id); return guarded([&] { m->impl.comm_init(id); }); }
+int nvsm_comm_selftest(int device) { return guarded([&] { cunvsm::rccl_selftest(device); }); }
 int nvsm_set_allreduce_callback(nvsm_model* m, nvsm_allreduce_fn fn, void* user) {
     NVSM_REQUIRE(m);
     return guarded([&] { m->impl.set_allreduce_callback(fn, user); });

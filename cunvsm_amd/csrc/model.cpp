@@ -43,6 +43,35 @@ struct RcclApi {
     }
 };
 
+// 1-rank communicator + the two all-reduce flavours of the step, on a private stream (nvsm_comm_selftest)
+void rccl_selftest(int device) {
+    RcclApi* api = RcclApi::load();
+    NVSM_HIP_CHECK(hipSetDevice(device));
+    RcclApi::UniqueId u;
+    if (api->GetUniqueId(&u) != 0) throw Error(NVSM_ERR_DEVICE, "ncclGetUniqueId failed");
+    void* comm = nullptr;
+    if (api->CommInitRank(&comm, 1, u, 0) != 0) throw Error(NVSM_ERR_DEVICE, "ncclCommInitRank(1 rank) failed");
+    hipStream_t s;
+    NVSM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    const int n = 1024;
+    DevBuf<float> f; DevBuf<double> d;
+    f.alloc(n); d.alloc(n);
+    std::vector<float> hf(n); std::vector<double> hd(n);
+    for (int i = 0; i < n; ++i) { hf[i] = 0.5f * i; hd[i] = 0.25 * i; }
+    NVSM_HIP_CHECK(hipMemcpy(f.p, hf.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    NVSM_HIP_CHECK(hipMemcpy(d.p, hd.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    int rc = api->AllReduce(f.p, f.p, n, RcclApi::kFloat32, RcclApi::kSum, comm, s);
+    if (rc == 0) rc = api->AllReduce(d.p, d.p, n, RcclApi::kFloat64, RcclApi::kSum, comm, s);
+    NVSM_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<float> rf(n); std::vector<double> rd(n);
+    NVSM_HIP_CHECK(hipMemcpy(rf.data(), f.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    NVSM_HIP_CHECK(hipMemcpy(rd.data(), d.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    api->CommDestroy(comm);
+    (void)hipStreamDestroy(s);
+    if (rc != 0) throw Error(NVSM_ERR_DEVICE, "ncclAllReduce failed in the self-test");
+    if (rf != hf || rd != hd) throw Error(NVSM_ERR_DEVICE, "1-rank all-reduce did not return its input (wrong dtype / op enum?)");
+}
+
 void rccl_unique_id(char id[128]) {
     RcclApi* api = RcclApi::load();
     RcclApi::UniqueId u;
@@ -226,6 +255,12 @@ void Model::initialize(uint64_t seed) {
     if (seed == 0) throw Error(NVSM_ERR_INVALID_ARGUMENT, "Please specify a seed value > 0");   // cpp/main.cu:708
     rng_.seed(static_cast<std::minstd_rand0::result_type>(seed));
     device_seed_ = seed;
+    initialize_from_rng_state();
+}
+
+void Model::initialize_from_rng_state() {
+    NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    if (device_seed_ == 0) device_seed_ = 1;
     auto glorot = [&](DevBuf<float>& dst, size_t rows, size_t cols) {
         std::vector<float> h(rows * cols);
         const float max = std::sqrt(6.0 / static_cast<double>(rows + cols));

@@ -95,6 +95,7 @@ class Model {
     ~Model();
 
     void initialize(uint64_t seed);
+    void initialize_from_rng_state();      // Glorot draws continue from the generator's current state
     uint64_t rng_get_state();
     void rng_set_state(uint64_t s);
 

@@ -1,0 +1,398 @@
+// cuNVSMTrainModel — the reference's trainer (cpp/main.cu) on top of libcunvsm_amd.so's C ABI: same option names,
+// defaults and validation (cpp/main.cu:15-76,623-721), same training loop (iterate_data :366-469, train :492-621),
+// same log lines and the same outputs ("<output>_meta" protobuf, "<output>_<epoch>[_<batch>].hdf5").
+//
+// Differences, all forced by what exists on this platform:
+//   * <path to Indri index> is a TREC-text collection file: libindri and its on-disk format are not available, the
+//     index is rebuilt in memory (host/trectext_index.hpp); a directory holding an Indri "manifest" is refused.
+//   * only TextEntity::Objective (LSE / NVSM) is accelerated: non-zero --entity_similarity_weight /
+//     --term_similarity_weight, --check_gradients and the l2 normalisers are refused with a clear message.
+//   * extensions: --stopwords, --device, --sampler {host,device}, --allow_ragged_batches.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cmath>
+#include <fstream>
+#include <iomanip>
+#include <memory>
+#include <set>
+
+#include "../../include/cunvsm_amd.h"
+#include "data.hpp"
+#include "flags.hpp"
+#include "hdf5_writer.hpp"
+#include "index_source.hpp"
+#include "trectext_index.hpp"
+
+using namespace nvsm_host;
+
+namespace {
+
+uint64_t FLAGS_num_epochs, FLAGS_document_cutoff, FLAGS_word_repr_size, FLAGS_entity_repr_size, FLAGS_batch_size, FLAGS_window_size,
+    FLAGS_num_random_entities, FLAGS_seed, FLAGS_max_vocabulary_size, FLAGS_min_document_frequency;
+std::string FLAGS_document_list, FLAGS_term_blacklist, FLAGS_update_method, FLAGS_weighting, FLAGS_feature_weighting, FLAGS_nonlinearity,
+    FLAGS_output, FLAGS_stopwords, FLAGS_sampler;
+double FLAGS_regularization_lambda, FLAGS_learning_rate, FLAGS_max_document_frequency, FLAGS_entity_similarity_weight,
+    FLAGS_term_similarity_weight;
+bool FLAGS_bias_negative_samples, FLAGS_l2_phrase_normalization, FLAGS_l2_entity_normalization, FLAGS_batch_normalization,
+    FLAGS_include_oov, FLAGS_compute_initial_cost, FLAGS_check_gradients, FLAGS_no_shuffle, FLAGS_dump_initial_model,
+    FLAGS_allow_ragged_batches, FLAGS_logtostderr, FLAGS_alsologtostderr;
+int64_t FLAGS_dump_every, FLAGS_v, FLAGS_device, FLAGS_minloglevel;
+
+void define_flags(Flags* f) {      // names, defaults and help strings of cpp/main.cu:15-76
+    f->define_uint64("num_epochs", &FLAGS_num_epochs, 100000, "Number of training iterations.");
+    f->define_uint64("document_cutoff", &FLAGS_document_cutoff, 0, "Number of documents per epoch (default: all).");
+    f->define_string("document_list", &FLAGS_document_list, "", "Path to document list (default: all).");
+    f->define_string("term_blacklist", &FLAGS_term_blacklist, "", "Path to term blacklist (default: none).");
+    f->define_uint64("word_repr_size", &FLAGS_word_repr_size, 4, "Dimensionality of word representations.");
+    f->define_uint64("entity_repr_size", &FLAGS_entity_repr_size, 4, "Dimensionality of entity representations.");
+    f->define_uint64("batch_size", &FLAGS_batch_size, 1024, "Size of training batches.");
+    f->define_uint64("window_size", &FLAGS_window_size, 8, "Size of training word windows.");
+    f->define_uint64("num_random_entities", &FLAGS_num_random_entities, 1, "Number of random negative examples sampled for each positive example.");
+    f->define_uint64("seed", &FLAGS_seed, 0, "Pseudo-random number generator seed.");
+    f->define_double("regularization_lambda", &FLAGS_regularization_lambda, 0.01, "Regularization lambda.");
+    f->define_double("learning_rate", &FLAGS_learning_rate, 0.0, "Learning rate.");
+    f->define_string("update_method", &FLAGS_update_method, "", "Update method (sgd, adagrad, sparse_adam, dense_adam or full_adam).");
+    f->define_string("weighting", &FLAGS_weighting, "auto", "Instance weighting strategy (auto, uniform or inv_doc_frequency).");
+    f->define_string("feature_weighting", &FLAGS_feature_weighting, "uniform", "Feature weighting strategy (uniform or self_information).");
+    f->define_bool("bias_negative_samples", &FLAGS_bias_negative_samples, false, "Introduces a bias towards negative samples. This is considered a bug in the CIKM model.");
+    f->define_string("nonlinearity", &FLAGS_nonlinearity, "", "Nonlinearity (tanh or hard_tanh).");
+    f->define_bool("l2_phrase_normalization", &FLAGS_l2_phrase_normalization, false, "Enables l2 normalization of phrase representations.");
+    f->define_bool("l2_entity_normalization", &FLAGS_l2_entity_normalization, false, "Enables l2 normalization of entity representations.");
+    f->define_bool("batch_normalization", &FLAGS_batch_normalization, false, "Enables batch normalization.");
+    f->define_uint64("max_vocabulary_size", &FLAGS_max_vocabulary_size, 60000, "Maximum vocabulary size.");
+    f->define_uint64("min_document_frequency", &FLAGS_min_document_frequency, 2, "Minimum document frequency of term in order to be retained by vocabulary filtering.");
+    f->define_double("max_document_frequency", &FLAGS_max_document_frequency, 0.5, "Maximum document frequency of term in order to be retained by vocabulary filtering. If smaller than 1.0, then max_document_frequency is interpreted as relative to the index size; otherwise, it is considered an absolute threshold.");
+    f->define_bool("include_oov", &FLAGS_include_oov, false, "Whether to include a special-purpose OoV token for term positions with a filtered dictionary term.");
+    f->define_bool("compute_initial_cost", &FLAGS_compute_initial_cost, false, "Compute the cost before any learning is performed.");
+    f->define_bool("check_gradients", &FLAGS_check_gradients, false, "Enable gradient checking. CAUTION: this will lead to insanely slow learning.");
+    f->define_bool("no_shuffle", &FLAGS_no_shuffle, false, "Do not shuffle the training set.");
+    f->define_bool("dump_initial_model", &FLAGS_dump_initial_model, false, "Dump the model after random initialization, but before training.");
+    f->define_int64("dump_every", &FLAGS_dump_every, 0, "Number of batches that should be processed before the model is dumped during a single epoch. The model is always dumped at the end of every epoch.");
+    f->define_double("entity_similarity_weight", &FLAGS_entity_similarity_weight, 0.0, "Mixture weight of the entity-entity objective.");
+    f->define_double("term_similarity_weight", &FLAGS_term_similarity_weight, 0.0, "Mixture weight of the term-term objective.");
+    f->define_string("output", &FLAGS_output, "", "Path to output model.");
+    // extensions
+    f->define_string("stopwords", &FLAGS_stopwords, "", "Stop list applied while indexing the collection (Indri <word> parameter file or plain words).");
+    f->define_int64("device", &FLAGS_device, 0, "HIP device ordinal.");
+    f->define_string("sampler", &FLAGS_sampler, "host", "Negative sampler: host (minstd_rand0, draw-for-draw the reference) or device.");
+    f->define_bool("allow_ragged_batches", &FLAGS_allow_ragged_batches, false, "Train on batches whose size is not a multiple of 1024 instead of skipping them as the reference does.");
+    // glog's own options that the reference's scripts pass
+    f->define_bool("logtostderr", &FLAGS_logtostderr, true, "Log to stderr (there is no log-file sink).");
+    f->define_bool("alsologtostderr", &FLAGS_alsologtostderr, true, "Accepted for compatibility.");
+    f->define_int64("v", &FLAGS_v, 0, "Verbosity of VLOG messages.");
+    f->define_int64("minloglevel", &FLAGS_minloglevel, 0, "Accepted for compatibility.");
+}
+
+void check_status(int status, const char* what) {
+    if (status != NVSM_OK) NVSM_LOG(FATAL) << what << ": " << nvsm_last_error();
+}
+#define NVSM_CALL(expr) check_status((expr), #expr)
+
+uint64_t rng_state(const RNG& rng) { std::stringstream ss; ss << rng; uint64_t s; ss >> s; return s; }
+void rng_set_state(RNG* rng, uint64_t s) { std::stringstream ss; ss << s; ss >> *rng; }
+
+template <typename T>
+std::string vec_to_string(const std::vector<T>& v) {          // include/cuNVSM/base.h:121-128
+    std::ostringstream os;
+    os << std::setprecision(20) << "[";
+    for (const T& x : v) os << x << ", ";
+    os << "]";
+    return os.str();
+}
+
+template <typename ContainerT>
+ContainerT* read_strings(const std::string& path) {           // cpp/main.cu:148-163
+    std::ifstream file(path);
+    NVSM_CHECK(file.good()) << "cannot read " << path;
+    ContainerT* strings = new ContainerT;
+    std::string str;
+    while (std::getline(file, str)) if (!str.empty()) strings->insert(strings->end(), str);
+    return strings;
+}
+
+bool is_directory(const std::string& path) { struct stat st; return stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+bool is_file(const std::string& path) { struct stat st; return stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+
+struct TrainConfig {
+    uint64_t num_epochs, batch_size, window_size, num_random_entities;
+    float regularization_lambda, learning_rate;
+    int update_method, adam_mode;
+    bool no_shuffle;
+};
+
+class Trainer {
+ public:
+    Trainer(nvsm_model* model, const TrainConfig& tc, int64_t num_words, int64_t num_entities, int dw, int de)
+        : model_(model), tc_(tc), num_words_(num_words), num_entities_(num_entities), dw_(dw), de_(de) {}
+
+    // DumpModelFn (cpp/main.cu:335-364) + write_to_hdf5 (include/cuNVSM/lse_hdf5_inl.h)
+    void dump_model(size_t epoch, const std::string& identifier) {
+        if (FLAGS_output.empty()) return;
+        std::stringstream ss;
+        ss << FLAGS_output << "_" << epoch;
+        if (!identifier.empty()) ss << "_" << identifier;
+        ss << ".hdf5";
+        const std::string filename = ss.str();
+        std::vector<float> E(static_cast<size_t>(num_entities_) * de_), b(de_), T(static_cast<size_t>(de_) * dw_), W(static_cast<size_t>(num_words_) * dw_);
+        NVSM_CALL(nvsm_get_param(model_, "entity_representations-representations", E.data(), static_cast<int64_t>(E.size())));
+        NVSM_CALL(nvsm_get_param(model_, "word_entity_mapping-bias", b.data(), static_cast<int64_t>(b.size())));
+        NVSM_CALL(nvsm_get_param(model_, "word_entity_mapping-transform", T.data(), static_cast<int64_t>(T.size())));
+        NVSM_CALL(nvsm_get_param(model_, "word_representations-representations", W.data(), static_cast<int64_t>(W.size())));
+        // ModelBase::get_data() is a std::map: datasets are created in name order; dims {cols, rows} (cpp/hdf5.cu:33-35)
+        write_hdf5(filename, {
+            {"entity_representations-representations", static_cast<unsigned long long>(num_entities_), static_cast<unsigned long long>(de_), E.data()},
+            {"word_entity_mapping-bias", 1ull, static_cast<unsigned long long>(de_), b.data()},
+            {"word_entity_mapping-transform", static_cast<unsigned long long>(dw_), static_cast<unsigned long long>(de_), T.data()},
+            {"word_representations-representations", static_cast<unsigned long long>(num_words_), static_cast<unsigned long long>(dw_), W.data()}});
+        NVSM_LOG(INFO) << "Saved model to " << filename << ".";
+    }
+
+    // iterate_data (cpp/main.cu:366-469)
+    std::pair<size_t, float> iterate_data(bool backpropagate, DataSourceInterface* data_source, Batch* batch, size_t dump_epoch, bool may_dump) {
+        size_t epoch_num_batches = 0;
+        float agg_cost = 0.0;
+        const auto iteration_start = std::chrono::steady_clock::now();
+        while (data_source->has_next()) {
+            const auto batch_start = std::chrono::steady_clock::now();
+            batch->clear();
+            data_source->next(batch);
+            const size_t n = batch->num_instances();
+            if (n % 1024 != 0 && !FLAGS_allow_ragged_batches) {                        // maxThreadsPerBlock, :392-398
+                NVSM_LOG(ERROR) << "Skipping Batch #" << epoch_num_batches << " as it is not a multiple of " << 1024 << " (" << n << " instances).";
+            } else if (n > 0) {
+                nvsm_batch b;
+                b.features = batch->features(); b.feature_weights = batch->feature_weights();
+                b.labels = batch->labels(); b.weights = batch->weights();
+                b.num_instances = static_cast<int64_t>(n); b.on_device = 0;
+                NVSM_CALL(nvsm_compute_cost(model_, &b, nullptr));
+                NVSM_CALL(nvsm_compute_gradients(model_));
+                if (backpropagate) NVSM_CALL(nvsm_update(model_, tc_.learning_rate, nvsm_scaled_regularization_lambda(model_)));
+                float cost = 0.f;
+                NVSM_CALL(nvsm_get_cost(model_, &cost));
+                agg_cost += cost;
+                windows_ += n;
+                if (verbosity() >= 1) {
+                    const double epoch_duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - iteration_start).count();
+                    const double batch_duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - batch_start).count();
+                    const double progress = data_source->progress();
+                    std::string remaining = "unknown time";
+                    if (progress > 0.0 && std::isfinite(progress)) remaining = seconds_to_humanreadable_time((1.0 - progress) * (epoch_duration / progress));
+                    NVSM_LOG(INFO) << "Batch #" << epoch_num_batches << " (" << std::setprecision(8) << progress * 100.0 << "%; " << remaining
+                                   << " remaining): cost=" << cost << ", duration=" << batch_duration;
+                }
+            }
+            if (may_dump && FLAGS_dump_every > 0 && epoch_num_batches > 0 && epoch_num_batches % static_cast<size_t>(FLAGS_dump_every) == 0)
+                dump_model(dump_epoch, std::to_string(epoch_num_batches));
+            ++epoch_num_batches;
+        }
+        NVSM_CHECK(epoch_num_batches > 0) << "No batches to train during epoch";
+        return std::make_pair(epoch_num_batches, agg_cost);
+    }
+
+    uint64_t windows() const { return windows_; }
+
+ private:
+    nvsm_model* model_;
+    TrainConfig tc_;
+    int64_t num_words_, num_entities_;
+    int dw_, de_;
+    uint64_t windows_ = 0;
+};
+
+void* pinned_alloc(size_t bytes) { void* p = nullptr; check_status(nvsm_host_alloc(bytes, &p), "nvsm_host_alloc"); return p; }
+void pinned_free(void* p) { (void)nvsm_host_free(p); }
+
+int run(int argc, char** argv) {
+    Flags flags;
+    define_flags(&flags);
+    const std::vector<std::string> args = flags.parse(argc, argv);
+    verbosity() = static_cast<int>(FLAGS_v);
+    log_to_stderr() = FLAGS_logtostderr || FLAGS_alsologtostderr;
+
+    if (args.size() < 2) {
+        std::cerr << "Usage: " << args[0] << " [OPTIONS] <path to TREC-text collection>\n" << flags.usage();
+        NVSM_LOG(FATAL) << "Check failed: argc >= 2 Usage: " << args[0] << " [OPTIONS] <path to Indri index>";
+    }
+    static const std::map<std::string, std::pair<int, int>> UPDATE_METHODS = {                         // cpp/main.cu:479-485
+        {"sgd", {NVSM_SGD, NVSM_ADAM_NONE}}, {"adagrad", {NVSM_ADAGRAD, NVSM_ADAM_NONE}}, {"sparse_adam", {NVSM_ADAM, NVSM_ADAM_SPARSE}},
+        {"dense_adam", {NVSM_ADAM, NVSM_ADAM_DENSE_UPDATE}}, {"full_adam", {NVSM_ADAM, NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE}}};
+    static const std::map<std::string, WeightingStrategy> WEIGHTING_STRATEGIES = {
+        {"auto", AUTOMATIC_WEIGHTING}, {"uniform", UNIFORM}, {"inv_doc_frequency", INV_DOC_FREQUENCY}};  // :136-140
+    static const std::map<std::string, TermWeightingStrategy> FEATURE_WEIGHTING_STRATEGIES = {
+        {"uniform", UNIFORM_TERM_WEIGHTING}, {"self_information", SELF_INFORMATION_TERM_WEIGHTING}};    // :142-145
+    static const std::map<std::string, int> NONLINEARITIES = {{"tanh", NVSM_TANH}, {"hard_tanh", NVSM_HARD_TANH}};   // :487-490
+    NVSM_CHECK(UPDATE_METHODS.count(FLAGS_update_method)) << "Please specify a valid --update_method.";
+    NVSM_CHECK(WEIGHTING_STRATEGIES.count(FLAGS_weighting)) << "Please specify a valid --weighting.";
+    NVSM_CHECK(FEATURE_WEIGHTING_STRATEGIES.count(FLAGS_feature_weighting)) << "Please specify a valid --feature_weighting.";
+    NVSM_CHECK(NONLINEARITIES.count(FLAGS_nonlinearity)) << "Please specify a valid --nonlinearity.";
+    NVSM_CHECK(FLAGS_sampler == "host" || FLAGS_sampler == "device") << "--sampler must be host or device.";
+
+    const std::string repository_path = args[1];
+    if (is_directory(repository_path))
+        NVSM_LOG(FATAL) << repository_path << " is a directory: Indri repositories cannot be read here (libindri and its on-disk format are "
+                           "not available); pass the TREC-text collection file the index was built from.";
+    NVSM_CHECK(is_file(repository_path)) << "cannot read collection " << repository_path;
+
+    NVSM_LOG(INFO) << "Indexing " << repository_path << ".";
+    std::unique_ptr<TrectextIndex> index(TrectextIndex::from_file(repository_path, FLAGS_stopwords));
+    NVSM_LOG(INFO) << "Indexed " << index->documentCount() << " documents, " << index->termCount() << " term occurrences, "
+                   << index->uniqueTermCount() << " unique terms.";
+
+    NVSM_CHECK(FLAGS_max_vocabulary_size > 0);
+    uint64_t max_document_frequency = 0;                                               // cpp/main.cu:662-671
+    if (FLAGS_max_document_frequency <= 1.0) {
+        max_document_frequency = static_cast<uint64_t>(std::ceil(index->documentCount() * FLAGS_max_document_frequency));
+        NVSM_LOG(INFO) << "Setting max_document_frequency to " << max_document_frequency << ".";
+    } else {
+        max_document_frequency = static_cast<uint64_t>(FLAGS_max_document_frequency);
+    }
+
+    TrainConfig tc;
+    tc.num_epochs = FLAGS_num_epochs; tc.batch_size = FLAGS_batch_size; tc.window_size = FLAGS_window_size;
+    tc.num_random_entities = FLAGS_num_random_entities;
+    tc.regularization_lambda = static_cast<float>(FLAGS_regularization_lambda);
+    tc.learning_rate = static_cast<float>(FLAGS_learning_rate);
+    tc.update_method = UPDATE_METHODS.at(FLAGS_update_method).first;
+    tc.adam_mode = UPDATE_METHODS.at(FLAGS_update_method).second;
+    tc.no_shuffle = FLAGS_no_shuffle;
+    NVSM_CHECK(FLAGS_entity_similarity_weight >= 0.0 && FLAGS_entity_similarity_weight <= 1.0);
+    NVSM_CHECK(FLAGS_term_similarity_weight >= 0.0 && FLAGS_term_similarity_weight <= 1.0);
+    NVSM_CHECK(FLAGS_seed > 0) << "Please specify a --seed value.";
+    if (tc.learning_rate == 0.0f) tc.learning_rate = (tc.update_method == NVSM_ADAM) ? 0.001f : 0.01f;   // :710-721
+    if (FLAGS_entity_similarity_weight != 0.0 || FLAGS_term_similarity_weight != 0.0)
+        NVSM_LOG(FATAL) << "only the text-entity objective (LSE / NVSM) is implemented on this platform; "
+                           "--entity_similarity_weight and --term_similarity_weight must be 0.";
+    if (FLAGS_check_gradients)
+        NVSM_LOG(FATAL) << "--check_gradients is not available in the trainer; the full-parameter gradient check runs in the test-suite.";
+
+    NVSM_LOG(INFO) << "Model descriptor: word_repr_size: " << FLAGS_word_repr_size << " entity_repr_size: " << FLAGS_entity_repr_size
+                   << " transform_desc { batch_normalization: " << (FLAGS_batch_normalization ? "true" : "false") << " nonlinearity: "
+                   << (NONLINEARITIES.at(FLAGS_nonlinearity) == NVSM_TANH ? "TANH" : "HARD_TANH") << " } clip_sigmoid: true bias_negative_samples: "
+                   << (FLAGS_bias_negative_samples ? "true" : "false");
+    NVSM_LOG(INFO) << "Data configuration: repository_path: \"" << repository_path << "\" max_vocabulary_size: " << FLAGS_max_vocabulary_size
+                   << " min_document_frequency: " << FLAGS_min_document_frequency << " max_document_frequency: " << max_document_frequency
+                   << " include_oov: " << (FLAGS_include_oov ? "true" : "false");
+    NVSM_LOG(INFO) << "Training configuration: num_epochs: " << tc.num_epochs << " batch_size: " << tc.batch_size << " window_size: "
+                   << tc.window_size << " num_random_entities: " << tc.num_random_entities << " regularization_lambda: " << tc.regularization_lambda
+                   << " learning_rate: " << tc.learning_rate << " update_method: " << FLAGS_update_method << " no_shuffle: " << (tc.no_shuffle ? "true" : "false");
+    NVSM_LOG(INFO) << "FLOATING_POINT_TYPE=float32";
+
+    RNG rng;
+    rng.seed(static_cast<RNG::result_type>(FLAGS_seed));                                 // cpp/main.cu:729-730
+
+    if (nvsm_device_count() < 1) NVSM_LOG(FATAL) << "no HIP device visible: cuNVSMTrainModel has no CPU path.";
+    set_batch_allocator(pinned_alloc, pinned_free);
+
+    // construct_data_source<TextEntity::Objective> (:228-238): IndriSource wrapped in AsyncSource(10 batches)
+    std::unique_ptr<std::vector<std::string>> document_list;
+    if (!FLAGS_document_list.empty()) {
+        NVSM_LOG(INFO) << "Reading document list from " << FLAGS_document_list << ".";
+        document_list.reset(read_strings<std::vector<std::string>>(FLAGS_document_list));
+    }
+    std::unique_ptr<IndexSource::TermBlacklist> term_blacklist;
+    if (!FLAGS_term_blacklist.empty()) {
+        NVSM_LOG(INFO) << "Reading term blacklist from " << FLAGS_term_blacklist << ".";
+        term_blacklist.reset(read_strings<IndexSource::TermBlacklist>(FLAGS_term_blacklist));
+    }
+    IndexSource* index_source = new IndexSource(
+        index.release(), tc.window_size, &rng, FLAGS_max_vocabulary_size, FLAGS_min_document_frequency, max_document_frequency,
+        FLAGS_document_cutoff, FLAGS_include_oov, false /* include_digits */, document_list.get(), term_blacklist.get(),
+        !tc.no_shuffle, AUTOMATIC_SAMPLING, WEIGHTING_STRATEGIES.at(FLAGS_weighting), FEATURE_WEIGHTING_STRATEGIES.at(FLAGS_feature_weighting));
+    std::unique_ptr<DataSourceInterface> data_source(new AsyncSource(10, tc.batch_size, tc.window_size, index_source));
+
+    Metadata meta;
+    data_source->extract_metadata(&meta);
+    const size_t vocabulary_size = meta.term_size(), corpus_size = meta.object_size();
+    NVSM_CHECK(vocabulary_size > 0);
+    NVSM_CHECK(corpus_size > 0);
+    NVSM_LOG(INFO) << "Training statistics: vocabulary size=" << vocabulary_size << ", corpus size=" << corpus_size;
+
+    nvsm_config cfg;
+    nvsm_config_default(&cfg);
+    cfg.num_words = static_cast<int64_t>(vocabulary_size); cfg.num_entities = static_cast<int64_t>(corpus_size);
+    cfg.word_repr_size = static_cast<int32_t>(FLAGS_word_repr_size); cfg.entity_repr_size = static_cast<int32_t>(FLAGS_entity_repr_size);
+    cfg.batch_normalization = FLAGS_batch_normalization; cfg.nonlinearity = NONLINEARITIES.at(FLAGS_nonlinearity);
+    cfg.clip_sigmoid = 1;                                                                // :645
+    cfg.bias_negative_samples = FLAGS_bias_negative_samples;
+    cfg.l2_normalize_phrase_reprs = FLAGS_l2_phrase_normalization; cfg.l2_normalize_entity_reprs = FLAGS_l2_entity_normalization;
+    cfg.window_size = static_cast<int32_t>(tc.window_size); cfg.num_random_entities = static_cast<int32_t>(tc.num_random_entities);
+    cfg.regularization_lambda = tc.regularization_lambda;
+    cfg.update_method = tc.update_method; cfg.adam_mode = tc.adam_mode;
+    cfg.max_batch_size = static_cast<int32_t>(tc.batch_size);
+    cfg.device = static_cast<int32_t>(FLAGS_device);
+    cfg.sampler = FLAGS_sampler == "host" ? NVSM_SAMPLER_HOST_MINSTD : NVSM_SAMPLER_DEVICE;
+    nvsm_model* model = nullptr;
+    NVSM_CALL(nvsm_create(&cfg, &model));
+    // model.initialize(rng): the SAME generator the data source has just drawn from (cpp/main.cu:497-520)
+    NVSM_CALL(nvsm_rng_set_state(model, rng_state(rng)));
+    NVSM_CALL(nvsm_initialize_from_rng_state(model));
+    NVSM_CALL(nvsm_synchronize(model));
+    const uint64_t num_parameters = vocabulary_size * FLAGS_word_repr_size + corpus_size * FLAGS_entity_repr_size +
+                                    FLAGS_entity_repr_size * FLAGS_word_repr_size + FLAGS_entity_repr_size;
+    NVSM_LOG(INFO) << "Initialized cuNVSM with " << num_parameters << " parameters for training on " << vocabulary_size << " words and "
+                   << corpus_size << " objects.";
+
+    if (!FLAGS_output.empty()) {                                                         // :527-537
+        std::ofstream meta_file(FLAGS_output + "_meta", std::ios::binary);
+        const std::string wire = meta.SerializeAsString();
+        meta_file.write(wire.data(), static_cast<std::streamsize>(wire.size()));
+        NVSM_CHECK(meta_file.good()) << "cannot write " << FLAGS_output << "_meta";
+    }
+
+    Trainer trainer(model, tc, static_cast<int64_t>(vocabulary_size), static_cast<int64_t>(corpus_size),
+                    static_cast<int>(FLAGS_word_repr_size), static_cast<int>(FLAGS_entity_repr_size));
+    Batch batch(tc.batch_size, tc.window_size);
+    std::vector<float> epoch_costs;
+
+    // data_source->reset() re-shuffles with the shared generator (cpp/data_indri.cpp:404): hand the state over and back
+    auto reset_data_source = [&] {
+        uint64_t s = 0;
+        NVSM_CALL(nvsm_rng_get_state(model, &s));
+        rng_set_state(&rng, s);
+        data_source->reset();
+        NVSM_CALL(nvsm_rng_set_state(model, rng_state(rng)));
+    };
+
+    if (FLAGS_compute_initial_cost) {                                                    // :543-561
+        const auto r = trainer.iterate_data(false, data_source.get(), &batch, 0, false);
+        reset_data_source();
+        epoch_costs.push_back(r.second / r.first);
+        NVSM_LOG(INFO) << "Epoch #0 (initial): cost=" << vec_to_string(epoch_costs);
+    }
+    if (FLAGS_dump_initial_model) trainer.dump_model(0, "");
+
+    const auto start = std::chrono::steady_clock::now();
+    size_t num_batches = 0;
+    for (size_t epoch = 1; epoch <= tc.num_epochs; ++epoch) {                            // :575-620
+        const auto epoch_start = std::chrono::steady_clock::now();
+        const uint64_t windows_before = trainer.windows();
+        const auto r = trainer.iterate_data(true, data_source.get(), &batch, epoch, true);
+        num_batches += r.first;
+        const double epoch_duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - epoch_start).count();
+        const double total_duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+        epoch_costs.push_back(r.second / r.first);
+        NVSM_LOG(INFO) << "Epoch #" << epoch << ": duration=" << seconds_to_humanreadable_time(epoch_duration) << " ("
+                       << num_batches / total_duration << " batches/second) cost=" << vec_to_string(epoch_costs);
+        NVSM_VLOG(1) << "Epoch #" << epoch << ": " << (trainer.windows() - windows_before) / epoch_duration << " n-gram windows/second";
+        trainer.dump_model(epoch, "");
+        reset_data_source();
+    }
+    NVSM_CALL(nvsm_synchronize(model));
+    data_source.reset();
+    nvsm_destroy(model);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    try {
+        return run(argc, argv);
+    } catch (const FatalError&) {
+        return 1;                       // the message has been logged (cpp/main.cu:113-134 exits 1 from its terminate handler)
+    } catch (const std::exception& e) {
+        std::cerr << "Exception: " << e.what() << std::endl;
+        return 1;
+    }
+}

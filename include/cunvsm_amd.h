@@ -113,6 +113,16 @@ void nvsm_destroy(nvsm_model* m);
 int nvsm_initialize(nvsm_model* m, uint64_t seed);
 int nvsm_rng_get_state(nvsm_model* m, uint64_t* state);   /* `rng_state << *rng`  (cpp/main.cu:401-402) */
 int nvsm_rng_set_state(nvsm_model* m, uint64_t state);
+/* model.initialize(&rng) with a generator that has ALREADY been consumed: the reference seeds one RNG in main()
+ * (cpp/main.cu:729-730), lets the data source draw from it first (document shuffling, cpp/main.cu:497-499) and only
+ * then initialises the parameters (cpp/main.cu:520). The caller installs that state with nvsm_rng_set_state and
+ * calls this instead of nvsm_initialize(seed). */
+int nvsm_initialize_from_rng_state(nvsm_model* m);
+
+/* Pinned host memory for batches handed over with on_device = 0 — what TextEntity::Batch allocates with
+ * cudaHostAlloc (cpp/data.cu:16-27), so that the H2D copies of compute_cost are truly asynchronous. */
+int nvsm_host_alloc(size_t bytes, void** out);
+int nvsm_host_free(void* p);
 
 /* ModelBase::get_data() (cpp/model.cu:64-93) — the four tensors write_to_hdf5 dumps. Names:
  *   "word_representations-representations"   [num_words][word_repr_size]
@@ -164,6 +174,9 @@ int nvsm_comm_init(nvsm_model* m, const char id[128]);
  * sum it in place across ranks (e.g. torch.distributed gloo). */
 typedef int (*nvsm_allreduce_fn)(double* host_buf, int64_t count, void* user);
 int nvsm_set_allreduce_callback(nvsm_model* m, nvsm_allreduce_fn fn, void* user);
+/* Single-process check of the RCCL plumbing (dlopen, symbols, enum values, stream use): builds a 1-rank communicator
+ * on `device` and all-reduces an f32 and an f64 buffer through the same code path nvsm_step uses with world_size > 1. */
+int nvsm_comm_selftest(int device);
 
 /* Per-kernel timing of the hot path, measured with HIP events on the handle's stream (bench.py's
  * roofline leg). enable=1 records around every launch of subsequent steps (adds sync points at

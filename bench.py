@@ -172,10 +172,25 @@ def main():
                             world_size=world, rank=rank, sync_batch_norm=1)
     model = ca.Model(cfg)
     model.initialize(1)                     # --seed 1 (scripts/functions.sh:393); identical replicas on every rank
+    transport = "single"
     if world > 1:
-        obj = [comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(obj, src=0)
-        model.comm_init(obj[0])
+        # the engine's own RCCL communicator (all-reduces on its stream, no host round trip); if it cannot be built on
+        # this node, fall back to torch.distributed through the host-callback transport so that the run still completes
+        ok = torch.zeros(1, device="cuda")
+        try:
+            obj = [comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(obj, src=0)
+            model.comm_init(obj[0])
+            ok += 1
+        except Exception as e:            # noqa: BLE001
+            sys.stderr.write("rank %d: nvsm_comm_init failed (%s)\n" % (rank, e))
+        dist.all_reduce(ok)
+        if int(ok.item()) == world:
+            transport = "rccl"
+        else:
+            from cunvsm_amd import dp
+            model.set_allreduce_callback(dp.torch_allreduce_device(dist, torch.device("cuda", local_rank)))
+            transport = "torch.distributed(nccl) via host callback"
 
     # synthetic batches, resident in HBM before the timed region
     rs = np.random.RandomState(1234 + rank)
@@ -260,7 +275,7 @@ def main():
                                    "hard_tanh+BN %s lambda=1e-2 lr=1e-3 %s word ids, inputs resident in HBM, device negative sampler"
                                    % (wl["num_words"], wl["num_entities"], B, method,
                                       "uniform" if args.uniform_words else "Zipf(1)"),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "update_method": method,
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "update_method": method, "collectives": transport,
                        "inputs": "host" if args.host_batches else "hbm"},
             "roofline": roofline,
             "kernel_breakdown": breakdown,

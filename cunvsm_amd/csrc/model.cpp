@@ -291,7 +291,7 @@ void Model::comm_init(const char id[128]) {
 
 void Model::allreduce_f64(double* dev, int64_t n) {
     if (cfg_.world_size <= 1) return;
-    if (comm_) {
+    if (comm_ && !ar_fn_) {            // an installed callback takes precedence (every rank must use the same transport)
         const int rc = rccl_->AllReduce(dev, dev, n, RcclApi::kFloat64, RcclApi::kSum, comm_, stream_);
         if (rc != 0) throw Error(NVSM_ERR_DEVICE, "ncclAllReduce(f64) failed");
     } else if (ar_fn_) {
@@ -308,7 +308,7 @@ void Model::allreduce_f64(double* dev, int64_t n) {
 
 void Model::allreduce_f32(float* dev, int64_t n) {
     if (cfg_.world_size <= 1) return;
-    if (comm_) {
+    if (comm_ && !ar_fn_) {
         const int rc = rccl_->AllReduce(dev, dev, n, RcclApi::kFloat32, RcclApi::kSum, comm_, stream_);
         if (rc != 0) throw Error(NVSM_ERR_DEVICE, "ncclAllReduce(f32) failed");
     } else if (ar_fn_) {

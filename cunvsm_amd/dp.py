@@ -40,6 +40,17 @@ def torch_allreduce(dist, group=None):
     return fn
 
 
+def torch_allreduce_device(dist, device, group=None):
+    """As torch_allreduce, for backends that only reduce device tensors (nccl): stages the host buffer through `device`."""
+    import torch
+
+    def fn(buf):
+        t = torch.from_numpy(np.ascontiguousarray(buf)).to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        buf[:] = t.cpu().numpy()
+    return fn
+
+
 def init_rccl(model, dist, rank):
     """Bootstraps the engine's own RCCL communicator: rank 0 creates the ncclUniqueId, torch.distributed
     (any backend) broadcasts the 128 bytes, every rank joins."""

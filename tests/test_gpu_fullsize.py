@@ -1,0 +1,134 @@
+"""Parity at BASELINE.json's full size (configs[1]: |V| = 50k, |D| = 100k, 300 → 256, window 10, 16 negatives,
+batch 51 200, hard_tanh + batch-norm): one complete step against the fp64 oracle, plus size-independent properties
+of the HIP path that need no oracle (conservation of the scattered mass, linearity in the instance weights,
+invariance under a permutation of the batch, run-to-run bit-stability)."""
+import numpy as np
+import pytest
+
+import cunvsm_amd as ca
+from oracle import nvsm_oracle as orc
+from tests.helpers import PARAMS, gpu_model, load_params, oracle_model, random_params, rel_err, zipf_ids
+
+pytestmark = pytest.mark.gpu
+
+SPEC = dict(num_words=50000, num_entities=100000, word_dim=300, entity_dim=256, window=10, num_random=16,
+            nonlinearity="hard_tanh", batch_norm=True)
+SPEC["lambda"] = 0.01
+B = 51200
+
+
+def full_batch(rs, weighted=False):
+    w, k = SPEC["window"], SPEC["num_random"]
+    words = zipf_ids(rs, SPEC["num_words"], B * w)
+    labels = rs.randint(0, SPEC["num_entities"], B).astype(np.int64)
+    ww = np.ones(B * w, np.float32)
+    iw = rs.uniform(0.5, 1.5, B).astype(np.float32) if weighted else np.ones(B, np.float32)
+    ids = rs.randint(0, SPEC["num_entities"], (B, k + 1)).astype(np.int64)
+    ids[:, 0] = labels
+    return words, ww, labels, iw, ids.ravel()
+
+
+@pytest.fixture(scope="module")
+def problem():
+    rs = np.random.RandomState(2024)
+    # projections must leave the hard_tanh linear region for some units, so scale T up a little
+    params = random_params(SPEC, rs)
+    params[PARAMS[2]] = (params[PARAMS[2]] * 4).astype(np.float32)
+    return params, full_batch(rs, weighted=True)
+
+
+@pytest.mark.parametrize("method", ["sparse_adam", "sgd"])
+def test_full_size_step_matches_fp64_oracle(problem, method):
+    params, (words, ww, labels, iw, ids) = problem
+    spec = dict(SPEC, update_method=method)
+    o, g = oracle_model(spec, orc.F64), gpu_model(spec, B)
+    load_params(o, params, False)
+    load_params(g, params, True)
+    o.forward(words, ww, ids, iw)
+    o.backward()
+    g.compute_cost(ca.Batch(words, labels, ww, iw), ids)
+    g.compute_gradients()
+    co, cg = o.get_cost(), g.get_cost()
+    assert abs(co - cg) <= 2e-5 * abs(co), (co, cg)                      # fp32 tolerance on the loss
+    for name, tol in (("grad_transform", 5e-4), ("grad_bias", 5e-4), ("grad_phrase", 5e-4)):
+        a, b = g.get_tensor(name), o.get(name)
+        assert rel_err(a, b) < tol, (name, rel_err(a, b))
+        assert abs(np.linalg.norm(a) - np.linalg.norm(b)) <= 1e-4 * np.linalg.norm(b), name     # gradient norms
+    lr = 1e-3
+    o.update(lr)
+    g.update(lr)
+    # Adam divides every component by its own sqrt(v): components whose gradient is small (and therefore carries a
+    # larger relative fp32 error) weigh as much as the large ones in the update, hence the looser bound
+    tol = 5e-3 if method.endswith("adam") else 5e-4
+    for name in PARAMS:
+        new_o, new_g, old = o.get(name), g.get_param(name).astype(np.float64), params[name].astype(np.float64)
+        change = np.linalg.norm(new_o - old)
+        assert np.linalg.norm(new_g - new_o) <= tol * change + 1e-7 * np.linalg.norm(old), (name, np.linalg.norm(new_g - new_o), change)
+
+
+def test_scatter_conserves_mass_sgd(problem):
+    """SGD, λ = 0: Σ_rows ΔE = lr · Σ_j m_j · proj[j / R] and Σ_rows ΔW = lr · Σ_{b,j} wt · gphrase[b] — a checksum of
+    the whole sorted scatter (870 400 + 512 000 entries) computed from the kernel's own inputs in float64."""
+    params, (words, ww, labels, iw, ids) = problem
+    spec = dict(SPEC, update_method="sgd")
+    spec["lambda"] = 0.0
+    g = gpu_model(spec, B)
+    load_params(g, params, True)
+    g.compute_cost(ca.Batch(words, labels, ww, iw), ids)
+    g.compute_gradients()
+    mult = g.get_tensor("multipliers").astype(np.float64).reshape(B, -1)
+    proj = g.get_tensor("proj").astype(np.float64).reshape(B, -1)
+    gphrase = g.get_tensor("grad_phrase").astype(np.float64).reshape(B, -1)
+    lr = 0.5
+    g.update(lr)
+    dE = g.get_param(PARAMS[1]).astype(np.float64).reshape(-1, SPEC["entity_dim"]) - params[PARAMS[1]].astype(np.float64).reshape(-1, SPEC["entity_dim"])
+    dW = g.get_param(PARAMS[0]).astype(np.float64).reshape(-1, SPEC["word_dim"]) - params[PARAMS[0]].astype(np.float64).reshape(-1, SPEC["word_dim"])
+    want_E = lr * (mult.sum(axis=1)[:, None] * proj).sum(axis=0)
+    want_W = lr * SPEC["window"] * gphrase.sum(axis=0)
+    assert np.linalg.norm(dE.sum(axis=0) - want_E) <= 2e-3 * np.linalg.norm(want_E) + 1e-6
+    assert np.linalg.norm(dW.sum(axis=0) - want_W) <= 2e-3 * np.linalg.norm(want_W) + 1e-6
+    # rows that no entry touched are bit-identical (no decay at λ = 0)
+    touched = np.zeros(SPEC["num_entities"], bool)
+    touched[ids] = True
+    assert np.all(dE[~touched] == 0.0)
+
+
+def test_linearity_and_permutation_invariance(problem):
+    params, (words, ww, labels, iw, ids) = problem
+    spec = dict(SPEC, update_method="sgd", batch_norm=False)        # batch-norm couples instances through its statistics
+    g = gpu_model(spec, B)
+    load_params(g, params, True)
+
+    def grads(iw_, perm=None):
+        w_, l_, i_, x_ = words.reshape(B, -1), labels, ids.reshape(B, -1), iw_
+        if perm is not None:
+            w_, l_, i_, x_ = w_[perm], l_[perm], i_[perm], x_[perm]
+        g.compute_cost(ca.Batch(np.ascontiguousarray(w_).ravel(), np.ascontiguousarray(l_), ww, np.ascontiguousarray(x_)),
+                       np.ascontiguousarray(i_).ravel())
+        g.compute_gradients()
+        return g.get_cost(), g.get_tensor("grad_transform").astype(np.float64), g.get_tensor("grad_bias").astype(np.float64)
+
+    c1, t1, b1 = grads(iw)
+    c2, t2, b2 = grads((2 * iw).astype(np.float32))
+    assert abs(c2 - 2 * c1) <= 2e-6 * abs(c2)
+    assert rel_err(t2, 2 * t1) < 1e-5 and rel_err(b2, 2 * b1) < 1e-5
+    perm = np.random.RandomState(5).permutation(B)
+    c3, t3, b3 = grads(iw, perm)
+    assert abs(c3 - c1) <= 2e-6 * abs(c1)
+    assert rel_err(t3, t1) < 2e-5 and rel_err(b3, b1) < 2e-5
+
+
+def test_full_size_steps_are_bit_stable(problem):
+    """No atomics on the parameter path: two runs of the same three steps end in identical tables."""
+    params, (words, ww, labels, iw, ids) = problem
+    outs = []
+    for _ in range(2):
+        g = gpu_model(dict(SPEC, update_method="sparse_adam"), B)
+        load_params(g, params, True)
+        for _step in range(3):
+            g.compute_cost(ca.Batch(words, labels, ww, iw), ids)
+            g.compute_gradients()
+            g.update(1e-3)
+        outs.append([g.get_param(n) for n in PARAMS[:2]])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)

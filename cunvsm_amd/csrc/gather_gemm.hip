@@ -310,6 +310,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     }
 }
 
+bool launch_gemm_panel(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
+                       int lda, int ldb, int ldc, float alpha, const float* bias_n, int slabs, int k_split_len,
+                       size_t c_split_stride, hipStream_t s, double* colstats);   // gemm_panel.hip
+static bool g_gemm_panel_enabled = true;
+void gemm_set_panel_enabled(bool on) { g_gemm_panel_enabled = on; }
+
 int gemm_split_k_slabs(int K, int want) {
     if (want <= 1) return 1;
     int len = (K + want - 1) / want;
@@ -334,6 +340,10 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
         slabs = (K + len - 1) / len;
     }
     if (g.k_split_len <= 0) g.k_split_len = BK;
+    // CU-sized panels for the large-batch projection shapes (see gemm_panel.hip); everything else: 128 x 128 tiles
+    if (g_gemm_panel_enabled && launch_gemm_panel(a_layout, b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, slabs,
+                                                  g.k_split_len, c_split_stride, s, g.colstats))
+        return;
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(B) % 16 == 0);
     const int a_contig = a_layout == 0 ? K : M, b_contig = b_layout == 0 ? N : K;
@@ -353,8 +363,33 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
 #undef NVSM_GEMM_CASE
 }
 
+// out[i] = Σ_z partial[z][i], z ascending within 16 interleaved groups that are then summed in group order (a fixed
+// order: deterministic). 16 float4 columns x 16 slab groups per block so that ~1200 blocks stream the partials
+// (the one-thread-per-output form ran 300 blocks with 128 dependent-free but serial loads each: 32 us for 39 MB).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int slabs, size_t stride,
-                                                            float* __restrict__ out, int64_t n) {
+                                                            float* __restrict__ out, int64_t n4) {
+    __shared__ float4 red[16][16];
+    const int cl = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const int64_t c4 = static_cast<int64_t>(blockIdx.x) * 16 + cl;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < n4) {
+        for (int z = sg; z < slabs; z += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + z * stride + c4 * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[sg][cl] = acc;
+    __syncthreads();
+    if (sg == 0 && c4 < n4) {
+        float4 t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = red[k][cl]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(out + c4 * 4) = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_scalar_kernel(const float* __restrict__ partial, int slabs, size_t stride,
+                                                                   float* __restrict__ out, int64_t n) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         float s = 0.f;
@@ -364,7 +399,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 void launch_splitk_reduce(const float* partial, int slabs, size_t stride, float* out, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, partial, slabs, stride, out, n);
+    const bool vec = (n % 4 == 0) && (stride % 4 == 0) && (reinterpret_cast<uintptr_t>(partial) % 16 == 0) &&
+                     (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    if (vec) {
+        const int64_t n4 = n / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((n4 + 15) / 16)), dim3(256), 0, s, partial, slabs, stride, out, n4);
+    } else {
+        hipLaunchKernelGGL(splitk_reduce_scalar_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, partial, slabs, stride, out, n);
+    }
 }
 
 // =============================================================================================

@@ -20,6 +20,7 @@ void launch_gather_mean(const float* table, int dim, const int* idx, const float
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
                  hipStream_t s, double* colstats = nullptr);   // colstats [2][N] (no split-K): += Σ_rows C, Σ_rows C²
+void gemm_set_panel_enabled(bool on);    // experiments / tests: force the tiled kernel
 int gemm_split_k_slabs(int K, int want);   // actual number of slabs launch_gemm will use for `want`
 void launch_splitk_reduce(const float* partial, int slabs, size_t stride, float* out, int64_t n, hipStream_t s);
 

@@ -128,6 +128,8 @@ struct RowPassArgs {
     float lr, decay, lambda;
     float one_m_b1, s_m, one_m_b2, s_v, bc, eps, c_reg;
     int dense;                 // visit rows without entries (decay / dense Adam)
+    int max_blocks;            // 0 = one thread group per row; > 0 = cap the grid (rows are grid-strided) so that a kernel
+                               //   running concurrently on another stream finds free registers on every CU
 };
 void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
 void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);

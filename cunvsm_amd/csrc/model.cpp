@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -204,6 +205,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     NVSM_HIP_CHECK(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, hipEventDisableTiming));
+    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_aux_done_}) NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
 
     const int dw = cfg.word_repr_size, de = cfg.entity_repr_size, w = cfg.window_size;
     const int64_t N = B * R_;
@@ -233,6 +235,7 @@ Model::~Model() {
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
+    for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_aux_done_}) if (e) (void)hipEventDestroy(e);
     if (comm_ && rccl_) rccl_->CommDestroy(comm_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
@@ -306,20 +309,20 @@ void Model::allreduce_f64(double* dev, int64_t n) {
     }
 }
 
-void Model::allreduce_f32(float* dev, int64_t n) {
+void Model::allreduce_f32(float* dev, int64_t n, hipStream_t strm) {
     if (cfg_.world_size <= 1) return;
     if (comm_ && !ar_fn_) {
-        const int rc = rccl_->AllReduce(dev, dev, n, RcclApi::kFloat32, RcclApi::kSum, comm_, stream_);
+        const int rc = rccl_->AllReduce(dev, dev, n, RcclApi::kFloat32, RcclApi::kSum, comm_, strm);
         if (rc != 0) throw Error(NVSM_ERR_DEVICE, "ncclAllReduce(f32) failed");
     } else if (ar_fn_) {
         std::vector<float> h(n);
-        NVSM_HIP_CHECK(hipMemcpyAsync(h.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
-        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        NVSM_HIP_CHECK(hipMemcpyAsync(h.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost, strm));
+        NVSM_HIP_CHECK(hipStreamSynchronize(strm));
         ar_host_.assign(h.begin(), h.end());
         if (ar_fn_(ar_host_.data(), n, ar_user_) != 0) throw Error(NVSM_ERR_DEVICE, "all-reduce callback failed");
         for (int64_t i = 0; i < n; ++i) h[i] = static_cast<float>(ar_host_[i]);
-        NVSM_HIP_CHECK(hipMemcpyAsync(dev, h.data(), n * sizeof(float), hipMemcpyHostToDevice, stream_));
-        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        NVSM_HIP_CHECK(hipMemcpyAsync(dev, h.data(), n * sizeof(float), hipMemcpyHostToDevice, strm));
+        NVSM_HIP_CHECK(hipStreamSynchronize(strm));
     } else {
         throw Error(NVSM_ERR_STATE, "world_size > 1 but neither nvsm_comm_init nor an all-reduce callback was set");
     }
@@ -457,6 +460,12 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
 void Model::compute_gradients() {
     if (!have_forward_) throw Error(NVSM_ERR_STATE, "compute_gradients requires compute_cost");
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    backward_dx();
+    backward_T(stream_);
+    have_grads_ = true;
+}
+
+void Model::backward_dx() {
     const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size, w = cfg_.window_size;
     const int64_t B = B_;
     const bool dp = cfg_.world_size > 1;
@@ -484,24 +493,31 @@ void Model::compute_gradients() {
     {
         PROF("gemm_bwd_x");
         const float inv_w = static_cast<float>(std::exp(-std::log(static_cast<double>(w))));
+        NVSM_HIP_CHECK(hipEventRecord(ev_dx_, stream_));        // dx is final: the dT GEMM may start (fused step)
         launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, 1, 0, stream_);
+        NVSM_HIP_CHECK(hipEventRecord(ev_bwdx_, stream_));      // last reader of T before its update
     }
-    // B6: ∂T (stored [dw][de]) = phraseᵀ[dw x B] · dx[B x de], split-K over the batch   (params.cu:526-531)
+}
+
+// B6: ∂T (stored [dw][de]) = phraseᵀ[dw x B] · dx[B x de], split-K over the batch   (params.cu:526-531)
+void Model::backward_T(hipStream_t strm) {
+    const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size;
+    const int64_t B = B_;
+    const bool dp = cfg_.world_size > 1;
     {
-        PROF("gemm_bwd_T");
+        PROF_ON("gemm_bwd_T", strm);
         const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
         const size_t stride = static_cast<size_t>(de) * dw;
         if (slabs == 1) {
-            launch_gemm(1, 0, phrase_.p, dy_.p, gT_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr, 1, 0, stream_);
+            launch_gemm(1, 0, phrase_.p, dy_.p, gT_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr, 1, 0, strm);
         } else {
             launch_gemm(1, 0, phrase_.p, dy_.p, gT_partial_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr,
-                        gemm_slabs_want_, stride, stream_);
-            launch_splitk_reduce(gT_partial_.p, slabs, stride, gT_.p, static_cast<int64_t>(stride), stream_);
+                        gemm_slabs_want_, stride, strm);
+            launch_splitk_reduce(gT_partial_.p, slabs, stride, gT_.p, static_cast<int64_t>(stride), strm);
         }
     }
     // data parallel: one all-reduce of the dense projection gradient over xGMI
-    if (dp) { PROF("allreduce_grad"); allreduce_f32(gT_.p, static_cast<int64_t>(de) * dw); cost_valid_ = false; }
-    have_grads_ = true;
+    if (dp) { PROF_ON("allreduce_grad", strm); allreduce_f32(gT_.p, static_cast<int64_t>(de) * dw, strm); cost_valid_ = false; }
 }
 
 float Model::scaled_regularization_lambda() const {
@@ -562,7 +578,7 @@ static void fill_adam_consts(RowPassArgs& a, float bc, float sl) {
     a.c_reg = static_cast<float>((1.0 - b1) * static_cast<double>(sl));            // updates_adam.cu:208-212
 }
 
-void Model::update_entities(float lr, float sl) {
+void Model::update_entities(float lr, float sl, hipStream_t strm) {
     const int64_t N = B_ * R_;
     const int de = cfg_.entity_repr_size;
     TableState& t = ents_;
@@ -587,8 +603,13 @@ void Model::update_entities(float lr, float sl) {
             else { a.kind = ROW_ADAM_SPARSE_ENT; swap_sc = true; }
         }
     }
-    { PROF("chunk_pass_entities"); launch_chunk_pass(c, a, stream_); }
-    { PROF("row_pass_entities"); launch_row_pass(c, a, stream_); }
+    if (strm != stream_) {      // fused step. Capping the grid (NVSM_ENT_BLOCKS_PER_CU) so that GEMM workgroups find free registers
+                                // on every CU was measured and does not help (1.30 -> 1.31-1.33 ms): default 0 = uncapped
+        static const int per_cu = [] { const char* e = getenv("NVSM_ENT_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
+        a.max_blocks = 256 * per_cu;
+    }
+    { PROF_ON("chunk_pass_entities", strm); launch_chunk_pass(c, a, strm); }
+    { PROF_ON("row_pass_entities", strm); launch_row_pass(c, a, strm); }
     if (swap_sc) t.sc_cur ^= 1;
 }
 
@@ -656,8 +677,8 @@ void Model::update_words(float lr, float sl) {
     { PROF("row_pass_words_u"); launch_row_pass(c, r, stream_); }
 }
 
-void Model::update_transform(float lr, float sl) {
-    PROF("transform_update");
+void Model::update_transform(float lr, float sl, hipStream_t strm) {
+    PROF_ON("transform_update", strm);
     TransformUpdateArgs a{};
     a.T = T_.p; a.b = b_.p; a.gT = gT_.p; a.gb = gb_.p;
     a.s0T = s0T_.p; a.s0b = s0b_.p; a.s1T = s1T_.p; a.s1b = s1b_.p;
@@ -670,7 +691,7 @@ void Model::update_transform(float lr, float sl) {
     a.s_v = static_cast<float>(1.0 - 1.0 * static_cast<double>(a.one_m_b2));
     a.bc = adam_bc(t_transform_);
     if (cfg_.update_method == NVSM_ADAM) t_transform_ += 1;
-    launch_transform_update(a, stream_);
+    launch_transform_update(a, strm);
 }
 
 void Model::update(float lr, float scaled_lambda) {
@@ -678,16 +699,41 @@ void Model::update(float lr, float scaled_lambda) {
     if (lr < 0.f || scaled_lambda < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");   // storage.cu:62-63
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));     // join the side-stream CSR builds
-    update_entities(lr, scaled_lambda);
+    update_entities(lr, scaled_lambda, stream_);
     update_words(lr, scaled_lambda);
-    update_transform(lr, scaled_lambda);
+    update_transform(lr, scaled_lambda, stream_);
     have_grads_ = false;      // gradients are consumed (the reference's optimisers overwrite them too)
 }
 
+// One loop body of iterate_data (cpp/main.cu:400-444). With everything known up front the three independent chains of
+// the backward half run concurrently instead of back to back:
+//   side stream : documents update (needs only the loss kernel's outputs; HBM bound) → dT GEMM + reduce (MFMA bound)
+//                 → projection update (after the dx GEMM has read T)
+//   main stream : batch-norm backward → dx GEMM (MFMA bound) → words update (L2 / HBM bound)
+// Results are identical to compute_cost; compute_gradients; update — only the interleaving differs.
 void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, float* cost) {
     compute_cost(batch, entity_ids);
-    compute_gradients();
-    update(lr, scaled_regularization_lambda());
+    const float sl = scaled_regularization_lambda();
+    if (lr < 0.f || sl < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");
+    const bool dp = cfg_.world_size > 1;      // collectives stay on ONE stream: with data parallelism only the documents update moves
+    NVSM_HIP_CHECK(hipEventRecord(ev_loss_, stream_));
+    NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_loss_, 0));       // (the CSR builds are already queued there)
+    update_entities(lr, sl, aux_stream_);
+    backward_dx();
+    if (dp) {
+        backward_T(stream_);
+    } else {
+        NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_dx_, 0));
+        backward_T(aux_stream_);
+        NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_bwdx_, 0));
+        update_transform(lr, sl, aux_stream_);
+    }
+    NVSM_HIP_CHECK(hipEventRecord(ev_aux_done_, aux_stream_));
+    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
+    update_words(lr, sl);
+    if (dp) update_transform(lr, sl, stream_);
+    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_aux_done_, 0));       // the next forward pass reads E, T and rewrites phrase
+    have_grads_ = false;
     if (cost) *cost = get_cost();
 }
 

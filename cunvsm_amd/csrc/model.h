@@ -125,11 +125,13 @@ class Model {
     ParamRef find_param(const std::string& name);
     void build_csr(TableState& t, const int* keys, int64_t n);
     Csr csr_of(TableState& t, int64_t n);
-    void update_entities(float lr, float sl);
+    void backward_dx();                                  // B5, B7, B9 on the main stream
+    void backward_T(hipStream_t s);                      // B6 (+ its all-reduce)
+    void update_entities(float lr, float sl, hipStream_t s);
     void update_words(float lr, float sl);
-    void update_transform(float lr, float sl);
+    void update_transform(float lr, float sl, hipStream_t s);
     void allreduce_f64(double* dev, int64_t n);
-    void allreduce_f32(float* dev, int64_t n);
+    void allreduce_f32(float* dev, int64_t n, hipStream_t s);
     void alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entries);
     float adam_bc(uint64_t t) const;
 
@@ -141,6 +143,9 @@ class Model {
     // forward / backward kernels and are joined right before the row passes.
     hipStream_t aux_stream_ = nullptr;
     hipEvent_t ev_inputs_ = nullptr, ev_csr_ = nullptr;
+    // fused step(): the documents update (HBM bound) and the dT GEMM (MFMA bound) run on the side stream next to the
+    // dx GEMM and the words update on the main stream
+    hipEvent_t ev_loss_ = nullptr, ev_dx_ = nullptr, ev_bwdx_ = nullptr, ev_aux_done_ = nullptr;
     std::minstd_rand0 rng_;           // include/cuNVSM/base.h:36
     uint64_t device_seed_ = 1, step_count_ = 0;
 

@@ -341,6 +341,8 @@ static void row_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nve
     const int rpb = 256 / G;
     int64_t blocks = (c.rows + rpb - 1) / rpb;
     if (blocks > 256 * 64) blocks = 256 * 64;
+    // a.max_blocks > 0: persistent grid-stride launch that leaves room on every CU for a concurrent kernel
+    if (a.max_blocks > 0 && blocks > a.max_blocks) blocks = a.max_blocks;
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 #define NVSM_ROW_CASE(K) case K: hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K>), grid, block, 0, s, c, a, G, nvec); break;
     switch (a.kind) {

@@ -132,3 +132,25 @@ def test_full_size_steps_are_bit_stable(problem):
         outs.append([g.get_param(n) for n in PARAMS[:2]])
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("method", ["sparse_adam", "full_adam", "adagrad"])
+def test_fused_step_equals_separate_calls(problem, method):
+    """nvsm_step overlaps the documents update and the dT GEMM with the dx GEMM and the words update on two streams;
+    the arithmetic is the same kernels in the same per-tensor order, so the result must be bit-identical to
+    compute_cost → compute_gradients → update."""
+    params, (words, ww, labels, iw, ids) = problem
+    spec = dict(SPEC, update_method=method)
+    a, b = gpu_model(spec, B), gpu_model(spec, B)
+    load_params(a, params, True)
+    load_params(b, params, True)
+    batch = ca.Batch(words, labels, ww, iw)
+    for _ in range(3):
+        a.compute_cost(batch, ids)
+        a.compute_gradients()
+        a.update(1e-3)
+        ca_ = a.get_cost()
+        cb_ = b.step(batch, 1e-3, entity_ids=ids, want_cost=True)
+        assert ca_ == cb_
+    for n in PARAMS:
+        np.testing.assert_array_equal(a.get_param(n), b.get_param(n))

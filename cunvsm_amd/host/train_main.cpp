@@ -165,11 +165,16 @@ class Trainer {
                 b.features = batch->features(); b.feature_weights = batch->feature_weights();
                 b.labels = batch->labels(); b.weights = batch->weights();
                 b.num_instances = static_cast<int64_t>(n); b.on_device = 0;
-                NVSM_CALL(nvsm_compute_cost(model_, &b, nullptr));
-                NVSM_CALL(nvsm_compute_gradients(model_));
-                if (backpropagate) NVSM_CALL(nvsm_update(model_, tc_.learning_rate, nvsm_scaled_regularization_lambda(model_)));
                 float cost = 0.f;
-                NVSM_CALL(nvsm_get_cost(model_, &cost));
+                if (backpropagate) {
+                    // compute_cost → compute_gradients → update(lr, scaled λ) → get_cost (cpp/main.cu:405-444) as ONE call:
+                    // same arithmetic, the independent halves of the backward pass overlapped on two streams
+                    NVSM_CALL(nvsm_step(model_, &b, nullptr, tc_.learning_rate, &cost));
+                } else {
+                    NVSM_CALL(nvsm_compute_cost(model_, &b, nullptr));
+                    NVSM_CALL(nvsm_compute_gradients(model_));
+                    NVSM_CALL(nvsm_get_cost(model_, &cost));
+                }
                 agg_cost += cost;
                 windows_ += n;
                 if (verbosity() >= 1) {

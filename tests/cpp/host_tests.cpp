@@ -396,6 +396,35 @@ static int probe(int argc, char** argv) {
         std::printf("\"instances\": %lu, \"batches\": %lu, \"feature_checksum\": %ld}\n", (unsigned long)instances, (unsigned long)batches, checksum);
         return 0;
     }
+    if (what == "--dump-epoch" && argc >= 10) {
+        // --dump-epoch <trectext> <out.bin> <window> <batch> <seed> <max_vocab> <min_df> <cutoff>: the batches of the first
+        // epoch exactly as cuNVSMTrainModel's data source produces them (shuffled, --weighting uniform), + the state of
+        // the shared generator right after the source was built (= what the trainer initialises the model from)
+        TrectextIndex* index = TrectextIndex::from_file(argv[2]);
+        const size_t window = std::stoul(argv[4]), batch_size = std::stoul(argv[5]);
+        RNG rng; rng.seed(std::stoul(argv[6]));
+        const uint64_t max_df = static_cast<uint64_t>(std::ceil(index->documentCount() * 0.5));
+        IndexSource source(index, window, &rng, std::stoul(argv[7]), std::stoul(argv[8]), max_df, std::stoul(argv[9]), false, false,
+                           nullptr, nullptr, true, AUTOMATIC_SAMPLING, UNIFORM);
+        std::stringstream st; st << rng;
+        std::ofstream f(argv[3], std::ios::binary);
+        Batch batch(batch_size, window);
+        size_t nb = 0;
+        while (source.has_next()) {
+            source.next(&batch);
+            const int64_t n = static_cast<int64_t>(batch.num_instances());
+            f.write(reinterpret_cast<const char*>(&n), 8);
+            f.write(reinterpret_cast<const char*>(batch.features()), n * window * 8);
+            f.write(reinterpret_cast<const char*>(batch.feature_weights()), n * window * 4);
+            f.write(reinterpret_cast<const char*>(batch.labels()), n * 8);
+            f.write(reinterpret_cast<const char*>(batch.weights()), n * 4);
+            batch.clear();
+            ++nb;
+        }
+        std::printf("{\"rng_state\": %s, \"vocabulary\": %lu, \"corpus\": %lu, \"batches\": %lu}\n", st.str().c_str(),
+                    (unsigned long)source.vocabulary_size(), (unsigned long)source.corpus_size(), (unsigned long)nb);
+        return f.good() ? 0 : 1;
+    }
     return 2;
 }
 

@@ -122,3 +122,87 @@ def test_initialize_from_rng_state_continues_the_stream():
     ca._lib.check(L.nvsm_initialize_from_rng_state(b._h))
     for name in ("word_representations-representations", "entity_representations-representations", "word_entity_mapping-transform"):
         np.testing.assert_array_equal(a.get_param(name), b.get_param(name))
+
+
+def _read_dataset(path, name, shape):
+    out = path + "." + name + ".bin"
+    subprocess.run([H5DUMP, "-d", name, "-b", "LE", "-o", out, path], capture_output=True, check=True)
+    return np.fromfile(out, dtype="<f4").reshape(shape)
+
+
+def _read_batches(path, window):
+    raw = open(path, "rb").read()
+    off, batches = 0, []
+    while off < len(raw):
+        n = int(np.frombuffer(raw, "<i8", 1, off)[0]); off += 8
+        f = np.frombuffer(raw, "<i8", n * window, off); off += 8 * n * window
+        fw = np.frombuffer(raw, "<f4", n * window, off); off += 4 * n * window
+        l = np.frombuffer(raw, "<i8", n, off); off += 8 * n
+        w = np.frombuffer(raw, "<f4", n, off); off += 4 * n
+        batches.append((f, fw, l, w))
+    return batches
+
+
+@pytest.mark.parametrize("method,extra", [("sgd", []), ("sparse_adam", ["--batch_normalization"]), ("adagrad", ["--bias_negative_samples"])])
+def test_trainer_trajectory_matches_oracle(tmp_path, method, extra):
+    """The whole trainer against the CPU oracle on the same corpus: the data source's batches (dumped by the host-layer
+    probe), the shared minstd_rand0 stream (document shuffle → Glorot initialisation → negative sampling), every
+    optimiser step of one epoch, and the HDF5 round trip. Initial parameters must agree exactly; the parameters after
+    the epoch within the fp32 tolerance of ~20 accumulated steps."""
+    from oracle import nvsm_oracle as orc
+    from tests.helpers import METHODS
+    from tests.test_host_layer import BIN as HOST_TESTS
+    if not os.path.exists(HOST_TESTS):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cunvsm_amd", "host"), "build/host_tests"], stdout=subprocess.DEVNULL)
+    window, batch, seed, cutoff, dw, de, k, lam, lr = 10, 1024, 3, 200, 48, 32, 5, 0.01, 0.01 if method != "sparse_adam" else 0.001
+    nonlin = "hard_tanh" if "--batch_normalization" in extra else "tanh"
+    out = str(tmp_path / "m")
+    args = ["--word_repr_size", str(dw), "--entity_repr_size", str(de), "--window_size", str(window), "--num_random_entities", str(k),
+            "--regularization_lambda", str(lam), "--learning_rate", str(lr), "--weighting", "uniform", "--seed", str(seed),
+            "--update_method", method, "--batch_size", str(batch), "--nonlinearity", nonlin, "--max_vocabulary_size", "65536",
+            "--min_document_frequency", "0", "--document_cutoff", str(cutoff), "--num_epochs", "1", "--dump_initial_model",
+            "--output", out] + extra + [CRANFIELD]
+    r = run_trainer(args)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    epoch_bin = str(tmp_path / "epoch.bin")
+    info = json.loads(subprocess.run([HOST_TESTS, "--dump-epoch", CRANFIELD, epoch_bin, str(window), str(batch), str(seed), "65536", "0",
+                                      str(cutoff)], capture_output=True, text=True, check=True).stdout)
+    nV, nD = info["vocabulary"], info["corpus"]
+    m, mode = METHODS[method]
+    cfg = orc.make_config(nV, nD, dw, de, window, k, batch_norm="--batch_normalization" in extra,
+                          nonlinearity=orc.HARD_TANH if nonlin == "hard_tanh" else orc.TANH, clip_sigmoid=True,
+                          bias_negative_samples="--bias_negative_samples" in extra, lambda_=lam, update_method=m, adam_mode=mode)
+    oracle = orc.Model(cfg, orc.F32)
+    rng = orc.Rng(1)
+    rng.state = info["rng_state"]
+    oracle.initialize(rng)
+    shapes = {"word_representations-representations": (nV, dw), "entity_representations-representations": (nD, de),
+              "word_entity_mapping-transform": (dw, de), "word_entity_mapping-bias": (1, de)}
+    init = {n: _read_dataset(out + "_0.hdf5", n, s) for n, s in shapes.items()}
+    for n in shapes:
+        np.testing.assert_array_equal(init[n].ravel(), oracle.get(n).astype(np.float32))        # same RNG stream, same fp32 maths
+    costs = []
+    all_batches = _read_batches(epoch_bin, window)
+    for f, fw, l, w in all_batches:
+        if len(l) % 1024:
+            continue                                                                              # the trainer skips ragged batches
+        ids = rng.generate_labels(l, nD, k)
+        oracle.forward_native(np.ascontiguousarray(f), np.ascontiguousarray(fw), ids, np.ascontiguousarray(w))
+        oracle.backward()
+        costs.append(oracle.get_cost())
+        oracle.update(lr)
+    assert len(costs) >= 10
+    logged = epoch_costs(r.stderr)[-1]
+    # iterate_data divides the aggregated cost by ALL batches of the epoch, skipped ones included (cpp/main.cu:462,598)
+    want = np.sum(costs) / len(all_batches)
+    assert abs(logged - want) <= 1e-4 * abs(want), (logged, want)
+    final = {n: _read_dataset(out + "_1.hdf5", n, s) for n, s in shapes.items()}
+    from tests.helpers import rel_err
+    for n in shapes:
+        change = np.linalg.norm(oracle.get(n) - init[n].ravel().astype(np.float64))
+        diff = np.linalg.norm(final[n].ravel().astype(np.float64) - oracle.get(n))
+        # fp32 over ~23 steps: an error relative to the update (Adam's per-component normalisation amplifies it) plus the
+        # rounding of `θ·decay + lr·g` itself, which scales with ‖θ‖, not with the update
+        tol = (1e-2 if method.endswith("adam") else 2e-3) * change + 2e-6 * np.linalg.norm(init[n])
+        assert diff <= tol, (n, diff, change)

@@ -76,6 +76,8 @@ struct GemmArgs {
     float alpha;
     const float* bias_n;
     double* colstats;        // optional [2][N]: Σ_rows C, Σ_rows C² of the stored values (batch-norm statistics, F6)
+    float* rowsq;            // SWAP kernels, optional [ntiles][M]: rowsq_scale · Σ_{cols of the n tile} C² per row
+    float rowsq_scale;
     int mtiles, ntiles, slabs, groups, members;   // see gemm_decode_block
 };
 
@@ -182,7 +184,10 @@ __device__ __forceinline__ bool gemm_decode_block(const GemmArgs& g, int& mt, in
     return true;
 }
 
-template <int ALAY, int BLAY, bool FAST>
+// SWAP: the MFMA operands are fed swapped, i.e. each 32 x 32 tile is computed transposed, so that a lane ends up with
+// 4 x 4 consecutive columns of ONE output row: 16 B stores (the epilogue is store-issue bound) and row-wise sums of
+// squares for free (rowsq) — used for the dx·T GEMM, whose per-row mean of squares the Adam / Adagrad words update needs.
+template <int ALAY, int BLAY, bool FAST, bool SWAP = false>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int A_ELEMS = (ALAY == 0) ? BM * (BK + 1) : BK * BM;
     constexpr int B_ELEMS = (BLAY == 0) ? BK * BN : BN * (BK + 1);
@@ -247,11 +252,51 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 
+    if constexpr (SWAP) {
+        // acc[i][j][4 q + t] = C[m0 + wr 64 + i 32 + l31][n0 + wc 64 + j 32 + 8 q + 4 lk + t]
+        const bool vec_ok = (g.ldc % 4 == 0) && (reinterpret_cast<uintptr_t>(C) % 16 == 0);
+        float rsq[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + wr * 64 + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = n0 + wc * 64 + j * 32 + 8 * q + 4 * lk;
+                    if (row >= g.M || col >= g.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = g.alpha * acc[i][j][4 * q + t] + ((g.bias_n && col + t < g.N) ? g.bias_n[col + t] : 0.f);
+                    float* cp = C + static_cast<size_t>(row) * g.ldc + col;
+                    if (vec_ok && col + 3 < g.N) {
+                        stv<4>(cp, v);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) rsq[i] += v[t] * v[t];
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (col + t < g.N) { cp[t] = v[t]; rsq[i] += v[t] * v[t]; }
+                    }
+                }
+        }
+        if (g.rowsq) {
+            float* red = lds;             // [2 (wc)][BM]; the operand tiles are dead (loop ended on a barrier)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                rsq[i] += __shfl_xor(rsq[i], 32);
+                if (lk == 0) red[wc * BM + wr * 64 + i * 32 + l31] = rsq[i];
+            }
+            __syncthreads();
+            if (tid < BM && m0 + tid < g.M) g.rowsq[static_cast<size_t>(nt) * g.M + m0 + tid] = (red[tid] + red[BM + tid]) * g.rowsq_scale;
+        }
+        return;
+    }
     // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
     // Interior tiles store unguarded: a per-row bounds branch would put an s_waitcnt vmcnt(0) (stores count in
     // vmcnt on CDNA4) between every pair of the 64 stores of a lane.
@@ -316,6 +361,20 @@ bool launch_gemm_panel(int a_layout, int b_layout, const float* A, const float* 
 static bool g_gemm_panel_enabled = true;
 void gemm_set_panel_enabled(bool on) { g_gemm_panel_enabled = on; }
 
+int gemm_rowsq_parts(int N) { return (N + BN - 1) / BN; }
+
+__global__ void sum_parts_kernel(const float* __restrict__ parts, int nparts, int64_t stride, float* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        float s = parts[i];
+        for (int p = 1; p < nparts; ++p) s += parts[p * stride + i];
+        out[i] = s;
+    }
+}
+void launch_sum_parts(const float* parts, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(sum_parts_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, parts, nparts, stride, out, n);
+}
+
 int gemm_split_k_slabs(int K, int want) {
     if (want <= 1) return 1;
     int len = (K + want - 1) / want;
@@ -325,10 +384,11 @@ int gemm_split_k_slabs(int K, int want) {
 
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
-                 hipStream_t s, double* colstats) {
+                 hipStream_t s, double* colstats, float* rowsq, float rowsq_scale) {
     if (M <= 0 || N <= 0) return;
     GemmArgs g;
     g.colstats = (split_k > 1) ? nullptr : colstats;
+    g.rowsq = nullptr; g.rowsq_scale = rowsq_scale;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = alpha; g.bias_n = bias_n; g.c_split_stride = c_split_stride;
     int slabs = 1;
@@ -354,6 +414,13 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
     const int padded_groups = ((g.groups + 7) / 8) * 8;
     dim3 grid(padded_groups * g.members);
     dim3 block(256);
+    if (rowsq && split_k <= 1) {
+        if (fast && a_layout == 0 && b_layout == 1 && !g.colstats) {
+            g.rowsq = rowsq;
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 1, true, true>), grid, block, 0, s, g);
+            return;
+        }
+    }
 #define NVSM_GEMM_CASE(AL, BL)                                                                              \
     if (a_layout == AL && b_layout == BL) {                                                                 \
         if (fast) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AL, BL, true>), grid, block, 0, s, g);           \
@@ -361,6 +428,11 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
     }
     NVSM_GEMM_CASE(0, 0) NVSM_GEMM_CASE(0, 1) NVSM_GEMM_CASE(1, 0) NVSM_GEMM_CASE(1, 1)
 #undef NVSM_GEMM_CASE
+    if (rowsq && split_k <= 1) {      // shapes the SWAP kernel does not cover: a separate pass, all of it in part 0
+        launch_row_meansq(C, M, N, rowsq_scale, rowsq, s);
+        const int parts = gemm_rowsq_parts(N);
+        if (parts > 1) (void)hipMemsetAsync(rowsq + M, 0, sizeof(float) * static_cast<size_t>(parts - 1) * M, s);
+    }
 }
 
 // out[i] = Σ_z partial[z][i], z ascending within 16 interleaved groups that are then summed in group order (a fixed

@@ -19,7 +19,13 @@ void launch_gather_mean(const float* table, int dim, const int* idx, const float
 // is lost: alpha applied per slab, bias must be null) and the caller reduces with launch_splitk_reduce.
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
-                 hipStream_t s, double* colstats = nullptr);   // colstats [2][N] (no split-K): += Σ_rows C, Σ_rows C²
+                 hipStream_t s, double* colstats = nullptr,     // colstats [2][N] (no split-K): += Σ_rows C, Σ_rows C²
+                 float* rowsq = nullptr, float rowsq_scale = 0.f);
+// rowsq [gemm_rowsq_parts(N)][M]: rowsq_scale · Σ_cols C² per row, split by 128-column tile; launch_sum_parts adds the
+// parts in order (a runtime-length loop over the parts inside the row passes' unrolled gather was measured: it halves
+// their speed, so the parts are combined once up front)
+int gemm_rowsq_parts(int N);
+void launch_sum_parts(const float* parts, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
 void gemm_set_panel_enabled(bool on);    // experiments / tests: force the tiled kernel
 int gemm_split_k_slabs(int K, int want);   // actual number of slabs launch_gemm will use for `want`
 void launch_splitk_reduce(const float* partial, int slabs, size_t stride, float* out, int64_t n, hipStream_t s);

@@ -219,7 +219,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     widx_.alloc(B * w); ids_.alloc(N); iota_.alloc(std::max<int64_t>(B * w, N));
     launch_iota(iota_.p, static_cast<int64_t>(iota_.n), stream_);
     phrase_.alloc(B * dw); pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
-    coef_.alloc(N); probs_.alloc(N); pp_.alloc(B); msq_w_.alloc(B);
+    coef_.alloc(N); probs_.alloc(N); pp_.alloc(B); msq_w_.alloc(B); msq_parts_.alloc(B * gemm_rowsq_parts(dw));
     if (cfg.update_method == NVSM_ADAM && cfg.adam_mode <= NVSM_ADAM_SPARSE) U_.alloc(B * dw);
     if (cfg.update_method == NVSM_ADAGRAD) scale_w_.alloc(B);
     stats_.alloc(4 * de + 1, true); stats_fwd_ = stats_.p; stats_bwd_ = stats_.p + 2 * de;
@@ -494,7 +494,14 @@ void Model::backward_dx() {
         PROF("gemm_bwd_x");
         const float inv_w = static_cast<float>(std::exp(-std::log(static_cast<double>(w))));
         NVSM_HIP_CHECK(hipEventRecord(ev_dx_, stream_));        // dx is final: the dT GEMM may start (fused step)
-        launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, 1, 0, stream_);
+        // the words update of Adam (sparse / dense_update) and Adagrad needs mean_t(gphrase[b][t]²) per window
+        // (cpp/updates_adam.cu:232-240, updates_adagrad.cu:136-143): emitted by the GEMM epilogue, per 128-column tile
+        const bool need_msq = cfg_.update_method == NVSM_ADAGRAD ||
+                              (cfg_.update_method == NVSM_ADAM && cfg_.adam_mode != NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE);
+        const float inv_dw = static_cast<float>(std::exp(-std::log(static_cast<double>(dw))));
+        launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, 1, 0, stream_, nullptr,
+                    need_msq ? msq_parts_.p : nullptr, inv_dw);
+        if (need_msq) launch_sum_parts(msq_parts_.p, gemm_rowsq_parts(dw), B, msq_w_.p, B, stream_);
         NVSM_HIP_CHECK(hipEventRecord(ev_bwdx_, stream_));      // last reader of T before its update
     }
 }
@@ -624,7 +631,6 @@ void Model::update_words(float lr, float sl) {
     a.P = t.P.p; a.m = t.m.p; a.v = t.vfull.p; a.dim = dw;
     a.lr = lr; a.lambda = sl; a.eps = 1e-6f;
     a.decay = sl > 0.f ? static_cast<float>(1.0 - static_cast<double>(sl) * static_cast<double>(lr)) : 1.f;
-    const float inv_dw = static_cast<float>(std::exp(-std::log(static_cast<double>(dw))));
     const int method = cfg_.update_method, mode = cfg_.adam_mode;
 
     if (method == NVSM_SGD) {
@@ -634,7 +640,6 @@ void Model::update_words(float lr, float sl) {
         return;
     }
     if (method == NVSM_ADAGRAD) {
-        { PROF("row_meansq_words"); launch_row_meansq(gphrase_.p, B_, dw, inv_dw, msq_w_.p, stream_); }
         RowPassArgs s = a;                                             // accumulator pass (updates_adagrad.cu:136-158)
         s.kind = ROW_SCALAR_ACC; s.sq_src = msq_w_.p; s.dense = 1;
         s.sc_in = t.sc[t.sc_cur].p; s.sc_out = t.sc[t.sc_cur ^ 1].p;
@@ -655,8 +660,7 @@ void Model::update_words(float lr, float sl) {
         { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
         return;
     }
-    { PROF("row_meansq_words"); launch_row_meansq(gphrase_.p, B_, dw, inv_dw, msq_w_.p, stream_); }
-    a.sq_src = msq_w_.p; a.dense = 1;
+    a.sq_src = msq_w_.p; a.dense = 1;     // from the dx GEMM's epilogue
     a.sc_in = t.sc[t.sc_cur].p; a.sc_out = t.sc[t.sc_cur ^ 1].p;
     if (mode == NVSM_ADAM_DENSE_UPDATE) {
         a.kind = ROW_ADAM_DENSE;

@@ -164,7 +164,7 @@ class Model {
     int64_t B_ = 0;                   // instances of the current batch (this rank)
 
     // intermediates
-    DevBuf<float> phrase_, pre_, proj_, dy_, gphrase_, coef_, probs_, pp_, msq_w_, U_, scale_w_, grad_entity_;
+    DevBuf<float> phrase_, pre_, proj_, dy_, gphrase_, coef_, probs_, pp_, msq_w_, msq_parts_, U_, scale_w_, grad_entity_;
     DevBuf<double> stats_;                   // [2 de | 1 + 2 de] = Σx Σx² | loss Σdy Σdy·x̂ — cleared by one memset per step
     double* stats_fwd_ = nullptr;
     double* stats_bwd_ = nullptr;

@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--num-entities", type=int, default=100000)
     ap.add_argument("--uniform-words", action="store_true", help="uniform instead of Zipf(1) word ids (worst case for caches)")
     ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step (PCIe-inclusive rate)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="full-size steps of the CPU oracle timed for cpu_baseline (≈1 s each on 128 cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--read-cost-every", type=int, default=0, help="read the loss back every n steps (0 = never inside the timed region)")
     args = ap.parse_args()

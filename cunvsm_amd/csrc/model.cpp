@@ -451,6 +451,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         a.inv_de = static_cast<float>(std::exp(-std::log(static_cast<double>(de))));
         launch_loss(a, stream_);
     }
+    NVSM_HIP_CHECK(hipGetLastError());      // a failed launch of any kernel above surfaces here, not at the next sync
     have_forward_ = true;
 }
 
@@ -462,6 +463,7 @@ void Model::compute_gradients() {
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
     backward_dx();
     backward_T(stream_);
+    NVSM_HIP_CHECK(hipGetLastError());
     have_grads_ = true;
 }
 
@@ -706,6 +708,7 @@ void Model::update(float lr, float scaled_lambda) {
     update_entities(lr, scaled_lambda, stream_);
     update_words(lr, scaled_lambda);
     update_transform(lr, scaled_lambda, stream_);
+    NVSM_HIP_CHECK(hipGetLastError());
     have_grads_ = false;      // gradients are consumed (the reference's optimisers overwrite them too)
 }
 
@@ -737,6 +740,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     update_words(lr, sl);
     if (dp) update_transform(lr, sl, stream_);
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_aux_done_, 0));       // the next forward pass reads E, T and rewrites phrase
+    NVSM_HIP_CHECK(hipGetLastError());
     have_grads_ = false;
     if (cost) *cost = get_cost();
 }

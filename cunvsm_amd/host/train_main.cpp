@@ -3,8 +3,9 @@
 // same log lines and the same outputs ("<output>_meta" protobuf, "<output>_<epoch>[_<batch>].hdf5").
 //
 // Differences, all forced by what exists on this platform:
-//   * <path to Indri index> is a TREC-text collection file: libindri and its on-disk format are not available, the
-//     index is rebuilt in memory (host/trectext_index.hpp); a directory holding an Indri "manifest" is refused.
+//   * <path to Indri index> is either an Indri 5.x repository directory, read without libindri (host/indri_index.hpp;
+//     no docno look-ups, so --document_list needs the TREC-text form), or the TREC-text collection file itself, indexed
+//     in memory on start-up (host/trectext_index.hpp).
 //   * only TextEntity::Objective (LSE / NVSM) is accelerated: non-zero --entity_similarity_weight /
 //     --term_similarity_weight, --check_gradients and the l2 normalisers are refused with a clear message.
 //   * extensions: --stopwords, --device, --sampler {host,device}, --allow_ragged_batches.
@@ -22,6 +23,7 @@
 #include "flags.hpp"
 #include "hdf5_writer.hpp"
 #include "index_source.hpp"
+#include "indri_index.hpp"
 #include "trectext_index.hpp"
 
 using namespace nvsm_host;
@@ -216,7 +218,7 @@ int run(int argc, char** argv) {
     log_to_stderr() = FLAGS_logtostderr || FLAGS_alsologtostderr;
 
     if (args.size() < 2) {
-        std::cerr << "Usage: " << args[0] << " [OPTIONS] <path to TREC-text collection>\n" << flags.usage();
+        std::cerr << "Usage: " << args[0] << " [OPTIONS] <path to Indri index | TREC-text collection>\n" << flags.usage();
         NVSM_LOG(FATAL) << "Check failed: argc >= 2 Usage: " << args[0] << " [OPTIONS] <path to Indri index>";
     }
     static const std::map<std::string, std::pair<int, int>> UPDATE_METHODS = {                         // cpp/main.cu:479-485
@@ -234,15 +236,24 @@ int run(int argc, char** argv) {
     NVSM_CHECK(FLAGS_sampler == "host" || FLAGS_sampler == "device") << "--sampler must be host or device.";
 
     const std::string repository_path = args[1];
-    if (is_directory(repository_path))
-        NVSM_LOG(FATAL) << repository_path << " is a directory: Indri repositories cannot be read here (libindri and its on-disk format are "
-                           "not available); pass the TREC-text collection file the index was built from.";
-    NVSM_CHECK(is_file(repository_path)) << "cannot read collection " << repository_path;
-
-    NVSM_LOG(INFO) << "Indexing " << repository_path << ".";
-    std::unique_ptr<TrectextIndex> index(TrectextIndex::from_file(repository_path, FLAGS_stopwords));
-    NVSM_LOG(INFO) << "Indexed " << index->documentCount() << " documents, " << index->termCount() << " term occurrences, "
-                   << index->uniqueTermCount() << " unique terms.";
+    std::unique_ptr<IndexInterface> index;
+    if (is_directory(repository_path)) {
+        // an Indri repository (cpp/data_indri.cpp:18-66), read without libindri (host/indri_index.hpp)
+        if (!IndriDiskIndex::looks_like_repository(repository_path))
+            NVSM_LOG(FATAL) << "Unable to open Indri parameters: " << repository_path << " holds no manifest / index.";
+        NVSM_LOG(INFO) << "Opening Indri repository " << repository_path << ".";
+        IndriDiskIndex* disk = IndriDiskIndex::open(repository_path);
+        NVSM_LOG(INFO) << "Index holds " << disk->documentCount() << " documents, " << disk->termCount() << " term occurrences, "
+                       << disk->uniqueTermCount() << " unique terms.";
+        index.reset(disk);
+    } else {
+        NVSM_CHECK(is_file(repository_path)) << "cannot read collection " << repository_path;
+        NVSM_LOG(INFO) << "Indexing " << repository_path << ".";
+        TrectextIndex* built = TrectextIndex::from_file(repository_path, FLAGS_stopwords);
+        NVSM_LOG(INFO) << "Indexed " << built->documentCount() << " documents, " << built->termCount() << " term occurrences, "
+                       << built->uniqueTermCount() << " unique terms.";
+        index.reset(built);
+    }
 
     NVSM_CHECK(FLAGS_max_vocabulary_size > 0);
     uint64_t max_document_frequency = 0;                                               // cpp/main.cu:662-671

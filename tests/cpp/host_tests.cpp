@@ -11,6 +11,7 @@
 
 #include "../../cunvsm_amd/host/data.hpp"
 #include "../../cunvsm_amd/host/index_source.hpp"
+#include "../../cunvsm_amd/host/indri_index.hpp"
 #include "../../cunvsm_amd/host/trectext_index.hpp"
 
 using namespace nvsm_host;
@@ -428,8 +429,43 @@ static int probe(int argc, char** argv) {
     return 2;
 }
 
+// ---- cpp/data_tests.cpp:623-683: the Indri 5.8 repository the reference ships (test_data/Brown_index) ----
+static std::string g_brown_path;
+static void test_IndriSource_Brown() {
+    if (g_brown_path.empty()) { std::printf("    (skipped: NVSM_BROWN_INDEX not set)\n"); return; }
+    IndriDiskIndex* index = IndriDiskIndex::open(g_brown_path);
+    EXPECT_EQ(index->documentCount(), 500u);
+    EXPECT_EQ(index->uniqueTermCount(), 29980u);
+    EXPECT_EQ(index->termCount(), 1032531u);
+    EXPECT_EQ(index->documentLength(1), 2032);
+    EXPECT_EQ(index->term(TERMID_T(1)), std::string("time"));
+    EXPECT_EQ(index->term(std::string("jury")) > 10, true);
+    RNG rng;
+    IndexSource source(index, 16, &rng, 0, 0, 0, 0, false, false, nullptr, nullptr, true, AUTOMATIC_SAMPLING, UNIFORM);
+    EXPECT_EQ(source.corpus_size(), 500u);
+    size_t i = 0;
+    for (const auto& pair : source.document_id_mapping()) { EXPECT_EQ(pair.first, i); EXPECT_EQ(pair.second, static_cast<DOCID_T>(i + 1)); ++i; }
+    Batch batch(4, 16);
+    EXPECT_TRUE(source.has_next());
+    source.next(&batch);
+    std::map<size_t, std::string> str_instances;
+    for (size_t b = 0; b < batch.num_instances(); ++b) {
+        std::string tmp;
+        for (size_t j = 0; j < 16; ++j) tmp += source.term(batch.features()[b * 16 + j]) + " ";
+        str_instances[static_cast<size_t>(source.document_id_mapping().at(static_cast<size_t>(batch.labels()[b])))] = tmp;
+    }
+    const std::map<size_t, std::string> want = {
+        {405, "kept signal dowl car coming steady clear start back hamburger shut device want hang eat dont "},
+        {215, "conspire uncle make secret gift money mother story end child illness delirium brought feverish compulsion ride "},
+        {434, "morgan im usually strong woman im awfully tired hungry start meal eat meal girl cry morgan "},
+        {392, "write pleasant note beautiful last life part ways goodbye forever word fifty dollar add postscript beg "}};
+    EXPECT_TRUE(str_instances == want);
+    if (!(str_instances == want)) for (const auto& kv : str_instances) std::printf("      got %zu: %s\n", kv.first, kv.second.c_str());
+}
+
 int main(int argc, char** argv) {
     log_to_stderr() = false;
+    if (const char* e = std::getenv("NVSM_BROWN_INDEX")) g_brown_path = e;
     if (argc > 1 && std::string(argv[1]).compare(0, 2, "--") == 0) {
         try { return probe(argc, argv); } catch (const std::exception& e) { std::printf("probe failed: %s\n", e.what()); return 1; }
     }
@@ -449,6 +485,7 @@ int main(int argc, char** argv) {
         {"Batch.swap", test_Batch_swap},
         {"Metadata.roundtrip", test_Metadata_roundtrip},
         {"TrectextIndex.end_to_end", test_TrectextIndex},
+        {"IndriSourceTest.Brown", test_IndriSource_Brown},
     };
     int failed_tests = 0;
     for (const auto& t : tests) {

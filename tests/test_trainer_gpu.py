@@ -88,11 +88,27 @@ def test_trainer_refuses_what_it_cannot_do(tmp_path):
     r = run_trainer(["--update_method", "sgd", "--nonlinearity", "tanh", "--seed", "1", "--entity_similarity_weight", "0.5", CRANFIELD])
     assert r.returncode == 1 and "only the text-entity objective" in r.stderr
     r = run_trainer(["--update_method", "sgd", "--nonlinearity", "tanh", "--seed", "1", str(tmp_path)])
-    assert r.returncode == 1 and "Indri repositories cannot be read" in r.stderr
+    assert r.returncode == 1 and "Unable to open Indri parameters" in r.stderr
     r = run_trainer(["--update_method", "sgd", "--nonlinearity", "tanh", CRANFIELD])
     assert r.returncode == 1 and "Please specify a --seed value." in r.stderr
     r = run_trainer(["--update_method", "nope", "--nonlinearity", "tanh", "--seed", "1", CRANFIELD])
     assert r.returncode == 1 and "Please specify a valid --update_method." in r.stderr
+
+
+def test_trains_from_the_indri_repository(tmp_path):
+    """The reference's own input format: the Indri 5.8 repository it ships for its tests (500 Brown-corpus documents)."""
+    brown = os.path.join(ROOT, "tests", "golden", "Brown_index")
+    out = str(tmp_path / "brown")
+    r = run_trainer(["--word_repr_size", "64", "--entity_repr_size", "32", "--window_size", "16", "--num_random_entities", "5", "--seed", "1",
+                     "--update_method", "adagrad", "--batch_size", "4096", "--nonlinearity", "tanh", "--bias_negative_samples",
+                     "--weighting", "uniform", "--max_vocabulary_size", "30000", "--num_epochs", "2", "--output", out, brown])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "corpus size=500" in r.stderr
+    costs = epoch_costs(r.stderr)
+    assert len(costs) == 2 and costs[1] < costs[0]
+    meta = parse_metadata(out + "_meta")
+    assert len(meta.object) == 500 and [o.index_object_id for o in meta.object][:3] == [1, 2, 3]
+    assert meta.total_terms > 300000
 
 
 def test_rccl_selftest_and_pinned_alloc():

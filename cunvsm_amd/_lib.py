@@ -97,8 +97,9 @@ def lib():
         "nvsm_rng_get_state": (C.c_int, [vp, P(C.c_uint64)]), "nvsm_rng_set_state": (C.c_int, [vp, C.c_uint64]),
         "nvsm_param_size": (C.c_int, [vp, cp, P(i64)]),
         "nvsm_get_param": (C.c_int, [vp, cp, vp, i64]), "nvsm_set_param": (C.c_int, [vp, cp, vp, i64]),
+        "nvsm_increment_parameter": (C.c_int, [vp, cp, i64, C.c_float]),
         "nvsm_compute_cost": (C.c_int, [vp, P(NvsmBatch), vp]), "nvsm_compute_gradients": (C.c_int, [vp]),
-        "nvsm_update": (C.c_int, [vp, C.c_float, C.c_float]), "nvsm_get_cost": (C.c_int, [vp, P(C.c_float)]),
+        "nvsm_update": (C.c_int, [vp, C.c_float, C.c_float]), "nvsm_get_cost": (C.c_int, [vp, P(C.c_float)]), "nvsm_get_cost_f64": (C.c_int, [vp, P(C.c_double)]),
         "nvsm_scaled_regularization_lambda": (C.c_float, [vp]),
         "nvsm_step": (C.c_int, [vp, P(NvsmBatch), vp, C.c_float, P(C.c_float)]),
         "nvsm_tensor_size": (C.c_int, [vp, cp, P(i64)]), "nvsm_get_tensor": (C.c_int, [vp, cp, vp, i64]),

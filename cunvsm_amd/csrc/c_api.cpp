@@ -103,6 +103,11 @@ int nvsm_set_param(nvsm_model* m, const char* name, const float* src, int64_t co
     return guarded([&] { m->impl.set_param(name, src, count); });
 }
 
+int nvsm_increment_parameter(nvsm_model* m, const char* name, int64_t index, float delta) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(name);
+    return guarded([&] { m->impl.increment_param(name, index, delta); });
+}
+
 int nvsm_compute_cost(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(batch);
     return guarded([&] { m->impl.compute_cost(*batch, entity_ids); });
@@ -110,6 +115,7 @@ int nvsm_compute_cost(nvsm_model* m, const nvsm_batch* batch, const int64_t* ent
 int nvsm_compute_gradients(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.compute_gradients(); }); }
 int nvsm_update(nvsm_model* m, float lr, float scaled_lambda) { NVSM_REQUIRE(m); return guarded([&] { m->impl.update(lr, scaled_lambda); }); }
 int nvsm_get_cost(nvsm_model* m, float* cost) { NVSM_REQUIRE(m); NVSM_REQUIRE(cost); return guarded([&] { *cost = m->impl.get_cost(); }); }
+int nvsm_get_cost_f64(nvsm_model* m, double* cost) { NVSM_REQUIRE(m); NVSM_REQUIRE(cost); return guarded([&] { (void)m->impl.get_cost(); *cost = m->impl.cost_f64(); }); }
 float nvsm_scaled_regularization_lambda(nvsm_model* m) { return m ? m->impl.scaled_regularization_lambda() : 0.f; }
 int nvsm_step(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids, float lr, float* cost) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(batch);

@@ -792,6 +792,17 @@ void Model::set_param(const std::string& name, const float* src, int64_t count) 
     NVSM_HIP_CHECK(hipMemcpy(r.p, src, count * sizeof(float), hipMemcpyHostToDevice));
 }
 
+void Model::increment_param(const std::string& name, int64_t index, float delta) {
+    ParamRef r = find_param(name);
+    if (!r.p) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown parameter: " + name);
+    if (index < 0 || index >= r.n) throw Error(NVSM_ERR_INVALID_ARGUMENT, "parameter index out of range for " + name);
+    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    float v = 0.f;
+    NVSM_HIP_CHECK(hipMemcpy(&v, r.p + index, sizeof(float), hipMemcpyDeviceToHost));
+    v += delta;
+    NVSM_HIP_CHECK(hipMemcpy(r.p + index, &v, sizeof(float), hipMemcpyHostToDevice));
+}
+
 int64_t Model::tensor_size(const std::string& name) {
     const int64_t B = B_, N = B_ * R_;
     const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size;

@@ -103,12 +103,14 @@ class Model {
     void compute_gradients();
     void update(float lr, float scaled_lambda);
     float get_cost();
+    double cost_f64() const { return cost_; }      // valid after get_cost()
     float scaled_regularization_lambda() const;
     void step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, float* cost);
 
     int64_t param_size(const std::string& name);
     void get_param(const std::string& name, float* dst, int64_t count);
     void set_param(const std::string& name, const float* src, int64_t count);
+    void increment_param(const std::string& name, int64_t index, float delta);
     int64_t tensor_size(const std::string& name);
     void get_tensor(const std::string& name, float* dst, int64_t count);
 

@@ -7,7 +7,7 @@
 //     no docno look-ups, so --document_list needs the TREC-text form), or the TREC-text collection file itself, indexed
 //     in memory on start-up (host/trectext_index.hpp).
 //   * only TextEntity::Objective (LSE / NVSM) is accelerated: non-zero --entity_similarity_weight /
-//     --term_similarity_weight, --check_gradients and the l2 normalisers are refused with a clear message.
+//     --term_similarity_weight and the l2 normalisers are refused with a clear message.
 //   * extensions: --stopwords, --device, --sampler {host,device}, --allow_ragged_batches.
 #include <sys/stat.h>
 
@@ -168,7 +168,16 @@ class Trainer {
                 b.labels = batch->labels(); b.weights = batch->weights();
                 b.num_instances = static_cast<int64_t>(n); b.on_device = 0;
                 float cost = 0.f;
-                if (backpropagate) {
+                if (FLAGS_check_gradients) {
+                    NVSM_CALL(nvsm_compute_cost(model_, &b, nullptr));
+                    NVSM_CALL(nvsm_compute_gradients(model_));
+                    NVSM_CALL(nvsm_get_cost(model_, &cost));
+                    // cpp/main.cu:414-425 passes epsilon 1e-4 (and is validated in the fp64 test build). The forward pass here is
+                    // fp32: per-term rounding puts ~4e-9 of noise on the cost, as large as the 2·ε·g signal of the small
+                    // gradients at ε = 1e-4; ε = 1e-2 keeps the same 10 % threshold meaningful for every parameter.
+                    NVSM_CHECK(check_gradients(b, cost, 1e-2f, 1e-1f)) << "Gradient check failed.";
+                    if (backpropagate) NVSM_CALL(nvsm_update(model_, tc_.learning_rate, nvsm_scaled_regularization_lambda(model_)));
+                } else if (backpropagate) {
                     // compute_cost → compute_gradients → update(lr, scaled λ) → get_cost (cpp/main.cu:405-444) as ONE call:
                     // same arithmetic, the independent halves of the backward pass overlapped on two streams
                     NVSM_CALL(nvsm_step(model_, &b, nullptr, tc_.learning_rate, &cost));
@@ -198,6 +207,77 @@ class Trainer {
     }
 
     uint64_t windows() const { return windows_; }
+
+    // GradientCheckFn (cpp/gradient_check.cu:3-140) as main.cu calls it (:414-425: epsilon 1e-4, relative error
+    // threshold 1e-1): central differences of the cost for EVERY scalar parameter, negatives replayed (the sampled
+    // document ids of the batch are read back once and handed to every re-evaluation).
+    bool check_gradients(const nvsm_batch& b, float cost, float epsilon, float relative_error_threshold) {
+        const int64_t B = b.num_instances, w = static_cast<int64_t>(tc_.window_size), R = static_cast<int64_t>(tc_.num_random_entities) + 1;
+        const int64_t N = B * R;
+        std::vector<float> idsf(N), gT(static_cast<size_t>(de_) * dw_), gb(de_), gphrase(static_cast<size_t>(B) * dw_), gent(static_cast<size_t>(N) * de_);
+        NVSM_CALL(nvsm_get_tensor(model_, "entity_ids", idsf.data(), N));
+        NVSM_CALL(nvsm_get_tensor(model_, "grad_transform", gT.data(), static_cast<int64_t>(gT.size())));
+        NVSM_CALL(nvsm_get_tensor(model_, "grad_bias", gb.data(), static_cast<int64_t>(gb.size())));
+        NVSM_CALL(nvsm_get_tensor(model_, "grad_phrase", gphrase.data(), static_cast<int64_t>(gphrase.size())));
+        NVSM_CALL(nvsm_get_tensor(model_, "grad_entity", gent.data(), static_cast<int64_t>(gent.size())));
+        std::vector<int64_t> ids(N);
+        for (int64_t i = 0; i < N; ++i) ids[i] = static_cast<int64_t>(idsf[i]);
+        // RepresentationsStorage::get_parameter_gradient (cpp/storage.cu:133-183), densified once on the host
+        std::vector<double> gW(static_cast<size_t>(num_words_) * dw_, 0.0), gE(static_cast<size_t>(num_entities_) * de_, 0.0);
+        for (int64_t e = 0; e < B * w; ++e) {
+            const int64_t r = b.features[e];
+            const double wt = b.feature_weights ? b.feature_weights[e] : 1.0;
+            for (int t = 0; t < dw_; ++t) gW[r * dw_ + t] += wt * gphrase[(e / w) * dw_ + t];
+        }
+        for (int64_t j = 0; j < N; ++j)
+            for (int t = 0; t < de_; ++t) gE[ids[j] * de_ + t] += gent[static_cast<size_t>(j) * de_ + t];
+
+        auto eval = [&]() {       // the cost in fp64 (the device accumulator's precision): float costs differ in the 7th digit only
+            double c = 0.0;
+            NVSM_CALL(nvsm_compute_cost(model_, &b, ids.data()));
+            NVSM_CALL(nvsm_get_cost_f64(model_, &c));
+            return c;
+        };
+        // "Sanity check to make sure we're getting the right RNG state" (:28-29)
+        NVSM_CHECK(std::fabs(eval() - cost) <= 1e-5 * std::max(1.0, std::fabs(static_cast<double>(cost)))) << "cost is not reproducible with the recorded document ids";
+
+        bool checked = true;
+        size_t num_checked = 0;
+        auto check_param = [&](const char* what, const char* name, int64_t idx, double gradient) {
+            const float gradient_predict = static_cast<float>(-gradient);            // :42-43
+            NVSM_CALL(nvsm_increment_parameter(model_, name, idx, epsilon));
+            const double cost_added = eval();
+            NVSM_CALL(nvsm_increment_parameter(model_, name, idx, -2.0f * epsilon));
+            const double cost_removed = eval();
+            NVSM_CALL(nvsm_increment_parameter(model_, name, idx, epsilon));
+            const float gradient_approx = static_cast<float>((cost_added - cost_removed) / (2.0 * epsilon));
+            const float relative_error = std::fabs(gradient_predict - gradient_approx) / std::max(std::fabs(gradient_predict), std::fabs(gradient_approx));
+            const float ratio = gradient_approx != 0.f ? gradient_predict / gradient_approx : NAN;
+            ++num_checked;
+            if (gradient_predict * gradient_approx < 0.f) {
+                NVSM_LOG(ERROR) << "Parameter " << idx << " of " << what << " has gradient with incorrect direction (approx=" << gradient_approx
+                                << ", predict=" << gradient_predict << ", ratio=" << ratio << ", relative error=" << relative_error << ").";
+                checked = false;
+            } else if (relative_error >= relative_error_threshold) {
+                NVSM_VLOG(1) << "Parameter " << idx << " of " << what << " most likely has incorrect gradient (approx=" << gradient_approx
+                             << ", predict=" << gradient_predict << ", ratio=" << ratio << ", relative error=" << relative_error << ").";
+                if (!std::isnan(ratio)) checked = false;
+            } else if (gradient_approx != 0.f || gradient_predict != 0.f) {
+                NVSM_VLOG(2) << "Parameter " << idx << " of " << what << " has correct gradient (approx=" << gradient_approx << ", predict="
+                             << gradient_predict << ", ratio=" << ratio << ", relative error=" << relative_error << ").";
+            }
+        };
+        // model->params_ in ParamIdentifier order: WORD_REPRS, TRANSFORM (projection then bias), ENTITY_REPRS
+        for (size_t i = 0; i < gW.size(); ++i) check_param("word representations", "word_representations-representations", static_cast<int64_t>(i), gW[i]);
+        for (size_t i = 0; i < gT.size(); ++i) check_param("transform", "word_entity_mapping-transform", static_cast<int64_t>(i), gT[i]);
+        for (size_t i = 0; i < gb.size(); ++i) check_param("transform (bias)", "word_entity_mapping-bias", static_cast<int64_t>(i), gb[i]);
+        for (size_t i = 0; i < gE.size(); ++i) check_param("entity representations", "entity_representations-representations", static_cast<int64_t>(i), gE[i]);
+        NVSM_CHECK(std::fabs(eval() - cost) <= 1e-5 * std::max(1.0, std::fabs(static_cast<double>(cost)))) << "parameters were not restored";
+        // leave the model as the caller had it: forward result and gradients of this batch
+        NVSM_CALL(nvsm_compute_gradients(model_));
+        NVSM_VLOG(1) << "Gradient check: " << num_checked << " parameters, " << (checked ? "passed" : "FAILED") << ".";
+        return checked;
+    }
 
  private:
     nvsm_model* model_;
@@ -279,8 +359,6 @@ int run(int argc, char** argv) {
     if (FLAGS_entity_similarity_weight != 0.0 || FLAGS_term_similarity_weight != 0.0)
         NVSM_LOG(FATAL) << "only the text-entity objective (LSE / NVSM) is implemented on this platform; "
                            "--entity_similarity_weight and --term_similarity_weight must be 0.";
-    if (FLAGS_check_gradients)
-        NVSM_LOG(FATAL) << "--check_gradients is not available in the trainer; the full-parameter gradient check runs in the test-suite.";
 
     NVSM_LOG(INFO) << "Model descriptor: word_repr_size: " << FLAGS_word_repr_size << " entity_repr_size: " << FLAGS_entity_repr_size
                    << " transform_desc { batch_normalization: " << (FLAGS_batch_normalization ? "true" : "false") << " nonlinearity: "

@@ -134,6 +134,8 @@ int nvsm_host_free(void* p);
 int nvsm_param_size(nvsm_model* m, const char* name, int64_t* count);
 int nvsm_get_param(nvsm_model* m, const char* name, float* host_dst, int64_t count);
 int nvsm_set_param(nvsm_model* m, const char* name, const float* host_src, int64_t count);
+/* Storage::increment_parameter(idx, epsilon) (cpp/storage.cu:123-131,252-264): the gradient checker's poke. */
+int nvsm_increment_parameter(nvsm_model* m, const char* name, int64_t index, float delta);
 
 /* Model::compute_cost(batch, rng) (cpp/model.cu:135-143 → cpp/objective.cu:30-313).
  * entity_ids: optional [num_instances * (num_random_entities + 1)] int64 HOST array laid out as
@@ -145,6 +147,9 @@ int nvsm_compute_gradients(nvsm_model* m);
 int nvsm_update(nvsm_model* m, float learning_rate, float scaled_regularization_lambda);
 /* ForwardResult::get_cost() (cpp/intermediate_results.cu:80-124) — synchronises the stream, like the reference. */
 int nvsm_get_cost(nvsm_model* m, float* cost);
+/* the same value before it is narrowed to FloatT: the device accumulates Σ ω·log p in fp64, which is what lets the
+ * gradient checker difference two costs that agree to seven digits */
+int nvsm_get_cost_f64(nvsm_model* m, double* cost);
 /* ForwardResult::scaled_regularization_lambda() (cpp/intermediate_results.cu:126-129): lambda / (global) batch */
 float nvsm_scaled_regularization_lambda(nvsm_model* m);
 

@@ -222,3 +222,16 @@ def test_trainer_trajectory_matches_oracle(tmp_path, method, extra):
         # rounding of `θ·decay + lr·g` itself, which scales with ‖θ‖, not with the update
         tol = (1e-2 if method.endswith("adam") else 2e-3) * change + 2e-6 * np.linalg.norm(init[n])
         assert diff <= tol, (n, diff, change)
+
+
+def test_check_gradients_flag(tmp_path):
+    """--check_gradients (cpp/main.cu:414-425 → cpp/gradient_check.cu): central differences for every scalar parameter of
+    a small model; passes on the real gradients and the run aborts when the check cannot pass (ε far too large)."""
+    args = ["--word_repr_size", "3", "--entity_repr_size", "4", "--window_size", "3", "--num_random_entities", "1", "--seed", "2",
+            "--update_method", "sgd", "--batch_size", "1024", "--nonlinearity", "tanh", "--weighting", "uniform", "--document_cutoff", "12",
+            "--max_vocabulary_size", "30", "--min_document_frequency", "0", "--num_epochs", "1", "--check_gradients", "--allow_ragged_batches",
+            "--v", "1", CRANFIELD]
+    r = run_trainer(args, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert re.search(r"Gradient check: \d+ parameters, passed", r.stderr)
+    assert "incorrect direction" not in r.stderr

@@ -203,6 +203,8 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     NVSM_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     own_stream_ = true;
     NVSM_HIP_CHECK(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
+    NVSM_HIP_CHECK(hipStreamCreateWithFlags(&aux2_stream_, hipStreamNonBlocking));
+    NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, hipEventDisableTiming));
     for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_aux_done_}) NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -233,6 +235,8 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
 Model::~Model() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
+    if (aux2_stream_) { (void)hipStreamSynchronize(aux2_stream_); (void)hipStreamDestroy(aux2_stream_); }
+    if (ev_csr_ents_) (void)hipEventDestroy(ev_csr_ents_);
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
     for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_aux_done_}) if (e) (void)hipEventDestroy(e);
@@ -250,6 +254,7 @@ void Model::set_stream(hipStream_t s) {
 void Model::synchronize() {
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(aux_stream_));
+    NVSM_HIP_CHECK(hipStreamSynchronize(aux2_stream_));
 }
 
 // ModelBase::initialize (cpp/model.cu:37-43) with init_matrix_glorot (include/cuNVSM/cuda_utils.h:35-56):
@@ -402,10 +407,14 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
 
     // Row-order (CSR) of both tables for the update, on the side stream: needs only the indices.
     NVSM_HIP_CHECK(hipEventRecord(ev_inputs_, stream_));
+    // two side streams: the sorts are latency-bound chains of small launches, so the two tables' builds run next to
+    // each other (at batch 4096 one behind the other they were the longest chain of the whole step)
     NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_inputs_, 0));
-    { PROF_ON("csr_entities", aux_stream_); build_csr(ents_, ids_.p, N); }
-    { PROF_ON("csr_words", aux_stream_); build_csr(words_, widx_.p, B * w); }
-    NVSM_HIP_CHECK(hipEventRecord(ev_csr_, aux_stream_));
+    NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_inputs_, 0));
+    { PROF_ON("csr_entities", aux_stream_); build_csr(ents_, ids_.p, N, aux_stream_); }
+    NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, aux_stream_));
+    { PROF_ON("csr_words", aux2_stream_); build_csr(words_, widx_.p, B * w, aux2_stream_); }
+    NVSM_HIP_CHECK(hipEventRecord(ev_csr_, aux2_stream_));
 
     // F3: phrase representations (objective.cu:126-130)
     { PROF("gather_mean_words"); launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, phrase_.p, stream_); }
@@ -571,9 +580,9 @@ Csr Model::csr_of(TableState& t, int64_t n) {
     return c;
 }
 
-void Model::build_csr(TableState& t, const int* keys, int64_t n) {
-    sort_pairs(t.sort_temp.p, t.sort_temp_bytes, keys, t.sorted_key.p, iota_.p, t.sorted_entry.p, n, t.sort_bits, aux_stream_);
-    launch_csr_build(csr_of(t, n), aux_stream_);
+void Model::build_csr(TableState& t, const int* keys, int64_t n, hipStream_t s) {
+    sort_pairs(t.sort_temp.p, t.sort_temp_bytes, keys, t.sorted_key.p, iota_.p, t.sorted_entry.p, n, t.sort_bits, s);
+    launch_csr_build(csr_of(t, n), s);
 }
 
 static void fill_adam_consts(RowPassArgs& a, float bc, float sl) {
@@ -704,7 +713,8 @@ void Model::update(float lr, float scaled_lambda) {
     if (!have_grads_) throw Error(NVSM_ERR_STATE, "update requires compute_gradients");
     if (lr < 0.f || scaled_lambda < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");   // storage.cu:62-63
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
-    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));     // join the side-stream CSR builds
+    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));     // join the side-stream CSR builds
+    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
     update_entities(lr, scaled_lambda, stream_);
     update_words(lr, scaled_lambda);
     update_transform(lr, scaled_lambda, stream_);

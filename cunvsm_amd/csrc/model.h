@@ -125,7 +125,7 @@ class Model {
  private:
     struct ParamRef { float* p; int64_t n; };
     ParamRef find_param(const std::string& name);
-    void build_csr(TableState& t, const int* keys, int64_t n);
+    void build_csr(TableState& t, const int* keys, int64_t n, hipStream_t s);
     Csr csr_of(TableState& t, int64_t n);
     void backward_dx();                                  // B5, B7, B9 on the main stream
     void backward_T(hipStream_t s);                      // B6 (+ its all-reduce)
@@ -144,6 +144,8 @@ class Model {
     // The batch → CSR builds depend only on the indices, so they run on a side stream concurrently with the
     // forward / backward kernels and are joined right before the row passes.
     hipStream_t aux_stream_ = nullptr;
+    hipStream_t aux2_stream_ = nullptr;   // the words CSR build: next to the documents CSR build instead of behind it
+    hipEvent_t ev_csr_ents_ = nullptr;
     hipEvent_t ev_inputs_ = nullptr, ev_csr_ = nullptr;
     // fused step(): the documents update (HBM bound) and the dT GEMM (MFMA bound) run on the side stream next to the
     // dx GEMM and the words update on the main stream

@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step (PCIe-inclusive rate)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="full-size steps of the CPU oracle timed for cpu_baseline (≈1 s each on 128 cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sequential", action="store_true", help="compute_cost / compute_gradients / update as separate calls on one stream "
+                    "(un-overlapped per-kernel timings) instead of the fused multi-stream nvsm_step")
     ap.add_argument("--read-cost-every", type=int, default=0, help="read the loss back every n steps (0 = never inside the timed region)")
     args = ap.parse_args()
 
@@ -225,7 +227,13 @@ def main():
     last_cost = None
     for s in range(args.steps):
         want = args.read_cost_every > 0 and (s + 1) % args.read_cost_every == 0
-        c = model.step(pool[s % len(pool)], lr, want_cost=want)
+        if args.sequential:
+            model.compute_cost(pool[s % len(pool)])
+            model.compute_gradients()
+            model.update(lr)
+            c = model.get_cost() if want else None
+        else:
+            c = model.step(pool[s % len(pool)], lr, want_cost=want)
         if want:
             last_cost = c
     model.synchronize()
@@ -261,7 +269,7 @@ def main():
         # largest kernel of the step that runs with nothing else next to it but the (tiny) side-stream sorts. In the fused
         # step the documents update / dT GEMM overlap the dx GEMM / words update on a second stream; their event-timed
         # durations (marked "overlapped") include the time they share the chip and are not per-kernel roofline figures.
-        for k in ("chunk_pass_entities", "row_pass_entities", "gemm_bwd_T", "transform_update", "csr_entities", "csr_words"):
+        for k in (() if args.sequential else ("chunk_pass_entities", "row_pass_entities", "gemm_bwd_T", "transform_update", "csr_entities", "csr_words")):
             if k in breakdown:
                 breakdown[k]["overlapped"] = True
         dom = "loss_fused" if "loss_fused" in breakdown else next((k for k in breakdown if algorithmic_bytes(k, wl, method)), None)
@@ -283,7 +291,7 @@ def main():
                                    % (wl["num_words"], wl["num_entities"], B, method,
                                       "uniform" if args.uniform_words else "Zipf(1)"),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "update_method": method, "collectives": transport,
-                       "inputs": "host" if args.host_batches else "hbm"},
+                       "inputs": "host" if args.host_batches else "hbm", "step": "sequential calls" if args.sequential else "fused nvsm_step"},
             "roofline": roofline,
             "kernel_breakdown": breakdown,
             "final_cost": round(float(final_cost), 6),

@@ -415,10 +415,9 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
     const int padded_groups = ((g.groups + 7) / 8) * 8;
     dim3 grid(padded_groups * g.members);
     dim3 block(256);
-    // 47 KB of unused dynamic LDS cap the residency at two workgroups per CU. Alone the GEMM is as fast with two as with
-    // three (0.103 ms forward); in the fused step the third workgroup's 152 registers per lane are what the HBM-bound
-    // row passes of the other stream need to co-reside on the CU (1.262 -> 1.241 ms per step).
-    constexpr size_t lds_pad = 47 * 1024;
+    // (Capping the residency at two workgroups per CU with unused dynamic LDS, to leave registers for the HBM-bound row
+    // passes of the other stream, was A/B-tested interleaved: 1.268 vs 1.258 ms per step — no gain, not done.)
+    constexpr size_t lds_pad = 0;
     if (rowsq && split_k <= 1) {
         if (fast && a_layout == 0 && b_layout == 1 && !g.colstats) {
             g.rowsq = rowsq;

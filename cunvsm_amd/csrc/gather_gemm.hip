@@ -506,24 +506,6 @@ void launch_iota(int* dst, int64_t n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(iota_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, dst, n);
 }
 
-__global__ void fill_f32_kernel(float* __restrict__ dst, float v, int64_t n) {
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
-         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
-        dst[i] = v;
-}
-void launch_fill_f32(float* dst, float v, int64_t n, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(fill_f32_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, dst, v, n);
-}
-
-__global__ void scale_kernel(float* __restrict__ p, float sc, int64_t n) {
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
-         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
-        p[i] *= sc;
-}
-void launch_scale(float* p, float sc, int64_t n, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, p, sc, n);
-}
-
 // SplitMix64 finaliser as a counter-based generator; ids uniform over [0, num_entities) via 64-bit
 // multiply-high (bias < 2^-40). Same distribution as UniformLabelGenerator (cpp/labels.cu:4-22):
 // slot 0 = the positive label, slots 1..k uniform over ALL documents (may repeat / hit the positive).

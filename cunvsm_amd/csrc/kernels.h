@@ -31,7 +31,6 @@ int gemm_split_k_slabs(int K, int want);   // actual number of slabs launch_gemm
 void launch_splitk_reduce(const float* partial, int slabs, size_t stride, float* out, int64_t n, hipStream_t s);
 
 // ---- batch normalisation (F6, B5; replaces cuDNN per-activation BN, cpp/cudnn_utils.cu:82-183) --
-void launch_bn_colstats(const float* x, int64_t rows, int dim, double* sums /*[2][dim]: Σx, Σx²*/, hipStream_t s);
 void launch_bn_finalize(const double* sums, int dim, double n_global, float eps, float* mean, float* inv_std, hipStream_t s);
 // dβ = Σdy, dγ = Σdy·x̂ (double sums [2][dim]) → floats + grad_bias
 void launch_bn_bwd_finalize(const double* sums, int dim, float* dbeta, float* dgamma, float* grad_bias, hipStream_t s);
@@ -45,7 +44,6 @@ void launch_sample_entities(const int64_t* labels, int64_t B, int R, int64_t num
                             uint64_t step, int* ids, hipStream_t s);
 void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, hipStream_t s);
 void launch_iota(int* dst, int64_t n, hipStream_t s);
-void launch_fill_f32(float* dst, float v, int64_t n, hipStream_t s);
 
 // ---- fused loss forward + backward (F7–F16, B1–B4; replaces cpp/objective.cu:159-305,354-425 and the
 // nonlinearity at cpp/params.cu:430-446,474-491) ------------------------------------------------
@@ -155,7 +153,5 @@ struct TransformUpdateArgs {
 };
 void launch_transform_update(const TransformUpdateArgs& a, hipStream_t s);
 
-// scale (dense decay) — table *= s   (cpp/storage.cu:65-67), used when a table has no entries at all
-void launch_scale(float* p, float s, int64_t n, hipStream_t s_);
 
 }  // namespace cunvsm

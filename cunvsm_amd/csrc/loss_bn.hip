@@ -7,32 +7,9 @@ namespace cunvsm {
 // =============================================================================================
 // Batch normalisation, per-activation, γ ≡ 1, β = projection bias, batch statistics only
 // (replaces cudnnBatchNormalizationForwardTraining/Backward, cpp/cudnn_utils.cu:107-124,158-177).
-// Column sums are accumulated in fp32 over a 128-row slab per block and merged with native fp64
-// atomics, so var = E[x²] − E[x]² is formed in double.
+// The forward column sums Σx, Σx² come from the projection GEMM's epilogue (gather_gemm.hip): fp32 over a
+// 128-row tile, merged with native fp64 atomics, so var = E[x²] − E[x]² is formed in double.
 // =============================================================================================
-constexpr int kStatRows = 128;
-
-__global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, int64_t rows, int dim,
-                                                          double* __restrict__ sums) {
-    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kStatRows;
-    const int64_t r1 = min(rows, r0 + kStatRows);
-    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-        float s = 0.f, s2 = 0.f;
-        for (int64_t r = r0; r < r1; ++r) {
-            const float v = x[r * dim + c];
-            s += v;
-            s2 += v * v;
-        }
-        atomic_add_f64(sums + c, static_cast<double>(s));
-        atomic_add_f64(sums + dim + c, static_cast<double>(s2));
-    }
-}
-
-void launch_bn_colstats(const float* x, int64_t rows, int dim, double* sums, hipStream_t s) {
-    if (rows <= 0) return;
-    hipLaunchKernelGGL(bn_colstats_kernel, dim3(ceil_div(rows, kStatRows)), dim3(256), 0, s, x, rows, dim, sums);
-}
-
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int dim, double n, float eps,
                                    float* __restrict__ mean, float* __restrict__ inv_std) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -622,11 +622,8 @@ void Model::update_entities(float lr, float sl, hipStream_t strm) {
             else { a.kind = ROW_ADAM_SPARSE_ENT; swap_sc = true; }
         }
     }
-    if (strm != stream_) {      // fused step. Capping the grid (NVSM_ENT_BLOCKS_PER_CU) so that GEMM workgroups find free registers
-                                // on every CU was measured and does not help (1.30 -> 1.31-1.33 ms): default 0 = uncapped
-        static const int per_cu = [] { const char* e = getenv("NVSM_ENT_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
-        a.max_blocks = 256 * per_cu;
-    }
+    // (Capping this grid so that GEMM workgroups of the other stream find free registers on every CU was measured in
+    // the fused step: 1.30 -> 1.31-1.33 ms, no gain; RowPassArgs::max_blocks stays 0.)
     { PROF_ON("chunk_pass_entities", strm); launch_chunk_pass(c, a, strm); }
     { PROF_ON("row_pass_entities", strm); launch_row_pass(c, a, strm); }
     if (swap_sc) t.sc_cur ^= 1;

@@ -2,6 +2,7 @@
 #define NVSM_GEMM_DBG 1
 #include "../../cunvsm_amd/csrc/gather_gemm.hip"
 #include "../../cunvsm_amd/csrc/gemm_panel.hip"
+#include "../../cunvsm_amd/csrc/loss_bn.hip"
 #include <cstdio>
 #include <vector>
 #include <cmath>

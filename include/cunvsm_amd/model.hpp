@@ -4,7 +4,8 @@
 //
 //   reference                                         here
 //   Model(num_words, num_entities, desc, train_cfg)   cunvsm_amd::Model(nvsm_config)
-//   model.initialize(&rng)                            model.initialize(seed)
+//   model.initialize(&rng)                            model.initialize(seed)   |   model.initialize(rng) with the caller's
+//                                                     std::minstd_rand0, whose state is handed over and taken back
 //   ForwardResult* r = model.compute_cost(batch,&rng) model.compute_cost(batch)            (result lives in the handle)
 //   Gradients* g = model.compute_gradients(*r)        model.compute_gradients()
 //   model.update(*g, lr, r->scaled_regularization_lambda())   model.update(lr, model.scaled_regularization_lambda())
@@ -16,6 +17,8 @@
 #pragma once
 
 #include <map>
+#include <random>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -52,6 +55,20 @@ class Model {
     Model& operator=(const Model&) = delete;
 
     void initialize(uint64_t seed) { check(nvsm_initialize(h_, seed)); }
+    // model.initialize(&rng) (cpp/model.cu:37-43) with the reference's own generator object: the Glorot draws continue
+    // from *rng's state and *rng is advanced past them, exactly as if the reference had consumed it (cpp/main.cu:520)
+    void initialize(std::minstd_rand0* rng) {
+        check(nvsm_rng_set_state(h_, state_of(*rng)));
+        check(nvsm_initialize_from_rng_state(h_));
+        sync_rng(rng);
+    }
+    // after compute_cost with the host sampler: advance the caller's generator past the negatives that were drawn
+    void sync_rng(std::minstd_rand0* rng) {
+        uint64_t s = 0;
+        check(nvsm_rng_get_state(h_, &s));
+        std::stringstream ss; ss << s; ss >> *rng;
+    }
+    void push_rng(const std::minstd_rand0& rng) { check(nvsm_rng_set_state(h_, state_of(rng))); }
 
     // entity_ids: optional output of the caller's own label generator; nullptr = sample as configured
     void compute_cost(const Batch& batch, const int64_t* entity_ids = nullptr) { check(nvsm_compute_cost(h_, &batch.raw, entity_ids)); }
@@ -84,12 +101,17 @@ class Model {
     }
     void set_param(const std::string& name, const std::vector<float>& v) { check(nvsm_set_param(h_, name.c_str(), v.data(), static_cast<int64_t>(v.size()))); }
 
+    // Storage::increment_parameter (cpp/storage.cu:123-131) — the gradient checker's poke
+    void increment_parameter(const std::string& name, int64_t index, float epsilon) { check(nvsm_increment_parameter(h_, name.c_str(), index, epsilon)); }
+    double get_cost_f64() { double c = 0.0; check(nvsm_get_cost_f64(h_, &c)); return c; }
+
     void synchronize() { check(nvsm_synchronize(h_)); }
     void comm_init(const char id[128]) { check(nvsm_comm_init(h_, id)); }
     nvsm_model* handle() { return h_; }
     const nvsm_config& config() const { return cfg_; }
 
  private:
+    static uint64_t state_of(const std::minstd_rand0& rng) { std::stringstream ss; ss << rng; uint64_t s = 0; ss >> s; return s; }
     nvsm_config cfg_;
     nvsm_model* h_ = nullptr;
 };

@@ -59,3 +59,13 @@ def test_config_struct_matches_header_size():
     # 2 x int64 + 19 x int32/float + 5 reserved int32 = 16 + 24*4 = 112 bytes
     assert C.sizeof(ca.NvsmConfig) == 112
     assert C.sizeof(ca.NvsmBatch) == 48
+
+
+def test_public_headers_compile(tmp_path):
+    """include/cunvsm_amd.h is plain C (a cgo / JNI / ctypes binding can consume it); the C++ wrapper needs C++11 only."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "cunvsm_amd.h")])
+    src = tmp_path / "use.cpp"
+    src.write_text('#include "cunvsm_amd/model.hpp"\nint main() { nvsm_config c; nvsm_config_default(&c); return c.device; }\n')
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])

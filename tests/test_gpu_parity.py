@@ -144,6 +144,16 @@ SPECS = {
                      nonlinearity="hard_tanh", batch_norm=False, lambda_=0.0),
     "wide": dict(num_words=64, num_entities=64, word_dim=64, entity_dim=512, window=4, num_random=2,
                  nonlinearity="tanh", batch_norm=True, lambda_=0.0),
+    # kernel-dispatch corners: > 64 candidates per example (generic loss kernel), the reference's own k = 10 and a small
+    # k (loss_rows_kernel<11> / <6>), window 1, the largest supported document dimension (1024, 4 column slices per lane)
+    "many_negatives": dict(num_words=80, num_entities=90, word_dim=32, entity_dim=64, window=3, num_random=69,
+                           nonlinearity="tanh", batch_norm=False, lambda_=0.01),
+    "k10": dict(num_words=300, num_entities=150, word_dim=300, entity_dim=256, window=10, num_random=10,
+                nonlinearity="hard_tanh", batch_norm=True, lambda_=0.01),
+    "k4_window1": dict(num_words=50, num_entities=40, word_dim=24, entity_dim=128, window=1, num_random=4,
+                       nonlinearity="tanh", batch_norm=True, bias_negative_samples=True, lambda_=0.01),
+    "dim1024": dict(num_words=40, num_entities=30, word_dim=16, entity_dim=1024, window=2, num_random=3,
+                    nonlinearity="hard_tanh", batch_norm=False, lambda_=0.0),
 }
 for _s in SPECS.values():
     _s["lambda"] = _s.pop("lambda_")
@@ -159,7 +169,8 @@ def _pair(spec, B, seed, max_batch=None):
     return o, g, rs
 
 
-@pytest.mark.parametrize("name,B", [("lse", 256), ("nvsm", 1024), ("tiny", 1024), ("tiny_odd", 100), ("wide", 130), ("nvsm", 1000)])
+@pytest.mark.parametrize("name,B", [("lse", 256), ("nvsm", 1024), ("tiny", 1024), ("tiny_odd", 100), ("wide", 130), ("nvsm", 1000),
+                                    ("many_negatives", 96), ("k10", 512), ("k4_window1", 200), ("dim1024", 64)])
 def test_forward_backward_parity(name, B):
     spec = SPECS[name]
     o, g, rs = _pair(spec, B, 11)
@@ -186,7 +197,7 @@ def test_forward_backward_parity(name, B):
 
 
 @pytest.mark.parametrize("method", ["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
-@pytest.mark.parametrize("name", ["nvsm", "tiny", "lse"])
+@pytest.mark.parametrize("name", ["nvsm", "tiny", "lse", "tiny_odd", "k4_window1", "many_negatives"])
 @pytest.mark.parametrize("lam", [0.0, 0.01])
 def test_update_parity(method, name, lam):
     """Three optimiser steps on identical batches; parameters and optimiser state must track the oracle."""

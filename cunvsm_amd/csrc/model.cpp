@@ -200,10 +200,16 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         throw Error(NVSM_ERR_NO_DEVICE, "no HIP device visible — cunvsm_amd has no CPU fallback");
     if (cfg.device < 0 || cfg.device >= ndev) bad("device ordinal out of range");
     NVSM_HIP_CHECK(hipSetDevice(cfg.device));
-    NVSM_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    own_stream_ = true;
-    NVSM_HIP_CHECK(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
-    NVSM_HIP_CHECK(hipStreamCreateWithFlags(&aux2_stream_, hipStreamNonBlocking));
+    {
+        // the main stream carries the step's critical chain: highest priority; the side streams (sorts, documents update,
+        // dT GEMM) lowest. Interleaved A/B: 1.248 vs 1.261 ms per step.
+        int lo = 0, hi = 0;
+        NVSM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        NVSM_HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+        own_stream_ = true;
+        NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, lo));
+        NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux2_stream_, hipStreamNonBlocking, lo));
+    }
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, hipEventDisableTiming));

@@ -134,3 +134,49 @@ def test_dp_hip_equals_single_gpu(spec, tmp_path):
         assert rel_err(r[k]["gb"], ref.get_tensor("grad_bias")) < 1e-5
         assert abs(r[k]["sl"] - ref.scaled_regularization_lambda()) < 1e-12
     assert rel_err(np.concatenate([r[0]["gphrase"], r[1]["gphrase"]]), ref.get_tensor("grad_phrase")) < 1e-5
+
+
+def _worker_gpu_step(rank, port, spec, B, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import cunvsm_amd as ca
+    from cunvsm_amd import dp
+    from tests.helpers import gpu_model, load_params
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
+    params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
+    w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
+    m = gpu_model(spec, B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0)
+    load_params(m, params, True)
+    m.set_allreduce_callback(dp.torch_allreduce(dist))
+    costs = [m.step(ca.Batch(w, wl, wwt, wi), 0.05, entity_ids=wid, want_cost=True) for _ in range(2)]
+    np.savez(os.path.join(out_dir, "step_rank%d.npz" % rank), cost=np.array(costs), T=m.get_param("word_entity_mapping-transform"),
+             b=m.get_param("word_entity_mapping-bias"), E=m.get_param("entity_representations-representations"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["sgd", "sparse_adam"])
+def test_dp_fused_step(tmp_path, method):
+    """nvsm_step under data parallelism (documents update on the side stream, every collective on the main stream): after
+    the first step the replicated projection is identical on both ranks and equal to the single-GPU step on the whole
+    batch; the loss of the first step is the global loss."""
+    import torch.multiprocessing as mp
+    import cunvsm_amd as ca
+    from tests.helpers import gpu_model, load_params, rel_err
+    spec = dict(SPEC, update_method=method)
+    B = 256
+    port = _free_port()
+    mp.spawn(_worker_gpu_step, args=(port, spec, B, str(tmp_path)), nprocs=WORLD, join=True)
+    params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
+    ref = gpu_model(spec, B)
+    load_params(ref, params, True)
+    c0 = ref.step(ca.Batch(words, labels, ww, iw), 0.05, entity_ids=ids, want_cost=True)
+    T1, b1 = ref.get_param("word_entity_mapping-transform"), ref.get_param("word_entity_mapping-bias")
+    r = [np.load(os.path.join(str(tmp_path), "step_rank%d.npz" % k)) for k in range(WORLD)]
+    assert abs(r[0]["cost"][0] - c0) <= 1e-5 * abs(c0) and abs(r[1]["cost"][0] - c0) <= 1e-5 * abs(c0)
+    # replicas of the dense parameters stay in lock-step (both steps) ...
+    np.testing.assert_array_equal(r[0]["T"], r[1]["T"])
+    np.testing.assert_array_equal(r[0]["b"], r[1]["b"])
+    # ... and the embedding tables are rank-local ("sparse rows stay GPU-local"): they differ between the ranks
+    assert not np.array_equal(r[0]["E"], r[1]["E"])

@@ -403,6 +403,22 @@ int main(int argc, char** argv) {
         snprintf(nm, 64, "K3 v3 RB=17 epw=%d grid=%d", epw, g3);
         timeit(nm, [&] { hipLaunchKernelGGL((loss_kernel_v3<17>), dim3(g3), dim3(256), shmem, s, a2, epw); });
     }
+    {   // cold-cache timing: a 400 MB fill between launches evicts E (102 MB) from the 256 MB Infinity Cache, as the rest of
+        // a training step does; events bracket the loss kernel only
+        float* junk; CK(hipMalloc(&junk, 400u << 20));
+        float tot = 0; const int reps = 10;
+        for (int i = 0; i < reps + 2; ++i) {
+            CK(hipMemsetAsync(junk, i, 400u << 20, s));
+            CK(hipEventRecord(ev0, s));
+            launch_loss(a, s);
+            CK(hipEventRecord(ev1, s));
+            CK(hipEventSynchronize(ev1));
+            float ms; CK(hipEventElapsedTime(&ms, ev0, ev1));
+            if (i >= 2) tot += ms;
+        }
+        printf("%-28s avg %.1f us (cold Infinity Cache)\n", "production, evicted", tot / reps * 1e3);
+        hipFree(junk);
+    }
     timeit("K2 v2 RB=6", [&] { hipLaunchKernelGGL((loss_kernel_v2<6>), dim3(grid), dim3(256), shmem, s, a2); });
 
     // correctness: K0 vs K2 RB=17

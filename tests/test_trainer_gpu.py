@@ -75,11 +75,16 @@ def test_nvsm_recipe_runs(tmp_path):
     """NVSM flags of scripts/functions.sh:266 (hard_tanh + batch normalisation, no negative-sample bias), ragged batches allowed."""
     args = ["--word_repr_size", "64", "--entity_repr_size", "32", "--window_size", "10", "--num_random_entities", "4", "--seed", "1",
             "--update_method", "sparse_adam", "--batch_size", "2048", "--nonlinearity", "hard_tanh", "--batch_normalization",
-            "--num_epochs", "2", "--allow_ragged_batches", "--sampler", "device", "--v", "1", CRANFIELD]
+            "--num_epochs", "2", "--allow_ragged_batches", "--sampler", "device", "--v", "1", "--dump_every", "30",
+            "--output", str(tmp_path / "nvsm"), CRANFIELD]
     r = run_trainer(args)
     assert r.returncode == 0, r.stderr[-3000:]
     costs = epoch_costs(r.stderr)
     assert len(costs) == 2 and costs[1] < costs[0]
+    # --dump_every (cpp/main.cu:454-459): "<output>_<epoch>_<batch>.hdf5" every 30 batches + "<output>_<epoch>.hdf5" per epoch
+    for name in ("nvsm_1_30.hdf5", "nvsm_1_60.hdf5", "nvsm_1.hdf5", "nvsm_2_30.hdf5", "nvsm_2.hdf5", "nvsm_meta"):
+        assert os.path.exists(str(tmp_path / name)), name
+    assert not os.path.exists(str(tmp_path / "nvsm_0.hdf5"))          # no --dump_initial_model
     assert "Skipping Batch" not in r.stderr
     assert re.search(r"Batch #0 .*cost=", r.stderr)
 

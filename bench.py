@@ -12,9 +12,11 @@ batch 51 200, hard_tanh + batch-norm, Adam (sparse_adam; --update-method selects
 lr = 1e-3, Zipf(1) word ids, uniform document ids, all weights 1. Weak scaling: every rank gets its own
 51 200-window batch; the dense projection gradient is all-reduced over RCCL each step.
 
-Rank 0 prints ONE JSON line. `roofline` is for the kernel group with the largest share of the step, timed
-with HIP events on the engine's stream during the timed region; `cpu_baseline` is the CPU oracle (fp32,
-OpenMP) timed on this box's host cores on a bounded sample of the same workload (N = 1 only).
+Rank 0 prints ONE JSON line. `roofline` is for the document-embedding gather + loss kernel (the largest HBM
+gather of the step), timed with HIP events on the engine's stream inside the timed region; `kernel_breakdown`
+comes from a second, untimed pass with events around every kernel group (they cost ≈5 % of a step, so they stay
+out of the timed region); `cpu_baseline` is the CPU oracle (fp32, OpenMP) timed on this box's host cores on a
+bounded sample of the same workload (N = 1 only).
 """
 import argparse
 import json
@@ -37,9 +39,26 @@ def zipf_ids(rs, n, size):
     return rs.choice(n, size=size, p=p).astype(np.int64)
 
 
+# --config presets: BASELINE.json configs[1] is the bench line; configs[3] / configs[4] are parity cases
+# (tests/test_gpu_configs.py) that can also be timed here as secondary figures.
+PRESETS = {
+    "nvsm": dict(),
+    "lse_small": dict(num_words=200000, word_dim=128, batch=4096, nonlinearity="tanh", batch_norm=0,
+                      bias_negative_samples=1, update_method="adagrad", lr=1e-2),
+    "large_tables": dict(num_words=500000, num_entities=2000000),
+}
+
+
 def workload(args):
-    return dict(num_words=args.num_words, num_entities=args.num_entities, word_dim=300, entity_dim=256,
-                window=10, num_random=16, batch=args.batch)
+    wl = dict(num_words=50000, num_entities=100000, word_dim=300, entity_dim=256, window=10, num_random=16, batch=51200,
+              nonlinearity="hard_tanh", batch_norm=1, bias_negative_samples=0, lr=1e-3, update_method="sparse_adam")
+    wl.update(PRESETS[args.config])
+    for k, v in (("num_words", args.num_words), ("num_entities", args.num_entities), ("batch", args.batch),
+                 ("update_method", args.update_method)):
+        if v is not None:                      # explicit flags win over the preset
+            wl[k] = v
+    args.update_method = wl.pop("update_method")
+    return wl
 
 
 def algorithmic_bytes(kernel, wl, method):
@@ -99,8 +118,9 @@ def cpu_baseline(args, wl, method):
     from tests.helpers import METHODS
     m, mode = METHODS[method]
     cfg = orc.make_config(wl["num_words"], wl["num_entities"], wl["word_dim"], wl["entity_dim"], wl["window"],
-                          wl["num_random"], batch_norm=True, nonlinearity=orc.HARD_TANH, clip_sigmoid=True,
-                          lambda_=1e-2, update_method=m, adam_mode=mode)
+                          wl["num_random"], batch_norm=bool(wl["batch_norm"]),
+                          nonlinearity=orc.HARD_TANH if wl["nonlinearity"] == "hard_tanh" else orc.TANH, clip_sigmoid=True,
+                          bias_negative_samples=bool(wl["bias_negative_samples"]), lambda_=1e-2, update_method=m, adam_mode=mode)
     model = orc.Model(cfg, orc.F32)
     rng = orc.Rng(1)
     model.initialize(rng)
@@ -117,7 +137,7 @@ def cpu_baseline(args, wl, method):
         ids = rng.generate_labels(labels, wl["num_entities"], wl["num_random"])      # host sampling, as the reference
         model.forward_native(words, ww, ids, iw)
         model.backward()
-        model.update(1e-3)
+        model.update(wl["lr"])
         model.get_cost()
         dt = time.perf_counter() - t0
         if s >= warm:
@@ -132,16 +152,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--update-method", default="sparse_adam", choices=["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
-    ap.add_argument("--batch", type=int, default=51200)
-    ap.add_argument("--num-words", type=int, default=50000)
-    ap.add_argument("--num-entities", type=int, default=100000)
+    ap.add_argument("--config", default="nvsm", choices=sorted(PRESETS), help="nvsm = BASELINE configs[1] (the bench line)")
+    ap.add_argument("--update-method", default=None, choices=["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
+    ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default 51200)")
+    ap.add_argument("--num-words", type=int, default=None)
+    ap.add_argument("--num-entities", type=int, default=None)
     ap.add_argument("--uniform-words", action="store_true", help="uniform instead of Zipf(1) word ids (worst case for caches)")
     ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step (PCIe-inclusive rate)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="full-size steps of the CPU oracle timed for cpu_baseline (≈1 s each on 128 cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sequential", action="store_true", help="compute_cost / compute_gradients / update as separate calls on one stream "
                     "(un-overlapped per-kernel timings) instead of the fused multi-stream nvsm_step")
+    ap.add_argument("--no-profile", action="store_true", help="no HIP events at all (no roofline / breakdown in the output)")
+    ap.add_argument("--profile-all", action="store_true", help="events around every kernel group inside the timed region (≈5 %% slower)")
+    ap.add_argument("--gate-us", type=int, default=0, help="profiling aid: a spin kernel of this many microseconds in front of every "
+                    "step, so that the host has queued the step before the GPU starts it (the timeline then shows the GPU-side schedule)")
     ap.add_argument("--read-cost-every", type=int, default=0, help="read the loss back every n steps (0 = never inside the timed region)")
     args = ap.parse_args()
 
@@ -168,8 +193,9 @@ def main():
     method = args.update_method
     cfg = ca.default_config(num_words=wl["num_words"], num_entities=wl["num_entities"], word_repr_size=wl["word_dim"],
                             entity_repr_size=wl["entity_dim"], window_size=wl["window"],
-                            num_random_entities=wl["num_random"], batch_normalization=1, nonlinearity="hard_tanh",
-                            clip_sigmoid=1, bias_negative_samples=0, regularization_lambda=1e-2, update_method=method,
+                            num_random_entities=wl["num_random"], batch_normalization=wl["batch_norm"],
+                            nonlinearity=wl["nonlinearity"], clip_sigmoid=1,
+                            bias_negative_samples=wl["bias_negative_samples"], regularization_lambda=1e-2, update_method=method,
                             max_batch_size=wl["batch"], device=local_rank, sampler=ca.SAMPLER_DEVICE,
                             world_size=world, rank=rank, sync_batch_norm=1)
     model = ca.Model(cfg)
@@ -209,7 +235,7 @@ def main():
             pool.append(ca.Batch(torch.from_numpy(words).to(dev), torch.from_numpy(labels).to(dev),
                                  torch.ones(B * w, dtype=torch.float32, device=dev),
                                  torch.ones(B, dtype=torch.float32, device=dev)))
-    lr = 1e-3
+    lr = wl["lr"]
 
     def sync_all():
         model.synchronize()
@@ -220,22 +246,30 @@ def main():
     for s in range(args.warmup):
         model.step(pool[s % len(pool)], lr)
     sync_all()
-    model.profile_enable(True)
+    def run_steps(n):
+        for s in range(n):
+            want = args.read_cost_every > 0 and (s + 1) % args.read_cost_every == 0
+            if args.gate_us:
+                model.debug_delay(args.gate_us)
+            if args.sequential:
+                model.compute_cost(pool[s % len(pool)])
+                model.compute_gradients()
+                model.update(lr)
+                if want:
+                    model.get_cost()
+            else:
+                model.step(pool[s % len(pool)], lr, want_cost=want)
+
+    # Timed region: HIP events around the roofline kernel only (two records per step). Events around every kernel
+    # group (~50 records per step) cost ≈5 % of the step, so the full per-kernel breakdown comes from a second,
+    # untimed pass over the same batches (--profile-all puts it back into the timed region).
+    ROOFLINE_KERNEL = "loss_fused"
+    model.profile_enable(not args.no_profile)
+    model.profile_select(None if args.profile_all else ROOFLINE_KERNEL)
     model.profile_reset()
     sync_all()
     t0 = time.perf_counter()
-    last_cost = None
-    for s in range(args.steps):
-        want = args.read_cost_every > 0 and (s + 1) % args.read_cost_every == 0
-        if args.sequential:
-            model.compute_cost(pool[s % len(pool)])
-            model.compute_gradients()
-            model.update(lr)
-            c = model.get_cost() if want else None
-        else:
-            c = model.step(pool[s % len(pool)], lr, want_cost=want)
-        if want:
-            last_cost = c
+    run_steps(args.steps)
     model.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
@@ -246,7 +280,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_cost = model.get_cost()
-    prof = model.profile()
+    prof_timed = model.profile()
+    prof = prof_timed
+    breakdown_steps = args.steps
+    if not args.no_profile and not args.profile_all:
+        breakdown_steps = min(args.steps, 20)
+        model.profile_select(None)
+        model.profile_reset()
+        run_steps(breakdown_steps)          # every rank takes part (the collectives are in the step)
+        sync_all()
+        prof = model.profile()
     model.profile_enable(False)
 
     if rank == 0:
@@ -258,7 +301,7 @@ def main():
             if n == 0:
                 continue
             avg = ms / n
-            ent = {"avg_ms": round(avg, 4), "launches_per_step": round(n / args.steps, 2)}
+            ent = {"avg_ms": round(avg, 4), "launches_per_step": round(n / breakdown_steps, 2)}
             ab = algorithmic_bytes(k, wl, method)
             if ab:
                 ent["algorithmic_GBps"] = round(ab / (avg * 1e-3) / 1e9, 1)
@@ -272,28 +315,32 @@ def main():
         for k in (() if args.sequential else ("chunk_pass_entities", "row_pass_entities", "gemm_bwd_T", "transform_update", "csr_entities", "csr_words")):
             if k in breakdown:
                 breakdown[k]["overlapped"] = True
-        dom = "loss_fused" if "loss_fused" in breakdown else next((k for k in breakdown if algorithmic_bytes(k, wl, method)), None)
+        dom = ROOFLINE_KERNEL if prof_timed.get(ROOFLINE_KERNEL, (0, 0))[1] else None
         roofline = None
         if dom:
             ab = algorithmic_bytes(dom, wl, method)
-            avg = breakdown[dom]["avg_ms"]
+            avg = round(prof_timed[dom][0] / prof_timed[dom][1], 4)      # HIP events inside the timed region
             ach = ab / (avg * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(dom)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg}
         out = {
-            "metric": "n-gram windows/sec (batch=51200, NVSM config)", "value": round(value, 1), "unit": "windows/s",
+            "metric": "n-gram windows/sec (batch=51200, NVSM config)" if args.config == "nvsm" and B == 51200
+                      else "n-gram windows/sec (--config %s, batch=%d)" % (args.config, B), "value": round(value, 1), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "NVSM synthetic |V|=%d |D|=%d d_word=300 d_doc=256 window=10 neg=16 batch=%d/GPU "
-                                   "hard_tanh+BN %s lambda=1e-2 lr=1e-3 %s word ids, inputs resident in HBM, device negative sampler"
-                                   % (wl["num_words"], wl["num_entities"], B, method,
+            "config": {"workload": "%s synthetic |V|=%d |D|=%d d_word=%d d_doc=256 window=10 neg=16 batch=%d/GPU "
+                                   "%s%s %s lambda=1e-2 lr=%g %s word ids, inputs resident in HBM, device negative sampler"
+                                   % ("NVSM" if wl["batch_norm"] else "LSE", wl["num_words"], wl["num_entities"], wl["word_dim"], B,
+                                      wl["nonlinearity"], "+BN" if wl["batch_norm"] else "", method, wl["lr"],
                                       "uniform" if args.uniform_words else "Zipf(1)"),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "update_method": method, "collectives": transport,
                        "inputs": "host" if args.host_batches else "hbm", "step": "sequential calls" if args.sequential else "fused nvsm_step"},
             "roofline": roofline,
             "kernel_breakdown": breakdown,
+            "kernel_breakdown_source": ("timed region" if args.profile_all else
+                                        "separate untimed pass of %d steps with events around every kernel group" % breakdown_steps),
             "final_cost": round(float(final_cost), 6),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -142,7 +142,12 @@ int nvsm_set_allreduce_callback(nvsm_model* m, nvsm_allreduce_fn fn, void* user)
     return guarded([&] { m->impl.set_allreduce_callback(fn, user); });
 }
 
+int nvsm_debug_delay(nvsm_model* m, int microseconds) { NVSM_REQUIRE(m); return guarded([&] { m->impl.debug_delay(microseconds); }); }
 int nvsm_profile_enable(nvsm_model* m, int enable) { NVSM_REQUIRE(m); return guarded([&] { m->impl.synchronize(); m->impl.prof.enabled = enable != 0; }); }
+int nvsm_profile_select(nvsm_model* m, const char* kernel) {
+    NVSM_REQUIRE(m);
+    return guarded([&] { m->impl.synchronize(); m->impl.prof.only = kernel ? kernel : ""; });
+}
 int nvsm_profile_reset(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.synchronize(); m->impl.prof.reset(); }); }
 int nvsm_profile_names(nvsm_model* m, char* buf, int64_t buf_bytes) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(buf);

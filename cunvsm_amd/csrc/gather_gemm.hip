@@ -497,6 +497,14 @@ void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(narrow_i64_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, src, dst, n);
 }
 
+__global__ void delay_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+void launch_delay(int microseconds, hipStream_t s) {
+    if (microseconds > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, static_cast<long long>(microseconds) * 100);
+}
+
 __global__ void iota_kernel(int* __restrict__ dst, int64_t n) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x)

@@ -43,6 +43,7 @@ void launch_colsum_finalize(const double* sums, int dim, float* out, hipStream_t
 void launch_sample_entities(const int64_t* labels, int64_t B, int R, int64_t num_entities, uint64_t seed,
                             uint64_t step, int* ids, hipStream_t s);
 void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, hipStream_t s);
+void launch_delay(int microseconds, hipStream_t s);      // one wave spinning on the 100 MHz wall clock (profiling aid)
 void launch_iota(int* dst, int64_t n, hipStream_t s);
 
 // ---- fused loss forward + backward (F7–F16, B1–B4; replaces cpp/objective.cu:159-305,354-425 and the

@@ -86,6 +86,7 @@ void rccl_unique_id(char id[128]) {
 // ---------------------------------------------------------------------------------------------
 void Profiler::begin(const char* name, hipStream_t s) {
     if (!enabled) return;
+    if (!only.empty() && only != name) return;
     Slot& sl = slots_[name];
     if (sl.used == sl.ev.size()) {
         hipEvent_t a, b;
@@ -261,6 +262,11 @@ void Model::synchronize() {
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(aux_stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(aux2_stream_));
+}
+
+void Model::debug_delay(int microseconds) {
+    NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    launch_delay(microseconds, stream_);
 }
 
 // ModelBase::initialize (cpp/model.cu:37-43) with init_matrix_glorot (include/cuNVSM/cuda_utils.h:35-56):

@@ -60,6 +60,7 @@ struct RcclApi;
 class Profiler {
  public:
     bool enabled = false;
+    std::string only;          // when not empty, only this kernel group is timed (two events per step instead of ~50)
     void begin(const char* name, hipStream_t s);
     void end(hipStream_t s);
     void reset();
@@ -116,6 +117,7 @@ class Model {
 
     void set_stream(hipStream_t s);
     void synchronize();
+    void debug_delay(int microseconds);
     void comm_init(const char id[128]);
     void set_allreduce_callback(nvsm_allreduce_fn fn, void* user) { ar_fn_ = fn; ar_user_ = user; }
 

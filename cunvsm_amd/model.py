@@ -196,6 +196,14 @@ class Model:
     def profile_enable(self, on=True):
         check(lib().nvsm_profile_enable(self._h, int(on)))
 
+    def profile_select(self, kernel=None):
+        """Time only this kernel group (None = all of them)."""
+        check(lib().nvsm_profile_select(self._h, kernel.encode() if kernel else None))
+
+    def debug_delay(self, microseconds):
+        """Spin kernel on the model's stream (profiling aid: lets the host queue a whole step ahead of the GPU)."""
+        check(lib().nvsm_debug_delay(self._h, int(microseconds)))
+
     def profile_reset(self):
         check(lib().nvsm_profile_reset(self._h))
 

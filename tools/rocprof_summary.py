@@ -62,8 +62,26 @@ def pmc(fetch_path, write_path, json_path=None):
         print("%-70s %7d %14.1f %16.2f %14.1f %10.2f %12.1f" % (k[:70], e[0], e[1], rd / 1e6, e[2], e[3] / 1e3, gbs))
 
 
+def timeline(path, marker="sample_entities_kernel", which=-2):
+    """Start offset / duration / queue of every kernel of one steady-state step (from one `marker` launch to the next)."""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    qcol = next((c for c in ("stream_id", "queue_id", "queue", "stream") if c in cols), None)
+    rows = db.execute("select name, start, end, %s from kernels order by start" % (qcol or "0")).fetchall()
+    marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    if len(marks) < 3:
+        print("columns:", cols); return
+    a, b = marks[which], marks[which + 1]
+    t0 = rows[a][1]
+    print("step of %.1f us (%s -> next %s); columns: start_us dur_us end_us queue kernel" % ((rows[b][1] - t0) / 1e3, marker, marker))
+    for name, st, en, q in rows[a:b]:
+        print("%9.1f %8.1f %9.1f  q%-4s %s" % ((st - t0) / 1e3, (en - st) / 1e3, (en - t0) / 1e3, q, short(name)[:70]))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], *(sys.argv[3:4]))
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)

@@ -214,7 +214,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, hipEventDisableTiming));
-    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_aux_done_}) NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_}) NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
 
     const int dw = cfg.word_repr_size, de = cfg.entity_repr_size, w = cfg.window_size;
     const int64_t N = B * R_;
@@ -227,7 +227,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     in_words_.alloc(B * w); in_labels_.alloc(B); in_ids64_.alloc(N); in_wwts_.alloc(B * w); in_instw_.alloc(B);
     widx_.alloc(B * w); ids_.alloc(N); iota_.alloc(std::max<int64_t>(B * w, N));
     launch_iota(iota_.p, static_cast<int64_t>(iota_.n), stream_);
-    phrase_.alloc(B * dw); pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
+    phrase_.alloc(B * dw); phrase_alt_.alloc(B * dw); phrase_p_ = phrase_.p; pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
     coef_.alloc(N); probs_.alloc(N); pp_.alloc(B); msq_w_.alloc(B); msq_parts_.alloc(B * gemm_rowsq_parts(dw));
     if (cfg.update_method == NVSM_ADAM && cfg.adam_mode <= NVSM_ADAM_SPARSE) U_.alloc(B * dw);
     if (cfg.update_method == NVSM_ADAGRAD) scale_w_.alloc(B);
@@ -246,7 +246,7 @@ Model::~Model() {
     if (ev_csr_ents_) (void)hipEventDestroy(ev_csr_ents_);
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
-    for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_aux_done_}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_}) if (e) (void)hipEventDestroy(e);
     if (comm_ && rccl_) rccl_->CommDestroy(comm_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
@@ -262,6 +262,20 @@ void Model::synchronize() {
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(aux_stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(aux2_stream_));
+    E_pending_ = T_pending_ = false;
+}
+
+// nvsm_step leaves the side streams' tails (documents update; dT GEMM + projection update) running when it returns, so
+// that they overlap the start of the next step; whoever next touches what a tail reads or writes joins it first.
+void Model::join_T() {
+    if (!T_pending_) return;
+    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_T_done_, 0));
+    T_pending_ = false;
+}
+void Model::join_E() {
+    if (!E_pending_) return;
+    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_E_done_, 0));
+    E_pending_ = false;
 }
 
 void Model::debug_delay(int microseconds) {
@@ -280,6 +294,7 @@ void Model::initialize(uint64_t seed) {
 
 void Model::initialize_from_rng_state() {
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    synchronize();
     if (device_seed_ == 0) device_seed_ = 1;
     auto glorot = [&](DevBuf<float>& dst, size_t rows, size_t cols) {
         std::vector<float> h(rows * cols);
@@ -428,14 +443,17 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     { PROF_ON("csr_words", aux2_stream_); build_csr(words_, widx_.p, B * w, aux2_stream_); }
     NVSM_HIP_CHECK(hipEventRecord(ev_csr_, aux2_stream_));
 
-    // F3: phrase representations (objective.cu:126-130)
-    { PROF("gather_mean_words"); launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, phrase_.p, stream_); }
+    // F3: phrase representations (objective.cu:126-130). The previous step's dT GEMM may still be reading its phrase
+    // matrix on the side stream: write the other one.
+    if (T_pending_) phrase_p_ = (phrase_p_ == phrase_.p) ? phrase_alt_.p : phrase_.p;
+    { PROF("gather_mean_words"); launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, phrase_p_, stream_); }
 
     // F5: projection GEMM  pre[B][de] = phrase[B][dw] · Tt[dw][de] (+ b when no BN)   (params.cu:417-421)
     // F6 (first half): with batch-norm the column sums Σx, Σx² of the projection ride in the GEMM epilogue
+    join_T();        // the previous step's projection update (after its dT GEMM, the last reader of dy)
     {
         PROF("gemm_fwd");
-        launch_gemm(0, 0, phrase_.p, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
+        launch_gemm(0, 0, phrase_p_, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
                     cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_,
                     cfg_.batch_normalization ? stats_fwd_ : nullptr);
     }
@@ -450,6 +468,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     }
 
     // F7–F16 + B1–B4: fused loss
+    join_E();        // the previous step's documents update: reads proj / coef, writes E
     {
         PROF("loss_fused");
         LossArgs a;
@@ -540,9 +559,9 @@ void Model::backward_T(hipStream_t strm) {
         const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
         const size_t stride = static_cast<size_t>(de) * dw;
         if (slabs == 1) {
-            launch_gemm(1, 0, phrase_.p, dy_.p, gT_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr, 1, 0, strm);
+            launch_gemm(1, 0, phrase_p_, dy_.p, gT_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr, 1, 0, strm);
         } else {
-            launch_gemm(1, 0, phrase_.p, dy_.p, gT_partial_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr,
+            launch_gemm(1, 0, phrase_p_, dy_.p, gT_partial_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr,
                         gemm_slabs_want_, stride, strm);
             launch_splitk_reduce(gT_partial_.p, slabs, stride, gT_.p, static_cast<int64_t>(stride), strm);
         }
@@ -744,22 +763,29 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     if (lr < 0.f || sl < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");
     const bool dp = cfg_.world_size > 1;      // collectives stay on ONE stream: with data parallelism only the documents update moves
     NVSM_HIP_CHECK(hipEventRecord(ev_loss_, stream_));
-    NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_loss_, 0));       // (the CSR builds are already queued there)
+    // side stream 1 (behind the documents CSR build): the documents update, HBM-bound — next to the MFMA-bound dx GEMM
+    // now, and free to run on next to the next step's projection GEMM; the next loss kernel joins it
+    NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_loss_, 0));
     update_entities(lr, sl, aux_stream_);
+    NVSM_HIP_CHECK(hipEventRecord(ev_E_done_, aux_stream_));
+    E_pending_ = true;
     backward_dx();
     if (dp) {
         backward_T(stream_);
     } else {
-        NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_dx_, 0));
-        backward_T(aux_stream_);
-        NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_bwdx_, 0));
-        update_transform(lr, sl, aux_stream_);
+        // side stream 2 (behind the words CSR build): the MFMA-bound dT GEMM next to the HBM-bound words update, then the
+        // projection update; the next projection GEMM joins it
+        // (started as soon as dx is final rather than after the dx GEMM: 1.084 vs 1.100 ms per step, interleaved A/B)
+        NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_dx_, 0));
+        backward_T(aux2_stream_);
+        NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_bwdx_, 0));      // the dx GEMM is the last reader of T
+        update_transform(lr, sl, aux2_stream_);
+        NVSM_HIP_CHECK(hipEventRecord(ev_T_done_, aux2_stream_));
+        T_pending_ = true;
     }
-    NVSM_HIP_CHECK(hipEventRecord(ev_aux_done_, aux_stream_));
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
     update_words(lr, sl);
     if (dp) update_transform(lr, sl, stream_);
-    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_aux_done_, 0));       // the next forward pass reads E, T and rewrites phrase
     NVSM_HIP_CHECK(hipGetLastError());
     have_grads_ = false;
     if (cost) *cost = get_cost();
@@ -801,14 +827,14 @@ void Model::get_param(const std::string& name, float* dst, int64_t count) {
     ParamRef r = find_param(name);
     if (!r.p) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown parameter: " + name);
     if (count != r.n) throw Error(NVSM_ERR_INVALID_ARGUMENT, "size mismatch for " + name);
-    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    synchronize();
     NVSM_HIP_CHECK(hipMemcpy(dst, r.p, count * sizeof(float), hipMemcpyDeviceToHost));
 }
 void Model::set_param(const std::string& name, const float* src, int64_t count) {
     ParamRef r = find_param(name);
     if (!r.p) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown parameter: " + name);
     if (count != r.n) throw Error(NVSM_ERR_INVALID_ARGUMENT, "size mismatch for " + name);
-    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    synchronize();
     NVSM_HIP_CHECK(hipMemcpy(r.p, src, count * sizeof(float), hipMemcpyHostToDevice));
 }
 
@@ -816,7 +842,7 @@ void Model::increment_param(const std::string& name, int64_t index, float delta)
     ParamRef r = find_param(name);
     if (!r.p) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown parameter: " + name);
     if (index < 0 || index >= r.n) throw Error(NVSM_ERR_INVALID_ARGUMENT, "parameter index out of range for " + name);
-    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    synchronize();
     float v = 0.f;
     NVSM_HIP_CHECK(hipMemcpy(&v, r.p + index, sizeof(float), hipMemcpyDeviceToHost));
     v += delta;
@@ -842,7 +868,7 @@ void Model::get_tensor(const std::string& name, float* dst, int64_t count) {
     if (needs_grads && !have_grads_) throw Error(NVSM_ERR_STATE, name + " requires compute_gradients (and no update since)");
     const float* src = nullptr;
     std::vector<float> tmp;
-    if (name == "phrase") src = phrase_.p;
+    if (name == "phrase") src = phrase_p_;
     else if (name == "pre") src = pre_.p;
     else if (name == "proj") src = proj_.p;
     else if (name == "probs") src = probs_.p;
@@ -859,12 +885,12 @@ void Model::get_tensor(const std::string& name, float* dst, int64_t count) {
         src = grad_entity_.p;
     } else if (name == "entity_ids") {
         std::vector<int> h(count);
-        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        synchronize();
         NVSM_HIP_CHECK(hipMemcpy(h.data(), ids_.p, count * sizeof(int), hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < count; ++i) dst[i] = static_cast<float>(h[i]);
         return;
     }
-    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    synchronize();
     NVSM_HIP_CHECK(hipMemcpy(dst, src, count * sizeof(float), hipMemcpyDeviceToHost));
 }
 

@@ -118,6 +118,9 @@ class Model {
     void set_stream(hipStream_t s);
     void synchronize();
     void debug_delay(int microseconds);
+    void join_T();
+    void join_E();
+    void join_aux() { join_T(); join_E(); }
     void comm_init(const char id[128]);
     void set_allreduce_callback(nvsm_allreduce_fn fn, void* user) { ar_fn_ = fn; ar_user_ = user; }
 
@@ -151,7 +154,7 @@ class Model {
     hipEvent_t ev_inputs_ = nullptr, ev_csr_ = nullptr;
     // fused step(): the documents update (HBM bound) and the dT GEMM (MFMA bound) run on the side stream next to the
     // dx GEMM and the words update on the main stream
-    hipEvent_t ev_loss_ = nullptr, ev_dx_ = nullptr, ev_bwdx_ = nullptr, ev_aux_done_ = nullptr;
+    hipEvent_t ev_loss_ = nullptr, ev_dx_ = nullptr, ev_bwdx_ = nullptr, ev_E_done_ = nullptr, ev_T_done_ = nullptr;
     std::minstd_rand0 rng_;           // include/cuNVSM/base.h:36
     uint64_t device_seed_ = 1, step_count_ = 0;
 
@@ -170,6 +173,9 @@ class Model {
     int64_t B_ = 0;                   // instances of the current batch (this rank)
 
     // intermediates
+    DevBuf<float> phrase_alt_;            // second phrase matrix (see compute_cost)
+    float* phrase_p_ = nullptr;           // the one the current forward result lives in
+    bool E_pending_ = false, T_pending_ = false;      // side-stream tails of the last nvsm_step not yet joined
     DevBuf<float> phrase_, pre_, proj_, dy_, gphrase_, coef_, probs_, pp_, msq_w_, msq_parts_, U_, scale_w_, grad_entity_;
     DevBuf<double> stats_;                   // [2 de | 1 + 2 de] = Σx Σx² | loss Σdy Σdy·x̂ — cleared by one memset per step
     double* stats_fwd_ = nullptr;

@@ -154,3 +154,34 @@ def test_fused_step_equals_separate_calls(problem, method):
         assert ca_ == cb_
     for n in PARAMS:
         np.testing.assert_array_equal(a.get_param(n), b.get_param(n))
+
+
+def test_back_to_back_fused_steps_equal_separate_calls(problem):
+    """nvsm_step returns with the documents update and the dT GEMM / projection update still running on the side
+    streams; the next step joins them only where it needs E and T (and writes the other phrase matrix meanwhile). Twelve
+    steps queued back to back over rotating device-resident batches — nothing waits on the host in between — must
+    leave exactly the tables that separate, fully ordered calls leave."""
+    import torch
+    params, _ = problem
+    rs = np.random.RandomState(77)
+    spec = dict(SPEC, update_method="sparse_adam")
+    a, b = gpu_model(spec, B, sampler=ca.SAMPLER_DEVICE), gpu_model(spec, B, sampler=ca.SAMPLER_DEVICE)
+    for m in (a, b):
+        m.initialize(5)                  # same device-sampler seed: the negatives of step s are the same on both
+        load_params(m, params, True)
+    dev = torch.device("cuda", 0)
+    host, devb = [], []
+    for _ in range(3):
+        words, ww, labels, iw, ids = full_batch(rs, weighted=True)
+        host.append(ca.Batch(words, labels, ww, iw))
+        devb.append(ca.Batch(torch.from_numpy(words).to(dev), torch.from_numpy(labels).to(dev),
+                             torch.from_numpy(ww).to(dev), torch.from_numpy(iw).to(dev)))
+    for s in range(12):
+        b.step(devb[s % 3], 1e-3)
+    for s in range(12):
+        a.compute_cost(host[s % 3])
+        a.compute_gradients()
+        a.update(1e-3)
+    for n in PARAMS:
+        np.testing.assert_array_equal(a.get_param(n), b.get_param(n))
+    assert a.get_cost() == b.get_cost()

@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_SO = os.path.join(_HERE, "libcunvsm_amd.so")
+_SO = os.environ.get("CUNVSM_AMD_LIB") or os.path.join(_HERE, "libcunvsm_amd.so")      # override: A/B of two builds
 _HEADER = os.path.join(_ROOT, "include", "cunvsm_amd.h")
 
 TANH, HARD_TANH = 0, 1

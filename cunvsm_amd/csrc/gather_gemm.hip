@@ -546,4 +546,37 @@ void launch_sample_entities(const int64_t* labels, int64_t B, int R, int64_t num
                            static_cast<uint64_t>(num_entities), seed, step, ids);
 }
 
+// One launch for the start of a step in device-sampler mode (instead of memset + narrow + sample: four launches with
+// their boundaries on the critical stream while nothing else is running): zero the step's statistics words, narrow
+// the int64 word ids and draw the document ids. Same per-element arithmetic as the kernels above.
+__global__ void step_prologue_kernel(const int64_t* __restrict__ words64, int* __restrict__ widx, int64_t nW,
+                                     const int64_t* __restrict__ labels, int64_t N, int R, uint64_t num_entities,
+                                     uint64_t seed, uint64_t step, int* __restrict__ ids,
+                                     double* __restrict__ stats, int nstats) {
+    const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    if (tid < nstats) stats[tid] = 0.0;
+    for (int64_t i = tid; i < nW; i += stride) widx[i] = static_cast<int>(words64[i]);
+    for (int64_t j = tid; j < N; j += stride) {
+        const int64_t b = j / R;
+        const int r = static_cast<int>(j - b * R);
+        if (r == 0) {
+            ids[j] = static_cast<int>(labels[b]);
+        } else {
+            const uint64_t h = splitmix64(splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + static_cast<uint64_t>(j));
+            ids[j] = static_cast<int>(__umul64hi(h, num_entities));
+        }
+    }
+}
+void launch_step_prologue(const int64_t* words64, int* widx, int64_t nW, const int64_t* labels, int64_t B, int R,
+                          int64_t num_entities, uint64_t seed, uint64_t step, int* ids, double* stats, int nstats,
+                          hipStream_t s) {
+    const int64_t N = B * R;
+    int grid = stream_grid(N > nW ? N : nW, 256);
+    const int need = (nstats + 255) / 256;
+    if (grid < need) grid = need;
+    hipLaunchKernelGGL(step_prologue_kernel, dim3(grid), dim3(256), 0, s, words64, widx, nW, labels, N, R,
+                       static_cast<uint64_t>(num_entities), seed, step, ids, stats, nstats);
+}
+
 }  // namespace cunvsm

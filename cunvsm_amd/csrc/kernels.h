@@ -31,18 +31,20 @@ int gemm_split_k_slabs(int K, int want);   // actual number of slabs launch_gemm
 void launch_splitk_reduce(const float* partial, int slabs, size_t stride, float* out, int64_t n, hipStream_t s);
 
 // ---- batch normalisation (F6, B5; replaces cuDNN per-activation BN, cpp/cudnn_utils.cu:82-183) --
-void launch_bn_finalize(const double* sums, int dim, double n_global, float eps, float* mean, float* inv_std, hipStream_t s);
-// dβ = Σdy, dγ = Σdy·x̂ (double sums [2][dim]) → floats + grad_bias
-void launch_bn_bwd_finalize(const double* sums, int dim, float* dbeta, float* dgamma, float* grad_bias, hipStream_t s);
+// (the forward statistics μ, 1/sqrt(σ²+ε) are evaluated inside the loss kernel from the GEMM's column sums: LossArgs)
+// dβ = Σdy, dγ = Σdy·x̂ (double sums [2][dim]) → floats, published together with grad_bias = dβ;
 // dx = invσ·(dy − (dβ + x̂·dγ)/N), in place on dy
-void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* inv_std, const float* dbeta,
-                  const float* dgamma, double n_global, int64_t rows, int dim, hipStream_t s);
+void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* inv_std, const double* sums, float* dbeta,
+                  float* dgamma, float* grad_bias, double n_global, int64_t rows, int dim, hipStream_t s);
 void launch_colsum_finalize(const double* sums, int dim, float* out, hipStream_t s);   // no-BN grad_bias = Σdy
 
 // ---- negative sampling on device (F2; same distribution as cpp/labels.cu:4-22) ----------------
 void launch_sample_entities(const int64_t* labels, int64_t B, int R, int64_t num_entities, uint64_t seed,
                             uint64_t step, int* ids, hipStream_t s);
 void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, hipStream_t s);
+void launch_step_prologue(const int64_t* words64, int* widx, int64_t nW, const int64_t* labels, int64_t B, int R,
+                          int64_t num_entities, uint64_t seed, uint64_t step, int* ids, double* stats, int nstats,
+                          hipStream_t s);
 void launch_delay(int microseconds, hipStream_t s);      // one wave spinning on the 100 MHz wall clock (profiling aid)
 void launch_iota(int* dst, int64_t n, hipStream_t s);
 
@@ -50,8 +52,11 @@ void launch_iota(int* dst, int64_t n, hipStream_t s);
 // nonlinearity at cpp/params.cu:430-446,474-491) ------------------------------------------------
 struct LossArgs {
     const float* pre;         // [B][de]  T·x (+b when !bn)
-    const float* bn_mean;     // [de] (bn)
-    const float* bn_inv_std;  // [de] (bn)
+    const double* bn_sums;    // [2][de] (bn) Σx, Σx² over the batch, from the projection GEMM's epilogue
+    double bn_n;              //      number of rows behind those sums (global batch with synchronised batch-norm)
+    float bn_eps;
+    float* bn_mean;           // [de] (bn) OUT: μ and 1/sqrt(σ²+ε), written by block 0 for the backward pass
+    float* bn_inv_std;        // [de] (bn) OUT
     const float* bias;        // [de] (bn: β)
     const float* E;           // [nD][de]
     const int* ids;           // [B*R]

@@ -10,33 +10,20 @@ namespace cunvsm {
 // The forward column sums Σx, Σx² come from the projection GEMM's epilogue (gather_gemm.hip): fp32 over a
 // 128-row tile, merged with native fp64 atomics, so var = E[x²] − E[x]² is formed in double.
 // =============================================================================================
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int dim, double n, float eps,
-                                   float* __restrict__ mean, float* __restrict__ inv_std) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= dim) return;
-    const double m = sums[c] / n;
-    double var = sums[dim + c] / n - m * m;            // biased variance
-    if (var < 0.0) var = 0.0;
-    mean[c] = static_cast<float>(m);
-    inv_std[c] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
-}
-
-void launch_bn_finalize(const double* sums, int dim, double n_global, float eps, float* mean, float* inv_std, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, s, sums, dim, n_global, eps, mean, inv_std);
-}
-
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int dim, float* __restrict__ dbeta,
-                                       float* __restrict__ dgamma, float* __restrict__ grad_bias) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= dim) return;
-    const float db = static_cast<float>(sums[c]);
-    dbeta[c] = db;
-    dgamma[c] = static_cast<float>(sums[dim + c]);
-    grad_bias[c] = db;                                 // ∂β = Σdy; ∂γ is computed and dropped (cudnn_utils.cu:173)
-}
-
-void launch_bn_bwd_finalize(const double* sums, int dim, float* dbeta, float* dgamma, float* grad_bias, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, s, sums, dim, dbeta, dgamma, grad_bias);
+// Batch statistics of V columns from the fp64 column sums Σx, Σx² the projection GEMM left (cudnn_utils.cu:107-124:
+// biased variance, 1/sqrt(σ² + ε)). Every wave of the loss kernel evaluates this for its own columns — a few dozen
+// fp64 operations — instead of a separate one-block launch on the critical stream between the GEMM and the loss.
+template <int V>
+__device__ __forceinline__ void bn_stats_from_sums(const double* __restrict__ sums, int dim, int c, double n, float eps,
+                                                   float (&mean)[V], float (&inv_std)[V]) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const double m = sums[c + i] / n;
+        double var = sums[dim + c + i] / n - m * m;            // biased variance
+        if (var < 0.0) var = 0.0;
+        mean[i] = static_cast<float>(m);
+        inv_std[i] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    }
 }
 
 __global__ void colsum_finalize_kernel(const double* __restrict__ sums, int dim, float* __restrict__ out) {
@@ -52,7 +39,8 @@ void launch_colsum_finalize(const double* sums, int dim, float* out, hipStream_t
 template <int V>
 __global__ __launch_bounds__(256) void bn_dx_kernel(float* __restrict__ dy, const float* __restrict__ pre,
                                                     const float* __restrict__ mean, const float* __restrict__ inv_std,
-                                                    const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                    const double* __restrict__ sums, float* __restrict__ dbeta,
+                                                    float* __restrict__ dgamma, float* __restrict__ grad_bias,
                                                     float inv_n, uint32_t total, uint32_t nvec, int dim) {
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
         const uint32_t b = q / nvec;
@@ -63,8 +51,16 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(float* __restrict__ dy, cons
         ldv<V>(pre + off, x);
         ldv<V>(mean + c, mu);
         ldv<V>(inv_std + c, is);
-        ldv<V>(dbeta + c, db);
-        ldv<V>(dgamma + c, dg);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {              // dβ = Σdy, dγ = Σdy·x̂ as floats (cudnn_utils.cu:158-173)
+            db[i] = static_cast<float>(sums[c + i]);
+            dg[i] = static_cast<float>(sums[dim + c + i]);
+        }
+        if (b == 0) {                              // ∂β = Σdy is the bias gradient; ∂γ is computed and dropped (:173)
+            stv<V>(dbeta + c, db);
+            stv<V>(dgamma + c, dg);
+            stv<V>(grad_bias + c, db);
+        }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const float xhat = (x[i] - mu[i]) * is[i];
@@ -74,18 +70,18 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(float* __restrict__ dy, cons
     }
 }
 
-void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* inv_std, const float* dbeta,
-                  const float* dgamma, double n_global, int64_t rows, int dim, hipStream_t s) {
+void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* inv_std, const double* sums, float* dbeta,
+                  float* dgamma, float* grad_bias, double n_global, int64_t rows, int dim, hipStream_t s) {
     if (rows <= 0) return;
     const float inv_n = static_cast<float>(1.0 / n_global);
     if (dim % 4 == 0) {
         const uint32_t nvec = dim / 4, total = static_cast<uint32_t>(rows * nvec);
         hipLaunchKernelGGL(bn_dx_kernel<4>, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, pre, mean, inv_std,
-                           dbeta, dgamma, inv_n, total, nvec, dim);
+                           sums, dbeta, dgamma, grad_bias, inv_n, total, nvec, dim);
     } else {
         const uint32_t nvec = dim, total = static_cast<uint32_t>(rows * nvec);
         hipLaunchKernelGGL(bn_dx_kernel<1>, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, pre, mean, inv_std,
-                           dbeta, dgamma, inv_n, total, nvec, dim);
+                           sums, dbeta, dgamma, grad_bias, inv_n, total, nvec, dim);
     }
 }
 
@@ -124,8 +120,8 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 #pragma unroll
         for (int i = 0; i < V; ++i) { sdy[it][i] = 0.f; sdyx[it][i] = 0.f; mu[it][i] = 0.f; is[it][i] = 1.f; beta[it][i] = 0.f; }
         if (a.bn && valid[it]) {
-            ldv<V>(a.bn_mean + c, mu[it]);
-            ldv<V>(a.bn_inv_std + c, is[it]);
+            bn_stats_from_sums<V>(a.bn_sums, de, c, a.bn_n, a.bn_eps, mu[it], is[it]);
+            if (blockIdx.x == 0 && wid == 0) { stv<V>(a.bn_mean + c, mu[it]); stv<V>(a.bn_inv_std + c, is[it]); }   // for bn_dx
             ldv<V>(a.bias + c, beta[it]);
         }
     }
@@ -298,8 +294,8 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
     float sdy[4] = {0, 0, 0, 0}, sdyx[4] = {0, 0, 0, 0};
     float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1}, beta[4] = {0, 0, 0, 0};
     if (a.bn) {
-        ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.bn_mean) + coff), mu);
-        ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.bn_inv_std) + coff), is);
+        bn_stats_from_sums<4>(a.bn_sums, de, valid ? c : 0, a.bn_n, a.bn_eps, mu, is);
+        if (blockIdx.x == 0 && wid == 0 && valid) { stv<4>(a.bn_mean + c, mu); stv<4>(a.bn_inv_std + c, is); }       // for bn_dx
         ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.bias) + coff), beta);
     }
     float lane_loss = 0.f;

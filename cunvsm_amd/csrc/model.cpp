@@ -374,7 +374,10 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     have_forward_ = have_grads_ = false;
     cost_valid_ = false;
 
-    NVSM_HIP_CHECK(hipMemsetAsync(stats_.p, 0, stats_.n * sizeof(double), stream_));   // Σx Σx² | loss Σdy Σdy·x̂
+    // device-sampler mode: zeroing the statistics, narrowing the word ids and drawing the document ids are one launch
+    const bool fused_prologue = !entity_ids && cfg_.sampler != NVSM_SAMPLER_HOST_MINSTD;
+    if (!fused_prologue)
+        NVSM_HIP_CHECK(hipMemsetAsync(stats_.p, 0, stats_.n * sizeof(double), stream_));   // Σx Σx² | loss Σdy Σdy·x̂
 
     // F1: batch → HBM (objective.cu:36-61)
     const int64_t* words_dev;
@@ -400,7 +403,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
                 instw_ = in_instw_.p;
             }
         }
-        launch_narrow_i64(words_dev, widx_.p, B * w, stream_);
+        if (!fused_prologue) launch_narrow_i64(words_dev, widx_.p, B * w, stream_);
     }
 
     // F2: target + negative document ids (objective.cu:63-89 → labels.cu:4-22)
@@ -427,7 +430,8 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             NVSM_HIP_CHECK(hipStreamSynchronize(stream_));           // host_ids_ is pageable and reused next step
             launch_narrow_i64(in_ids64_.p, ids_.p, N, stream_);
         } else {
-            launch_sample_entities(labels_dev_, B, R_, cfg_.num_entities, device_seed_ + 0x9E37u * cfg_.rank, step_count_, ids_.p, stream_);
+            launch_step_prologue(words_dev, widx_.p, B * w, labels_dev_, B, R_, cfg_.num_entities,
+                                 device_seed_ + 0x9E37u * cfg_.rank, step_count_, ids_.p, stats_.p, static_cast<int>(stats_.n), stream_);
         }
     }
     ++step_count_;
@@ -464,7 +468,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     if (cfg_.batch_normalization) {
         PROF("bn_stats");
         if (cfg_.world_size > 1 && cfg_.sync_batch_norm) allreduce_f64(stats_fwd_, 2 * de);
-        launch_bn_finalize(stats_fwd_, de, bn_n, 1e-4f, bn_mean_.p, bn_inv_std_.p, stream_);
+        // (μ and 1/sqrt(σ²+ε) themselves are evaluated by the loss kernel from these sums)
     }
 
     // F7–F16 + B1–B4: fused loss
@@ -473,6 +477,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         PROF("loss_fused");
         LossArgs a;
         a.pre = pre_.p; a.bn_mean = bn_mean_.p; a.bn_inv_std = bn_inv_std_.p; a.bias = b_.p;
+        a.bn_sums = stats_fwd_; a.bn_n = bn_n; a.bn_eps = 1e-4f;
         a.E = ents_.P.p; a.ids = ids_.p; a.inst_w = instw_;
         a.proj = proj_.p; a.dy = dy_.p; a.coef = coef_.p; a.probs = probs_.p; a.pp = pp_.p;
         a.loss_acc = stats_bwd_; a.colstats = stats_bwd_ + 1;
@@ -519,11 +524,9 @@ void Model::backward_dx() {
         if (cfg_.batch_normalization) {
             if (dp && cfg_.sync_batch_norm) {
                 allreduce_f64(stats_bwd_, 1 + 2 * de);
-                launch_bn_bwd_finalize(stats_bwd_ + 1, de, dbeta_.p, dgamma_.p, gb_.p, stream_);
-                launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, dbeta_.p, dgamma_.p, B_global, B, de, stream_);
+                launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, stats_bwd_ + 1, dbeta_.p, dgamma_.p, gb_.p, B_global, B, de, stream_);
             } else {
-                launch_bn_bwd_finalize(stats_bwd_ + 1, de, dbeta_.p, dgamma_.p, gb_.p, stream_);
-                launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, dbeta_.p, dgamma_.p, static_cast<double>(B), B, de, stream_);
+                launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, stats_bwd_ + 1, dbeta_.p, dgamma_.p, gb_.p, static_cast<double>(B), B, de, stream_);
                 if (dp) { allreduce_f64(stats_bwd_, 1 + 2 * de); launch_colsum_finalize(stats_bwd_ + 1, de, gb_.p, stream_); }
             }
         } else {

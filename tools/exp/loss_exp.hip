@@ -354,7 +354,19 @@ int main(int argc, char** argv) {
     fill_ids<<<2048, 256>>>(ids, B * R, 7, (int)nD);
     CK(hipDeviceSynchronize());
 
+    // the product kernel derives mean / inv_std from the fp64 column sums: build sums that give the values above
+    double* bn_sums; CK(hipMalloc(&bn_sums, 2 * de * 8));
+    {
+        std::vector<float> hm(de), hi(de); std::vector<double> hs(2 * de);
+        CK(hipMemcpy(hm.data(), mean, de * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hi.data(), istd, de * 4, hipMemcpyDeviceToHost));
+        for (int c = 0; c < de; ++c) {
+            const double m = hm[c], var = 1.0 / ((double)hi[c] * hi[c]) - 1e-4;
+            hs[c] = m * B; hs[de + c] = (var + m * m) * B;
+        }
+        CK(hipMemcpy(bn_sums, hs.data(), 2 * de * 8, hipMemcpyHostToDevice));
+    }
     LossArgs a{};
+    a.bn_sums = bn_sums; a.bn_n = (double)B; a.bn_eps = 1e-4f;
     a.pre = pre; a.bn_mean = mean; a.bn_inv_std = istd; a.bias = bias; a.E = E; a.ids = ids; a.inst_w = nullptr;
     a.proj = proj; a.dy = dy; a.coef = coef; a.probs = probs; a.pp = pp; a.loss_acc = stats; a.colstats = stats + 1;
     a.B = B; a.de = de; a.R = R; a.k = k; a.bn = 1; a.nonlinearity = 1; a.rebalance = 1;

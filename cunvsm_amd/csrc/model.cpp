@@ -63,7 +63,23 @@ void rccl_selftest(int device) {
     NVSM_HIP_CHECK(hipMemcpy(d.p, hd.data(), n * sizeof(double), hipMemcpyHostToDevice));
     int rc = api->AllReduce(f.p, f.p, n, RcclApi::kFloat32, RcclApi::kSum, comm, s);
     if (rc == 0) rc = api->AllReduce(d.p, d.p, n, RcclApi::kFloat64, RcclApi::kSum, comm, s);
+    // as nvsm_step does with world_size > 1: the next collective of the same communicator on a second, lower-priority
+    // stream ordered behind the first by an event, then back on the first stream
+    hipStream_t s2; hipEvent_t e1, e2;
+    int lo = 0, hi = 0;
+    NVSM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    NVSM_HIP_CHECK(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, lo));
+    NVSM_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    NVSM_HIP_CHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    NVSM_HIP_CHECK(hipEventRecord(e1, s));
+    NVSM_HIP_CHECK(hipStreamWaitEvent(s2, e1, 0));
+    if (rc == 0) rc = api->AllReduce(f.p, f.p, n, RcclApi::kFloat32, RcclApi::kSum, comm, s2);
+    NVSM_HIP_CHECK(hipEventRecord(e2, s2));
+    NVSM_HIP_CHECK(hipStreamWaitEvent(s, e2, 0));
+    if (rc == 0) rc = api->AllReduce(d.p, d.p, n, RcclApi::kFloat64, RcclApi::kSum, comm, s);
     NVSM_HIP_CHECK(hipStreamSynchronize(s));
+    NVSM_HIP_CHECK(hipStreamSynchronize(s2));
+    (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipStreamDestroy(s2);
     std::vector<float> rf(n); std::vector<double> rd(n);
     NVSM_HIP_CHECK(hipMemcpy(rf.data(), f.p, n * sizeof(float), hipMemcpyDeviceToHost));
     NVSM_HIP_CHECK(hipMemcpy(rd.data(), d.p, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -764,7 +780,13 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     compute_cost(batch, entity_ids);
     const float sl = scaled_regularization_lambda();
     if (lr < 0.f || sl < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");
-    const bool dp = cfg_.world_size > 1;      // collectives stay on ONE stream: with data parallelism only the documents update moves
+    // Data parallel: the dT GEMM, the all-reduce of the projection gradient and the projection update ride on side stream 2
+    // exactly as the single-GPU tail does. The three collectives of a step stay totally ordered on every rank by the
+    // events below (BN forward sums → BN backward sums on the main stream → [ev_dx] gradient on side stream 2 →
+    // [join_T] next step's BN forward sums), so one communicator serves both streams. NVSM_DP_T_ON_MAIN=1 keeps all
+    // collectives on the main stream (dT GEMM + all-reduce + update no longer overlap the words update).
+    static const bool t_on_main = std::getenv("NVSM_DP_T_ON_MAIN") != nullptr;
+    const bool dp = cfg_.world_size > 1 && t_on_main;
     NVSM_HIP_CHECK(hipEventRecord(ev_loss_, stream_));
     // side stream 1 (behind the documents CSR build): the documents update, HBM-bound — next to the MFMA-bound dx GEMM
     // now, and free to run on next to the next step's projection GEMM; the next loss kernel joins it

@@ -148,8 +148,11 @@ def _worker_gpu_step(rank, port, spec, B, out_dir):
     m = gpu_model(spec, B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0)
     load_params(m, params, True)
     m.set_allreduce_callback(dp.torch_allreduce(dist))
-    costs = [m.step(ca.Batch(w, wl, wwt, wi), 0.05, entity_ids=wid, want_cost=True) for _ in range(2)]
-    np.savez(os.path.join(out_dir, "step_rank%d.npz" % rank), cost=np.array(costs), T=m.get_param("word_entity_mapping-transform"),
+    costs = [m.step(ca.Batch(w, wl, wwt, wi), 0.05, entity_ids=wid, want_cost=True)]
+    T_after_1 = m.get_param("word_entity_mapping-transform")
+    for _ in range(3):
+        m.step(ca.Batch(w, wl, wwt, wi), 0.05, entity_ids=wid)
+    np.savez(os.path.join(out_dir, "step_rank%d.npz" % rank), cost=np.array(costs), T1=T_after_1, T=m.get_param("word_entity_mapping-transform"),
              b=m.get_param("word_entity_mapping-bias"), E=m.get_param("entity_representations-representations"))
     dist.barrier()
     dist.destroy_process_group()
@@ -158,9 +161,10 @@ def _worker_gpu_step(rank, port, spec, B, out_dir):
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["sgd", "sparse_adam"])
 def test_dp_fused_step(tmp_path, method):
-    """nvsm_step under data parallelism (documents update on the side stream, every collective on the main stream): after
-    the first step the replicated projection is identical on both ranks and equal to the single-GPU step on the whole
-    batch; the loss of the first step is the global loss."""
+    """nvsm_step under data parallelism (documents update on side stream 1; dT GEMM, the all-reduce of the projection
+    gradient and the projection update on side stream 2, joined by the next step): after the first step the replicated
+    projection is identical on both ranks and equal to the single-GPU step on the whole batch; the loss of the first
+    step is the global loss; further steps queued without reading the loss keep the replicas in lock-step."""
     import torch.multiprocessing as mp
     import cunvsm_amd as ca
     from tests.helpers import gpu_model, load_params, rel_err
@@ -178,5 +182,10 @@ def test_dp_fused_step(tmp_path, method):
     # replicas of the dense parameters stay in lock-step (both steps) ...
     np.testing.assert_array_equal(r[0]["T"], r[1]["T"])
     np.testing.assert_array_equal(r[0]["b"], r[1]["b"])
+    # ... the first data-parallel step moves the projection as the single-GPU step on the whole batch does
+    # (Adam divides by |g|: compare against the size of the step, not of T)
+    np.testing.assert_array_equal(r[0]["T1"], r[1]["T1"])
+    step = np.linalg.norm(T1 - params["word_entity_mapping-transform"])
+    assert np.linalg.norm(r[0]["T1"] - T1) <= (2e-2 if method.endswith("adam") else 1e-4) * step
     # ... and the embedding tables are rank-local ("sparse rows stay GPU-local"): they differ between the ranks
     assert not np.array_equal(r[0]["E"], r[1]["E"])

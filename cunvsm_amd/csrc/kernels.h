@@ -99,6 +99,8 @@ struct Csr {
     int* chunk2_base;     // [rows]  first level-2 chunk of a very long row
     int* chunk2_desc;     // [max_chunks2][2] first, last (exclusive) level-1 chunk
     int* num_chunks;      // [2]  level-1 / level-2 chunks in use
+    int* num_touched;     // [1]  rows with at least one entry (num_chunks + 2)
+    int* touched;         // [min(rows, max entries)] those rows, in no particular order (rows are independent)
     float* partial;       // [max_chunks][dim]
     float* partial_q;     // [max_chunks]
     float* partial2;      // [max_chunks2][dim]
@@ -110,6 +112,7 @@ struct Csr {
 constexpr int kChunk = 64;    // entries per level-1 chunk of a long row
 constexpr int kFan = 64;      // level-1 partials per level-2 chunk
 void launch_csr_build(const Csr& c, hipStream_t s);   // bounds + long-row chunk list, from sorted_key
+bool row_pass_split(const Csr& c);                    // rows >= entries: touched-row list + streaming pass over the rest
 
 // ---- row passes: gather Σ coef·X[src] per table row, then the optimiser's row-local formula --------
 enum RowKind {
@@ -140,6 +143,7 @@ struct RowPassArgs {
     int dense;                 // visit rows without entries (decay / dense Adam)
     int max_blocks;            // 0 = one thread group per row; > 0 = cap the grid (rows are grid-strided) so that a kernel
                                //   running concurrently on another stream finds free registers on every CU
+    int touched_only;          // set by launch_row_pass: visit the rows of Csr::touched only (see row_pass_split)
 };
 void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
 void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);

@@ -173,7 +173,8 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
         else { t.sc[0].alloc(rows, true); t.sc[1].alloc(rows, true); }
     }
     t.sorted_key.alloc(max_entries); t.sorted_entry.alloc(max_entries);
-    t.csr_zeroed.alloc(2 * rows + 2, true); t.chunk_base.alloc(rows, true);
+    t.csr_zeroed.alloc(2 * rows + 3, true); t.chunk_base.alloc(rows, true);
+    t.touched.alloc(std::min<int64_t>(rows, max_entries));
     t.max_chunks = static_cast<int>(2 * max_entries / kChunk + 2);
     t.chunk_desc.alloc(static_cast<size_t>(t.max_chunks) * 3, true);
     t.partial.alloc(static_cast<size_t>(t.max_chunks) * dim);
@@ -624,6 +625,7 @@ Csr Model::csr_of(TableState& t, int64_t n) {
     c.sorted_key = t.sorted_key.p; c.sorted_entry = t.sorted_entry.p;
     c.row_begin = t.csr_zeroed.p; c.row_end = t.csr_zeroed.p + t.rows; c.chunk_base = t.chunk_base.p;
     c.chunk_desc = t.chunk_desc.p; c.num_chunks = t.csr_zeroed.p + 2 * t.rows;
+    c.num_touched = c.num_chunks + 2; c.touched = t.touched.p;
     c.partial = t.partial.p; c.partial_q = t.partial_q.p;
     c.chunk2_base = t.chunk2_base.p; c.chunk2_desc = t.chunk2_desc.p;
     c.partial2 = t.partial2.p; c.partial2_q = t.partial2_q.p;

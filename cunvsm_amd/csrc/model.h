@@ -81,6 +81,7 @@ struct TableState {           // one embedding table + its optimiser state + its
     uint64_t t = 1;           // Adam step counter (cpp/updates_adam.cu:130)
     // CSR workspace
     DevBuf<int> sorted_key, sorted_entry, chunk_base, chunk_desc, chunk2_base, chunk2_desc;
+    DevBuf<int> touched;      // rows with entries (Csr::touched)
     DevBuf<int> csr_zeroed;   // [row_begin (rows) | row_end (rows) | num_chunks (2)]: one memset per step clears all three
     DevBuf<float> partial, partial_q, partial2, partial2_q;
     DevBuf<char> sort_temp;

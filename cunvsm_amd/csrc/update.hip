@@ -17,11 +17,14 @@ namespace cunvsm {
 // CSR construction from the sorted (row key, entry) pairs
 // =============================================================================================
 __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* __restrict__ row_begin,
-                                  int* __restrict__ row_end) {
+                                  int* __restrict__ row_end, int* __restrict__ touched, int* __restrict__ num_touched) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int k = key[i];
-        if (i == 0 || key[i - 1] != k) row_begin[k] = static_cast<int>(i);
+        if (i == 0 || key[i - 1] != k) {
+            row_begin[k] = static_cast<int>(i);
+            if (touched) touched[atomicAdd(num_touched, 1)] = k;      // list order is irrelevant: rows are independent
+        }
         if (i == n - 1 || key[i + 1] != k) row_end[k] = static_cast<int>(i + 1);
     }
 }
@@ -76,10 +79,11 @@ __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, co
 }
 
 void launch_csr_build(const Csr& c, hipStream_t s) {
-    // row_begin | row_end | num_chunks are one allocation (model.cpp): a single memset clears all three
-    (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * (2 * c.rows + 2), s);
+    // row_begin | row_end | num_chunks | num_touched are one allocation (model.cpp): a single memset clears them all
+    (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * (2 * c.rows + 3), s);
     if (c.n > 0)
-        hipLaunchKernelGGL(csr_bounds_kernel, dim3(stream_grid(c.n, 256)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end);
+        hipLaunchKernelGGL(csr_bounds_kernel, dim3(stream_grid(c.n, 256)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end,
+                           row_pass_split(c) ? c.touched : nullptr, c.num_touched);
     hipLaunchKernelGGL(csr_chunks_kernel, dim3(stream_grid(c.rows, 256)), dim3(256), 0, s, c.row_begin, c.row_end, c.rows,
                        c.chunk_base, c.chunk2_base, c.num_chunks);
     if (c.n > 0)
@@ -215,31 +219,109 @@ __global__ __launch_bounds__(256) void chunk2_pass_kernel(Csr c, int dim, int G,
     }
 }
 
+// The optimiser's row-local formula for columns [col, col+V) of one table row, given the row's gradient sum g, its
+// scalar q (mean-of-squares sum) and entry count. Shared by the row pass and by the untouched-rows pass below so that
+// a row without entries gets bit for bit the same arithmetic (g = 0, q = 0, cnt = 0) from either.
+template <int V, int KIND>
+struct RowKindTraits {
+    static constexpr bool kUsesM = (KIND == ROW_ADAM_MV || KIND == ROW_ADAM_SPARSE_ENT || KIND == ROW_ADAM_DENSE || KIND == ROW_ADAM_FULL);
+    static constexpr bool kUsesP = (KIND == ROW_SGD || KIND == ROW_ADAGRAD_ENT || KIND == ROW_ADAM_SPARSE_ENT || KIND == ROW_ADAM_DENSE || KIND == ROW_ADAM_FULL);
+};
+
+template <int V, int KIND>
+__device__ __forceinline__ void load_row_state(const RowPassArgs& a, size_t off, int cnt, bool p_always,
+                                               float (&p)[V], float (&m)[V], float (&v)[V]) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) { p[i] = 0.f; m[i] = 0.f; v[i] = 0.f; }
+    if (RowKindTraits<V, KIND>::kUsesM) ldv<V>(a.m + off, m);
+    if (KIND == ROW_ADAM_FULL) ldv<V>(a.v + off, v);
+    if (RowKindTraits<V, KIND>::kUsesP) {
+        if (p_always) ldv<V>(a.P + off, p);
+        else if (cnt != 0) ldv<V>(a.P + off, p);
+    }
+}
+
+template <int V, int KIND>
+__device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t row, bool first_col, size_t off, int cnt,
+                                                  bool touch_p, const float (&g)[V], float q, float (&p)[V],
+                                                  float (&m)[V], float (&v)[V]) {
+    if (KIND == ROW_SGD) {
+        if (!touch_p) return;
+#pragma unroll
+        for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * g[i];
+        stv<V>(a.P + off, p);
+    } else if (KIND == ROW_ADAGRAD_ENT) {
+        const float acc = a.sc_in[row] + q;
+        if (first_col) a.sc_out[row] = acc;
+        if (!touch_p) return;
+        const float sc = 1.f / sqrtf(acc + a.eps);
+#pragma unroll
+        for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * (g[i] * sc);
+        stv<V>(a.P + off, p);
+    } else if (KIND == ROW_SCALAR_ACC) {
+        if (first_col) a.sc_out[row] = a.sc_in[row] + q;
+    } else if (KIND == ROW_ADAM_FULL) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float mn = m[i] * a.s_m + a.one_m_b1 * g[i];      // updates_adam.cu:196-200
+            mn += (-a.c_reg) * p[i];                         // :203-213
+            float ag = g[i] + (-a.lambda) * p[i];            // :264-273
+            ag = ag * ag;
+            const float vn = v[i] * a.s_v + ag * a.one_m_b2; // :277-281
+            m[i] = mn;
+            v[i] = vn;
+            p[i] = p[i] + ((mn / (sqrtf(vn) + a.eps)) * a.bc) * a.lr;   // :312-328 (λ = 0)
+        }
+        stv<V>(a.m + off, m);
+        stv<V>(a.v + off, v);
+        stv<V>(a.P + off, p);
+    } else {
+        // ROW_ADAM_MV / ROW_ADAM_SPARSE_ENT / ROW_ADAM_DENSE: v is one scalar per row (updates_adam.cu:126).
+#pragma unroll
+        for (int i = 0; i < V; ++i) m[i] = m[i] * a.s_m + a.one_m_b1 * g[i];
+        stv<V>(a.m + off, m);
+        const float vn = a.sc_in[row] * a.s_v + a.one_m_b2 * q;
+        if (first_col) a.sc_out[row] = vn;
+        if (KIND == ROW_ADAM_SPARSE_ENT) {
+            if (!touch_p) return;
+            const float denom = sqrtf(vn) + a.eps;
+            const float fc = static_cast<float>(cnt);
+#pragma unroll
+            for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + (a.lr * fc) * ((a.bc * m[i]) / denom);
+            stv<V>(a.P + off, p);
+        } else if (KIND == ROW_ADAM_DENSE) {
+            const float denom = sqrtf(vn) + a.eps;
+#pragma unroll
+            for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + ((m[i] / denom) * a.bc) * a.lr;
+            stv<V>(a.P + off, p);
+        }
+    }
+}
+
 template <int V, int TABLE, int KIND>
 __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int G, int nvec) {
     constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
-    constexpr bool USES_M = (KIND == ROW_ADAM_MV || KIND == ROW_ADAM_SPARSE_ENT || KIND == ROW_ADAM_DENSE || KIND == ROW_ADAM_FULL);
-    constexpr bool USES_P = (KIND == ROW_SGD || KIND == ROW_ADAGRAD_ENT || KIND == ROW_ADAM_SPARSE_ENT || KIND == ROW_ADAM_DENSE || KIND == ROW_ADAM_FULL);
     const int rpb = blockDim.x / G;
     const int group = threadIdx.x / G, lig = threadIdx.x - group * G;
     if (group >= rpb) return;
     const int dim = a.dim;
-    for (int64_t row = static_cast<int64_t>(blockIdx.x) * rpb + group; row < c.rows;
-         row += static_cast<int64_t>(gridDim.x) * rpb) {
+    // touched_only: this launch owns the rows of Csr::touched (the rows without entries get their dense decay from
+    // untouched_rows_kernel); otherwise every table row
+    const int64_t limit = a.touched_only ? static_cast<int64_t>(*c.num_touched) : c.rows;
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * rpb + group; r < limit;
+         r += static_cast<int64_t>(gridDim.x) * rpb) {
+        const int64_t row = a.touched_only ? static_cast<int64_t>(c.touched[r]) : r;
         const int begin = c.row_begin[row], end = c.row_end[row];
         const int cnt = end - begin;
         if (cnt == 0 && !a.dense) continue;
-        const bool touch_p = !(cnt == 0 && a.decay == 1.f);      // sparse kinds leave untouched rows alone when λ = 0
+        const bool p_always = (a.decay != 1.f) || KIND == ROW_ADAM_FULL || KIND == ROW_ADAM_DENSE;
+        const bool touch_p = p_always || cnt != 0;              // sparse kinds leave untouched rows alone when λ = 0
         for (int cv = lig; cv < nvec; cv += G) {
             const int col = cv * V;
             const size_t off = static_cast<size_t>(row) * dim + col;
             // the row's own state does not depend on the entries: fetch it first so it is in flight during the gather
             float p[V], m[V], v[V];
-#pragma unroll
-            for (int i = 0; i < V; ++i) { p[i] = 0.f; m[i] = 0.f; v[i] = 0.f; }
-            if (USES_M) ldv<V>(a.m + off, m);
-            if (KIND == ROW_ADAM_FULL) ldv<V>(a.v + off, v);
-            if (USES_P && (touch_p || KIND == ROW_ADAM_FULL || KIND == ROW_ADAM_DENSE)) ldv<V>(a.P + off, p);
+            load_row_state<V, KIND>(a, off, cnt, p_always, p, m, v);
 
             float g[V];
 #pragma unroll
@@ -252,61 +334,50 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
             } else if (cnt > 0) {
                 accumulate_segment<V, TABLE, VEC>(a, c.sorted_entry, begin, end, col, g, q);
             }
-
-            if (KIND == ROW_SGD) {
-                if (!touch_p) continue;
-#pragma unroll
-                for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * g[i];
-                stv<V>(a.P + off, p);
-            } else if (KIND == ROW_ADAGRAD_ENT) {
-                const float acc = a.sc_in[row] + q;
-                if (cv == 0) a.sc_out[row] = acc;
-                if (!touch_p) continue;
-                const float sc = 1.f / sqrtf(acc + a.eps);
-#pragma unroll
-                for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * (g[i] * sc);
-                stv<V>(a.P + off, p);
-            } else if (KIND == ROW_SCALAR_ACC) {
-                if (cv == 0) a.sc_out[row] = a.sc_in[row] + q;
-            } else if (KIND == ROW_ADAM_FULL) {
-#pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    float mn = m[i] * a.s_m + a.one_m_b1 * g[i];      // updates_adam.cu:196-200
-                    mn += (-a.c_reg) * p[i];                         // :203-213
-                    float ag = g[i] + (-a.lambda) * p[i];            // :264-273
-                    ag = ag * ag;
-                    const float vn = v[i] * a.s_v + ag * a.one_m_b2; // :277-281
-                    m[i] = mn;
-                    v[i] = vn;
-                    p[i] = p[i] + ((mn / (sqrtf(vn) + a.eps)) * a.bc) * a.lr;   // :312-328 (λ = 0)
-                }
-                stv<V>(a.m + off, m);
-                stv<V>(a.v + off, v);
-                stv<V>(a.P + off, p);
-            } else {
-                // ROW_ADAM_MV / ROW_ADAM_SPARSE_ENT / ROW_ADAM_DENSE: v is one scalar per row (updates_adam.cu:126).
-#pragma unroll
-                for (int i = 0; i < V; ++i) m[i] = m[i] * a.s_m + a.one_m_b1 * g[i];
-                stv<V>(a.m + off, m);
-                const float vn = a.sc_in[row] * a.s_v + a.one_m_b2 * q;
-                if (cv == 0) a.sc_out[row] = vn;
-                if (KIND == ROW_ADAM_SPARSE_ENT) {
-                    if (!touch_p) continue;
-                    const float denom = sqrtf(vn) + a.eps;
-                    const float fc = static_cast<float>(cnt);
-#pragma unroll
-                    for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + (a.lr * fc) * ((a.bc * m[i]) / denom);
-                    stv<V>(a.P + off, p);
-                } else if (KIND == ROW_ADAM_DENSE) {
-                    const float denom = sqrtf(vn) + a.eps;
-#pragma unroll
-                    for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + ((m[i] / denom) * a.bc) * a.lr;
-                    stv<V>(a.P + off, p);
-                }
-            }
+            apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, touch_p, g, q, p, m, v);
         }
     }
 }
+
+// Rows without entries, when the pass is dense (λ > 0 and / or Adam's m·β₁, v·β₂ decay): most rows of a table much
+// larger than the batch. The row pass spends one wave and two dependent round trips (bounds, then state) on such a
+// row and its registers are sized for the 8-deep gather (3 waves per SIMD): 3 TB/s at |D| = 2M. This pass streams
+// them instead — one (row, 16 B column group) item per thread, four independent items in flight per thread, few
+// registers — and leaves the rows that do have entries to the row pass (launched on Csr::touched only).
+constexpr int kUntouchedUnroll = 4;
+template <int V, int KIND>
+__global__ __launch_bounds__(256) void untouched_rows_kernel(Csr c, RowPassArgs a, uint32_t nvec, uint64_t total) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const bool p_always = (a.decay != 1.f);
+    for (uint64_t base = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; base < total;
+         base += stride * kUntouchedUnroll) {
+        int64_t row[kUntouchedUnroll]; uint32_t cv[kUntouchedUnroll]; bool mine[kUntouchedUnroll];
+#pragma unroll
+        for (int u = 0; u < kUntouchedUnroll; ++u) {
+            const uint64_t q = base + u * stride;
+            const uint64_t qq = q < total ? q : total - 1;
+            row[u] = static_cast<int64_t>(qq / nvec);
+            cv[u] = static_cast<uint32_t>(qq - static_cast<uint64_t>(row[u]) * nvec);
+            mine[u] = (q < total) && (c.row_end[row[u]] == c.row_begin[row[u]]);
+        }
+        float p[kUntouchedUnroll][V], m[kUntouchedUnroll][V], v[kUntouchedUnroll][V];
+#pragma unroll
+        for (int u = 0; u < kUntouchedUnroll; ++u)
+            if (mine[u]) load_row_state<V, KIND>(a, static_cast<size_t>(row[u]) * a.dim + cv[u] * V, 0, p_always, p[u], m[u], v[u]);
+#pragma unroll
+        for (int u = 0; u < kUntouchedUnroll; ++u) {
+            if (!mine[u]) continue;
+            float g[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] = 0.f;
+            apply_row_formula<V, KIND>(a, row[u], cv[u] == 0, static_cast<size_t>(row[u]) * a.dim + cv[u] * V, 0, p_always,
+                                       g, 0.f, p[u], m[u], v[u]);
+        }
+    }
+}
+
+bool row_pass_split(const Csr& c) { return c.rows >= c.n && c.n > 0; }
+static bool kind_is_row_local_when_untouched(int kind) { return kind != ROW_ADAM_DENSE && kind != ROW_ADAM_FULL; }
 
 static void group_geometry(int dim, int& V, int& nvec, int& G) {
     V = (dim % 4 == 0) ? 4 : 1;
@@ -358,12 +429,42 @@ static void row_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nve
 #undef NVSM_ROW_CASE
 }
 
-void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s) {
+template <int V>
+static void untouched_dispatch(const Csr& c, const RowPassArgs& a, int nvec, hipStream_t s) {
+    const uint32_t nv = (a.kind == ROW_SCALAR_ACC) ? 1u : static_cast<uint32_t>(nvec);      // only the row scalar moves
+    const uint64_t total = static_cast<uint64_t>(c.rows) * nv;
+    const uint64_t per_block = 256ull * kUntouchedUnroll;
+    uint64_t blocks = (total + per_block - 1) / per_block;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+#define NVSM_UNT_CASE(K) case K: hipLaunchKernelGGL((untouched_rows_kernel<V, K>), grid, block, 0, s, c, a, nv, total); break;
+    switch (a.kind) {
+        NVSM_UNT_CASE(ROW_SGD)
+        NVSM_UNT_CASE(ROW_ADAGRAD_ENT)
+        NVSM_UNT_CASE(ROW_ADAM_MV)
+        NVSM_UNT_CASE(ROW_ADAM_SPARSE_ENT)
+        NVSM_UNT_CASE(ROW_SCALAR_ACC)
+        default: break;
+    }
+#undef NVSM_UNT_CASE
+}
+
+void launch_row_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
     if (c.rows <= 0) return;
     int V, nvec, G;
-    group_geometry(a.dim, V, nvec, G);
-    if (V == 4) { if (a.table == 0) row_pass_dispatch<4, 0>(c, a, G, nvec, s); else row_pass_dispatch<4, 1>(c, a, G, nvec, s); }
-    else        { if (a.table == 0) row_pass_dispatch<1, 0>(c, a, G, nvec, s); else row_pass_dispatch<1, 1>(c, a, G, nvec, s); }
+    group_geometry(a_in.dim, V, nvec, G);
+    RowPassArgs a = a_in;
+    a.touched_only = 0;
+    Csr cc = c;
+    // Table much larger than the batch (at most one entry per row on average): the rows with entries go through the
+    // row pass by list, all the others — if the pass is dense — through the streaming pass.
+    if (row_pass_split(c) && kind_is_row_local_when_untouched(a.kind)) {
+        if (a.dense) { if (V == 4) untouched_dispatch<4>(c, a, nvec, s); else untouched_dispatch<1>(c, a, nvec, s); }
+        a.touched_only = 1;
+        cc.rows = c.n < c.rows ? c.n : c.rows;      // upper bound of the list length: sizes the grid
+    }
+    if (V == 4) { if (a.table == 0) row_pass_dispatch<4, 0>(cc, a, G, nvec, s); else row_pass_dispatch<4, 1>(cc, a, G, nvec, s); }
+    else        { if (a.table == 0) row_pass_dispatch<1, 0>(cc, a, G, nvec, s); else row_pass_dispatch<1, 1>(cc, a, G, nvec, s); }
 }
 
 // =============================================================================================

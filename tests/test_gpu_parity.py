@@ -152,6 +152,12 @@ SPECS = {
                 nonlinearity="hard_tanh", batch_norm=True, lambda_=0.01),
     "k4_window1": dict(num_words=50, num_entities=40, word_dim=24, entity_dim=128, window=1, num_random=4,
                        nonlinearity="tanh", batch_norm=True, bias_negative_samples=True, lambda_=0.01),
+    # tables much larger than the batch: the row passes go by the touched-row list, the other rows through the
+    # streaming dense-decay pass (update.hip: row_pass_split)
+    "sparse_touch": dict(num_words=30000, num_entities=40000, word_dim=16, entity_dim=12, window=3, num_random=4,
+                         nonlinearity="hard_tanh", batch_norm=True, lambda_=0.01),
+    "sparse_touch_odd": dict(num_words=9000, num_entities=7000, word_dim=7, entity_dim=5, window=2, num_random=3,
+                             nonlinearity="tanh", batch_norm=False, lambda_=0.01),
     "dim1024": dict(num_words=40, num_entities=30, word_dim=16, entity_dim=1024, window=2, num_random=3,
                     nonlinearity="hard_tanh", batch_norm=False, lambda_=0.0),
 }
@@ -197,7 +203,7 @@ def test_forward_backward_parity(name, B):
 
 
 @pytest.mark.parametrize("method", ["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
-@pytest.mark.parametrize("name", ["nvsm", "tiny", "lse", "tiny_odd", "k4_window1", "many_negatives"])
+@pytest.mark.parametrize("name", ["nvsm", "tiny", "lse", "tiny_odd", "k4_window1", "many_negatives", "sparse_touch", "sparse_touch_odd"])
 @pytest.mark.parametrize("lam", [0.0, 0.01])
 def test_update_parity(method, name, lam):
     """Three optimiser steps on identical batches; parameters and optimiser state must track the oracle."""
@@ -219,7 +225,8 @@ def test_update_parity(method, name, lam):
     for p in PARAMS:
         delta = np.linalg.norm(o.get(p) - start[p])
         err = np.linalg.norm(g.get_param(p).astype(np.float64) - o.get(p))
-        assert err <= UPD_TOL * max(delta, 1e-12) + 1e-7 * np.linalg.norm(o.get(p)), (p, err, delta)
+        # + the fp32 storage floor: three successive roundings of every parameter (half an ulp = 6e-8 relative each)
+        assert err <= UPD_TOL * max(delta, 1e-12) + 2e-7 * np.linalg.norm(o.get(p)), (p, err, delta)
     if method != "sgd":
         pairs = {"adagrad": [("word_representations/a", "words.s0"), ("entity_representations/a", "entities.s0"),
                              ("word_entity_mapping/s0_transform", "transform.s0.transform")],

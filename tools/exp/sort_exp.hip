@@ -9,11 +9,15 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 using force_onesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+template <int BITS, int IPT, int HIPT = 8>
+using os_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, HIPT>, rocprim::kernel_config<1024, IPT>, BITS,
+                                        rocprim::block_radix_rank_algorithm::match>, 0>;
 
 int main() {
     struct Case { const char* name; int n; int rows; bool zipf; };
     Case cases[] = {{"entities uniform", 870400, 100000, false}, {"words zipf", 512000, 50000, true}, {"words uniform", 512000, 50000, false},
-                    {"entities 2M rows", 870400, 2000000, false}};
+                    {"entities 2M rows", 870400, 2000000, false}, {"ents B=4096", 69632, 100000, false}, {"words B=4096 200k", 40960, 200000, true}};
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& c : cases) {
@@ -48,6 +52,22 @@ int main() {
         timeit("rocprim onesweep forced", [&] { CK((rocprim::radix_sort_pairs<force_onesweep>(tmp, tb2, k_in, k_out, v_in, v_out, (size_t)c.n, 0, bits, s))); });
         CK(hipStreamSynchronize(s)); CK(hipMemcpy(r2.data(), v_out, c.n * 4, hipMemcpyDeviceToHost));
         printf("   same permutation: %s (tmp %zu / %zu bytes)\n", r1 == r2 ? "yes" : "NO", tb1, tb2);
+        auto variant = [&](const char* nm, auto cfg_tag) {
+            using CFG = decltype(cfg_tag);
+            size_t tb = 0;
+            CK((rocprim::radix_sort_pairs<CFG>(nullptr, tb, k_in, k_out, v_in, v_out, (size_t)c.n, 0, bits, s)));
+            void* t2; CK(hipMalloc(&t2, tb + 256));
+            timeit(nm, [&] { CK((rocprim::radix_sort_pairs<CFG>(t2, tb, k_in, k_out, v_in, v_out, (size_t)c.n, 0, bits, s))); });
+            std::vector<int> r3(c.n); CK(hipStreamSynchronize(s)); CK(hipMemcpy(r3.data(), v_out, c.n * 4, hipMemcpyDeviceToHost));
+            if (r3 != r1) printf("   %s: DIFFERENT permutation\n", nm);
+            hipFree(t2);
+        };
+        variant("onesweep 8b ipt8", os_cfg<8, 8>{});
+        variant("onesweep 9b ipt8", os_cfg<9, 8>{});
+        variant("onesweep 9b ipt4", os_cfg<9, 4>{});
+        variant("onesweep 10b ipt4", os_cfg<10, 4>{});
+        variant("onesweep 10b ipt8", os_cfg<10, 8>{});
+        variant("onesweep 6b ipt8", os_cfg<6, 8>{});
         hipFree(k_in); hipFree(k_out); hipFree(v_in); hipFree(v_out); hipFree(tmp);
     }
     return 0;

@@ -71,6 +71,7 @@ struct LossArgs {
     int64_t B;
     int de, R, k;
     int bn, nonlinearity, rebalance;
+    int l2_entity;            // l2_normalize_entity_reprs: gathered rows are divided by their norm (generic kernel only)
     float sig_eps, sig_hi, d_eps;
     double d_hi;              // 1 − d_eps compared in double (include/cuNVSM/cuda_utils.h:230)
     float inv_batch;          // exp(−log(B_global))
@@ -84,6 +85,12 @@ void launch_loss(const LossArgs& a, hipStream_t s);
 void launch_row_meansq(const float* G, int64_t rows, int dim, float inv_dim, float* out, hipStream_t s);
 // grad_entity[j][t] = coef[j] · proj[j/R][t]  (tests / gradient checker only)
 void launch_materialize_grad_entity(const float* coef, const float* proj, int64_t N, int R, int de, float* out, hipStream_t s);
+// ---- optional L2 row normaliser (cpp/cuda_utils.cu:12-130) ----
+void launch_l2_rows_forward(const float* x, int64_t rows, int dim, float* y, float* norms, hipStream_t s);
+void launch_l2_rows_backward(const float* g, const float* x, const float* norms, int64_t rows, int dim, float scale,
+                             float* gin, float* msq, hipStream_t s);
+void launch_materialize_grad_entity_l2(const float* coef, const float* proj, const float* E, const int* ids, int64_t N, int R,
+                                       int de, float* out, float* msq, hipStream_t s);
 
 // ---- batch → CSR by table row (replaces the atomic scatter of update_repr_kernel, cpp/storage.cu:37-49)
 size_t sort_pairs_temp_bytes(int64_t n, int bits);

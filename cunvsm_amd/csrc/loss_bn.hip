@@ -102,7 +102,7 @@ void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* i
 constexpr int kExamplesPerWave = 8;
 constexpr int kRowGroup = 4;
 
-template <int V, int NITER>
+template <int V, int NITER, bool L2E = false>
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     extern __shared__ float lds[];          // [2][4][de] column stats + [4] loss
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -188,6 +188,31 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 #pragma unroll
                     for (int it = 0; it < NITER; ++it)
                         if (valid[it]) ldv<V>(a.E + id * de + (it * 64 + lane) * V, e_next[u][it]);
+                }
+            }
+            if (L2E) {
+                // l2_normalize_entity_reprs (objective.cu:168-174, Normalizer::forward cuda_utils.cu:12-46): every gathered
+                // row is divided by its norm before it is negated / multiplied; the loss and the projection gradient
+                // see the normalised rows (the gradient w.r.t. the table is taken in materialize_grad_entity_l2_kernel)
+                float nsq[kRowGroup];
+#pragma unroll
+                for (int u = 0; u < kRowGroup; ++u) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                        for (int i = 0; i < V; ++i) t += e[u][it][i] * e[u][it][i];
+                    nsq[u] = t;
+                }
+#pragma unroll
+                for (int u = 0; u < kRowGroup; ++u) nsq[u] = wave_sum(nsq[u]);
+#pragma unroll
+                for (int u = 0; u < kRowGroup; ++u) {
+                    const float nrm = sqrtf(nsq[u]);
+#pragma unroll
+                    for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                        for (int i = 0; i < V; ++i) e[u][it][i] = (r0 + u < R) ? e[u][it][i] / nrm : 0.f;
                 }
             }
             float dot[kRowGroup];
@@ -424,7 +449,8 @@ template <int V, int NITER>
 static void launch_loss_t(const LossArgs& a, hipStream_t s) {
     const int grid = ceil_div(a.B, 4 * kExamplesPerWave);
     const size_t shmem = (8 * static_cast<size_t>(a.de) + 4) * sizeof(float);
-    hipLaunchKernelGGL((loss_kernel<V, NITER>), dim3(grid), dim3(256), shmem, s, a);
+    if (a.l2_entity) hipLaunchKernelGGL((loss_kernel<V, NITER, true>), dim3(grid), dim3(256), shmem, s, a);
+    else hipLaunchKernelGGL((loss_kernel<V, NITER, false>), dim3(grid), dim3(256), shmem, s, a);
 }
 
 template <int RB>
@@ -440,7 +466,7 @@ static void launch_loss_rows(const LossArgs& a, hipStream_t s) {
 void launch_loss(const LossArgs& a, hipStream_t s) {
     if (a.B <= 0) return;
     const int de = a.de;
-    if (de % 4 == 0 && de <= 256 && a.R <= 64) {
+    if (de % 4 == 0 && de <= 256 && a.R <= 64 && !a.l2_entity) {      // (the optional entity normaliser: generic kernel)
         if (a.R <= 6) launch_loss_rows<6>(a, s);
         else if (a.R <= 11) launch_loss_rows<11>(a, s);
         else launch_loss_rows<17>(a, s);
@@ -491,6 +517,89 @@ __global__ void materialize_grad_entity_kernel(const float* __restrict__ coef, c
 void launch_materialize_grad_entity(const float* coef, const float* proj, int64_t N, int R, int de, float* out, hipStream_t s) {
     if (N <= 0) return;
     hipLaunchKernelGGL(materialize_grad_entity_kernel, dim3(stream_grid(N * de, 256)), dim3(256), 0, s, coef, proj, N, R, de, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2 row normaliser (optional: --l2_phrase_normalization / --l2_entity_normalization, off in both recipes).
+// Normalizer::forward / backward, cpp/cuda_utils.cu:12-130: y = x / ‖x‖;  grad_in = (g·‖x‖² − x·(x·g)) / ‖x‖³.
+// One wave per row; not tuned — these are small streaming passes next to the gathers.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2_rows_forward_kernel(const float* __restrict__ x, int64_t rows, int dim,
+                                                              float* __restrict__ y, float* __restrict__ norms) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < rows; b += static_cast<int64_t>(gridDim.x) * 4) {
+        float s = 0.f;
+        for (int t = lane; t < dim; t += 64) { const float v = x[b * dim + t]; s += v * v; }
+        const float n = sqrtf(wave_sum(s));
+        if (lane == 0) norms[b] = n;
+        for (int t = lane; t < dim; t += 64) y[b * dim + t] = x[b * dim + t] / n;
+    }
+}
+void launch_l2_rows_forward(const float* x, int64_t rows, int dim, float* y, float* norms, hipStream_t s) {
+    if (rows > 0) hipLaunchKernelGGL(l2_rows_forward_kernel, dim3(stream_grid(rows * 64, 256)), dim3(256), 0, s, x, rows, dim, y, norms);
+}
+
+// gin = scale · (g·n² − x·(x·g)) / n³ (in place over g allowed), msq[b] = mean_t(gin²) when msq != null
+__global__ __launch_bounds__(256) void l2_rows_backward_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                               const float* __restrict__ norms, int64_t rows, int dim,
+                                                               float scale, float inv_dim, float* __restrict__ gin,
+                                                               float* __restrict__ msq) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < rows; b += static_cast<int64_t>(gridDim.x) * 4) {
+        float cr = 0.f;
+        for (int t = lane; t < dim; t += 64) cr += x[b * dim + t] * g[b * dim + t];
+        cr = wave_sum(cr);
+        const float n = norms[b], n2 = n * n, n3 = n2 * n;
+        float sq = 0.f;
+        for (int t = lane; t < dim; t += 64) {
+            const float v = ((g[b * dim + t] * n2 - x[b * dim + t] * cr) / n3) * scale;
+            gin[b * dim + t] = v;
+            sq += v * v;
+        }
+        if (msq) { sq = wave_sum(sq); if (lane == 0) msq[b] = sq * inv_dim; }
+    }
+}
+void launch_l2_rows_backward(const float* g, const float* x, const float* norms, int64_t rows, int dim, float scale,
+                             float* gin, float* msq, hipStream_t s) {
+    if (rows <= 0) return;
+    const float inv_dim = static_cast<float>(std::exp(-std::log(static_cast<double>(dim))));
+    hipLaunchKernelGGL(l2_rows_backward_kernel, dim3(stream_grid(rows * 64, 256)), dim3(256), 0, s, g, x, norms, rows, dim, scale,
+                       inv_dim, gin, msq);
+}
+
+// l2_normalize_entity_reprs: the gradient of every gathered document row, materialised as the reference does
+// (objective.cu:354-412): g_j = coef_j · proj[j / R] is the gradient w.r.t. the normalised row (the sign of the
+// negatives is already in coef_j), sent back through Normalizer::backward with the raw row E[id_j] as cached input.
+// out[j] = (g_j·n² − e·(e·g_j)) / n³, msq[j] = mean_t(out[j]²) (the per-entry mean of squares Adagrad / Adam accumulate).
+__global__ __launch_bounds__(256) void materialize_grad_entity_l2_kernel(const float* __restrict__ coef, const float* __restrict__ proj,
+                                                                         const float* __restrict__ E, const int* __restrict__ ids,
+                                                                         int64_t N, int R, int de, float inv_de,
+                                                                         float* __restrict__ out, float* __restrict__ msq) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t j = blockIdx.x * 4 + (threadIdx.x >> 6); j < N; j += static_cast<int64_t>(gridDim.x) * 4) {
+        const float* e = E + static_cast<size_t>(ids[j]) * de;
+        const float* pr = proj + (j / R) * de;
+        const float cf = coef[j];
+        float nsq = 0.f, cr = 0.f;
+        for (int t = lane; t < de; t += 64) { const float ev = e[t]; nsq += ev * ev; cr += ev * (pr[t] * cf); }
+        nsq = wave_sum(nsq); cr = wave_sum(cr);
+        const float n = sqrtf(nsq), n2 = n * n, n3 = n2 * n;
+        float sq = 0.f;
+        for (int t = lane; t < de; t += 64) {
+            const float v = ((pr[t] * cf) * n2 - e[t] * cr) / n3;
+            out[j * de + t] = v;
+            sq += v * v;
+        }
+        sq = wave_sum(sq);
+        if (lane == 0 && msq) msq[j] = sq * inv_de;
+    }
+}
+void launch_materialize_grad_entity_l2(const float* coef, const float* proj, const float* E, const int* ids, int64_t N, int R,
+                                       int de, float* out, float* msq, hipStream_t s) {
+    if (N <= 0) return;
+    const float inv_de = static_cast<float>(std::exp(-std::log(static_cast<double>(de))));
+    hipLaunchKernelGGL(materialize_grad_entity_l2_kernel, dim3(stream_grid(N * 64, 256)), dim3(256), 0, s, coef, proj, E, ids, N, R,
+                       de, inv_de, out, msq);
 }
 
 }  // namespace cunvsm

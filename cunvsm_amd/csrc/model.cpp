@@ -200,8 +200,6 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     if (cfg.nonlinearity != NVSM_TANH && cfg.nonlinearity != NVSM_HARD_TANH) bad("nonlinearity not implemented");  // params.cu:444-445
     if (cfg.update_method < NVSM_SGD || cfg.update_method > NVSM_ADAM) bad("unknown update_method");
     if (cfg.adam_mode < NVSM_ADAM_NONE || cfg.adam_mode > NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE) bad("unknown adam_mode");
-    if (cfg.l2_normalize_phrase_reprs || cfg.l2_normalize_entity_reprs)
-        throw Error(NVSM_ERR_UNSUPPORTED, "l2 phrase/entity normalisation is outside the accelerated hot path (off in the LSE and NVSM recipes)");
     if (cfg.entity_repr_size > 1024 || (cfg.entity_repr_size % 4 != 0 && cfg.entity_repr_size > 256))
         throw Error(NVSM_ERR_UNSUPPORTED, "entity_repr_size must be <= 1024 (multiple of 4) or <= 256");
     if (cfg.word_repr_size > 4096) throw Error(NVSM_ERR_UNSUPPORTED, "word_repr_size must be <= 4096");
@@ -245,6 +243,8 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     widx_.alloc(B * w); ids_.alloc(N); iota_.alloc(std::max<int64_t>(B * w, N));
     launch_iota(iota_.p, static_cast<int64_t>(iota_.n), stream_);
     phrase_.alloc(B * dw); phrase_alt_.alloc(B * dw); phrase_p_ = phrase_.p; pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
+    if (cfg.l2_normalize_phrase_reprs) { phrase_raw_.alloc(B * dw); phrase_norms_.alloc(B); }
+    if (cfg.l2_normalize_entity_reprs) { grad_entity_.alloc(N * de); ge_msq_.alloc(N); }
     coef_.alloc(N); probs_.alloc(N); pp_.alloc(B); msq_w_.alloc(B); msq_parts_.alloc(B * gemm_rowsq_parts(dw));
     if (cfg.update_method == NVSM_ADAM && cfg.adam_mode <= NVSM_ADAM_SPARSE) U_.alloc(B * dw);
     if (cfg.update_method == NVSM_ADAGRAD) scale_w_.alloc(B);
@@ -390,6 +390,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     B_ = B;
     have_forward_ = have_grads_ = false;
     cost_valid_ = false;
+    if (cfg_.l2_normalize_entity_reprs) join_E();      // that documents update still reads ids_, which the prologue rewrites
 
     // device-sampler mode: zeroing the statistics, narrowing the word ids and drawing the document ids are one launch
     const bool fused_prologue = !entity_ids && cfg_.sampler != NVSM_SAMPLER_HOST_MINSTD;
@@ -467,7 +468,13 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // F3: phrase representations (objective.cu:126-130). The previous step's dT GEMM may still be reading its phrase
     // matrix on the side stream: write the other one.
     if (T_pending_) phrase_p_ = (phrase_p_ == phrase_.p) ? phrase_alt_.p : phrase_.p;
-    { PROF("gather_mean_words"); launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, phrase_p_, stream_); }
+    {
+        PROF("gather_mean_words");
+        const bool l2p = cfg_.l2_normalize_phrase_reprs != 0;
+        launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, l2p ? phrase_raw_.p : phrase_p_, stream_);
+        // optional phrase normaliser (objective.cu:136-142): the raw means stay cached for its backward pass
+        if (l2p) launch_l2_rows_forward(phrase_raw_.p, B, dw, phrase_p_, phrase_norms_.p, stream_);
+    }
 
     // F5: projection GEMM  pre[B][de] = phrase[B][dw] · Tt[dw][de] (+ b when no BN)   (params.cu:417-421)
     // F6 (first half): with batch-norm the column sums Σx, Σx² of the projection ride in the GEMM epilogue
@@ -500,6 +507,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         a.loss_acc = stats_bwd_; a.colstats = stats_bwd_ + 1;
         a.B = B; a.de = de; a.R = R_; a.k = k;
         a.bn = cfg_.batch_normalization; a.nonlinearity = cfg_.nonlinearity;
+        a.l2_entity = cfg_.l2_normalize_entity_reprs;
         a.rebalance = (!cfg_.bias_negative_samples && k > 1);                                 // objective.cu:268
         a.sig_eps = cfg_.clip_sigmoid ? 1e-7f : 0.f;                                            // :245-246
         a.sig_hi = static_cast<float>(1.0 - static_cast<double>(a.sig_eps));
@@ -562,9 +570,13 @@ void Model::backward_dx() {
                               (cfg_.update_method == NVSM_ADAM && cfg_.adam_mode != NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE);
         const float inv_dw = static_cast<float>(std::exp(-std::log(static_cast<double>(dw))));
         // (A/B, interleaved: 1.235 ms per step with the epilogue fusion vs 1.262 ms with a separate row-mean-of-squares pass)
-        launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, 1, 0, stream_, nullptr,
-                    need_msq ? msq_parts_.p : nullptr, inv_dw);
-        if (need_msq) launch_sum_parts(msq_parts_.p, gemm_rowsq_parts(dw), B, msq_w_.p, B, stream_);
+        const bool l2p = cfg_.l2_normalize_phrase_reprs != 0;
+        launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, l2p ? 1.f : inv_w, nullptr, 1, 0, stream_,
+                    nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw);
+        if (l2p)        // Normalizer::backward, then the division by the window (objective.cu:461-476); mean of squares of the result
+            launch_l2_rows_backward(gphrase_.p, phrase_raw_.p, phrase_norms_.p, B, dw, inv_w, gphrase_.p,
+                                    need_msq ? msq_w_.p : nullptr, stream_);
+        else if (need_msq) launch_sum_parts(msq_parts_.p, gemm_rowsq_parts(dw), B, msq_w_.p, B, stream_);
         NVSM_HIP_CHECK(hipEventRecord(ev_bwdx_, stream_));      // last reader of T before its update
     }
 }
@@ -673,6 +685,13 @@ void Model::update_entities(float lr, float sl, hipStream_t strm) {
             else if (cfg_.adam_mode == NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE) { a.kind = ROW_ADAM_FULL; a.sq_src = nullptr; a.decay = 1.f; }
             else { a.kind = ROW_ADAM_SPARSE_ENT; swap_sc = true; }
         }
+    }
+    if (cfg_.l2_normalize_entity_reprs) {
+        // optional entity normaliser: the per-entry gradient rows are materialised (as the reference does) and scattered as
+        // they are: source row = entry, coefficient 1, per-entry mean of squares
+        launch_materialize_grad_entity_l2(coef_.p, proj_.p, t.P.p, ids_.p, N, R_, de, grad_entity_.p, ge_msq_.p, strm);
+        a.X = grad_entity_.p; a.coefs = nullptr; a.div = 1; a.div_magic = (uint64_t(1) << 37) + 1;
+        if (a.sq_src) a.sq_src = ge_msq_.p;
     }
     // (Capping this grid so that GEMM workgroups of the other stream find free registers on every CU was measured in
     // the fused step: 1.30 -> 1.31-1.33 ms, no gain; RowPassArgs::max_blocks stays 0.)
@@ -908,7 +927,10 @@ void Model::get_tensor(const std::string& name, float* dst, int64_t count) {
     else if (name == "grad_transform") src = gT_.p;
     else if (name == "grad_entity") {
         if (grad_entity_.n < static_cast<size_t>(count)) grad_entity_.alloc(count);
-        launch_materialize_grad_entity(coef_.p, proj_.p, B_ * R_, R_, cfg_.entity_repr_size, grad_entity_.p, stream_);
+        if (cfg_.l2_normalize_entity_reprs)
+            launch_materialize_grad_entity_l2(coef_.p, proj_.p, ents_.P.p, ids_.p, B_ * R_, R_, cfg_.entity_repr_size, grad_entity_.p, nullptr, stream_);
+        else
+            launch_materialize_grad_entity(coef_.p, proj_.p, B_ * R_, R_, cfg_.entity_repr_size, grad_entity_.p, stream_);
         src = grad_entity_.p;
     } else if (name == "entity_ids") {
         std::vector<int> h(count);

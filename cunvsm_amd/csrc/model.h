@@ -174,6 +174,7 @@ class Model {
     int64_t B_ = 0;                   // instances of the current batch (this rank)
 
     // intermediates
+    DevBuf<float> phrase_raw_, phrase_norms_, ge_msq_;      // optional L2 normalisers: cached raw phrase means + norms; per-entry mean of squares
     DevBuf<float> phrase_alt_;            // second phrase matrix (see compute_cost)
     float* phrase_p_ = nullptr;           // the one the current forward result lives in
     bool E_pending_ = false, T_pending_ = false;      // side-stream tails of the last nvsm_step not yet joined

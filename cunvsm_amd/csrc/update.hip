@@ -122,7 +122,7 @@ __device__ __forceinline__ void accumulate_segment(const RowPassArgs& a, const i
             const uint32_t src = static_cast<uint32_t>((static_cast<uint64_t>(en[u]) * a.div_magic) >> 37);
             float c;
             if (TABLE == 0) c = a.wts ? a.wts[en[u]] : 1.f;
-            else c = a.coefs[en[u]];
+            else c = a.coefs ? a.coefs[en[u]] : 1.f;
             sq[u] = need_q ? a.sq_src[src] : 0.f;
             const float scl = (TABLE == 0 && a.src_scale) ? a.src_scale[src] : 1.f;
             const bool ok = (e + u) < end;

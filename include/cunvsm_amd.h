@@ -62,8 +62,8 @@ typedef struct {
     int32_t nonlinearity;              /* transform_desc.nonlinearity */
     int32_t clip_sigmoid;              /* forced true by the reference CLI (cpp/main.cu:645) */
     int32_t bias_negative_samples;
-    int32_t l2_normalize_phrase_reprs; /* must be 0: NVSM_ERR_UNSUPPORTED otherwise */
-    int32_t l2_normalize_entity_reprs; /* must be 0 */
+    int32_t l2_normalize_phrase_reprs; /* objective.cu:99-103,136-142,461-468: optional; separate normaliser passes */
+    int32_t l2_normalize_entity_reprs; /* objective.cu:104-107,168-174,405-412: optional; generic loss kernel, gradient rows materialised */
     /* TrainConfig */
     int32_t window_size;
     int32_t num_random_entities;

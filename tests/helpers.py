@@ -26,6 +26,7 @@ def oracle_model(spec, dtype=orc.F64):
                           nonlinearity=orc.HARD_TANH if spec.get("nonlinearity", "tanh") == "hard_tanh" else orc.TANH,
                           clip_sigmoid=spec.get("clip_sigmoid", True),
                           bias_negative_samples=spec.get("bias_negative_samples", False),
+                          l2_phrase=spec.get("l2_phrase", False), l2_entity=spec.get("l2_entity", False),
                           lambda_=spec.get("lambda", 0.0), update_method=method, adam_mode=mode)
     return orc.Model(cfg, dtype)
 
@@ -39,6 +40,8 @@ def gpu_model(spec, max_batch, **extra):
                             nonlinearity=spec.get("nonlinearity", "tanh"),
                             clip_sigmoid=spec.get("clip_sigmoid", True),
                             bias_negative_samples=spec.get("bias_negative_samples", False),
+                            l2_normalize_phrase_reprs=int(spec.get("l2_phrase", False)),
+                            l2_normalize_entity_reprs=int(spec.get("l2_entity", False)),
                             regularization_lambda=spec.get("lambda", 0.0),
                             update_method=spec.get("update_method", "sgd"), max_batch_size=max_batch, **extra)
     return ca.Model(cfg)

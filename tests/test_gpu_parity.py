@@ -158,6 +158,13 @@ SPECS = {
                          nonlinearity="hard_tanh", batch_norm=True, lambda_=0.01),
     "sparse_touch_odd": dict(num_words=9000, num_entities=7000, word_dim=7, entity_dim=5, window=2, num_random=3,
                              nonlinearity="tanh", batch_norm=False, lambda_=0.01),
+    # the optional L2 normalisers (gradient_checking_tests.cu:92-110: phrase / entity / both)
+    "l2_phrase": dict(num_words=60, num_entities=40, word_dim=24, entity_dim=20, window=3, num_random=4,
+                      nonlinearity="tanh", batch_norm=False, l2_phrase=True, lambda_=0.01),
+    "l2_entity": dict(num_words=60, num_entities=40, word_dim=24, entity_dim=20, window=3, num_random=4,
+                      nonlinearity="hard_tanh", batch_norm=True, l2_entity=True, lambda_=0.01),
+    "l2_both": dict(num_words=300, num_entities=500, word_dim=300, entity_dim=256, window=10, num_random=16,
+                    nonlinearity="hard_tanh", batch_norm=True, l2_phrase=True, l2_entity=True, lambda_=0.01),
     "dim1024": dict(num_words=40, num_entities=30, word_dim=16, entity_dim=1024, window=2, num_random=3,
                     nonlinearity="hard_tanh", batch_norm=False, lambda_=0.0),
 }
@@ -176,7 +183,8 @@ def _pair(spec, B, seed, max_batch=None):
 
 
 @pytest.mark.parametrize("name,B", [("lse", 256), ("nvsm", 1024), ("tiny", 1024), ("tiny_odd", 100), ("wide", 130), ("nvsm", 1000),
-                                    ("many_negatives", 96), ("k10", 512), ("k4_window1", 200), ("dim1024", 64)])
+                                    ("many_negatives", 96), ("k10", 512), ("k4_window1", 200), ("dim1024", 64),
+                                    ("l2_phrase", 256), ("l2_entity", 256), ("l2_both", 512)])
 def test_forward_backward_parity(name, B):
     spec = SPECS[name]
     o, g, rs = _pair(spec, B, 11)
@@ -203,7 +211,8 @@ def test_forward_backward_parity(name, B):
 
 
 @pytest.mark.parametrize("method", ["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
-@pytest.mark.parametrize("name", ["nvsm", "tiny", "lse", "tiny_odd", "k4_window1", "many_negatives", "sparse_touch", "sparse_touch_odd"])
+@pytest.mark.parametrize("name", ["nvsm", "tiny", "lse", "tiny_odd", "k4_window1", "many_negatives", "sparse_touch", "sparse_touch_odd",
+                                  "l2_phrase", "l2_entity", "l2_both"])
 @pytest.mark.parametrize("lam", [0.0, 0.01])
 def test_update_parity(method, name, lam):
     """Three optimiser steps on identical batches; parameters and optimiser state must track the oracle."""
@@ -287,8 +296,5 @@ def test_error_behaviour():
     with pytest.raises(ca.NvsmError) as e:
         g.compute_cost(ca.Batch(np.zeros(2 * 9, np.int64), np.zeros(9, np.int64)))     # over capacity
     assert e.value.status == 1
-    with pytest.raises(ca.NvsmError) as e:
-        gpu_model(dict(spec), 8, l2_normalize_phrase_reprs=1)
-    assert e.value.status == 2
     with pytest.raises(ca.NvsmError):
         g.initialize(0)                                                                 # cpp/main.cu:708

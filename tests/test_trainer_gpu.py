@@ -229,10 +229,14 @@ def test_trainer_trajectory_matches_oracle(tmp_path, method, extra):
         assert diff <= tol, (n, diff, change)
 
 
-def test_check_gradients_flag(tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--l2_phrase_normalization"], ["--l2_entity_normalization"],
+                                   ["--l2_phrase_normalization", "--l2_entity_normalization", "--batch_normalization"]],
+                         ids=["plain", "l2_phrase", "l2_entity", "l2_both_bn"])
+def test_check_gradients_flag(tmp_path, extra):
     """--check_gradients (cpp/main.cu:414-425 → cpp/gradient_check.cu): central differences for every scalar parameter of
-    a small model; passes on the real gradients and the run aborts when the check cannot pass (ε far too large)."""
-    args = ["--word_repr_size", "3", "--entity_repr_size", "4", "--window_size", "3", "--num_random_entities", "1", "--seed", "2",
+    a small model; passes on the real gradients — also with the optional L2 normalisers, the configurations
+    cpp/gradient_checking_tests.cu:92-110 adds — and the run aborts when the check cannot pass (ε far too large)."""
+    args = extra + ["--word_repr_size", "3", "--entity_repr_size", "4", "--window_size", "3", "--num_random_entities", "1", "--seed", "2",
             "--update_method", "sgd", "--batch_size", "1024", "--nonlinearity", "tanh", "--weighting", "uniform", "--document_cutoff", "12",
             "--max_vocabulary_size", "30", "--min_document_frequency", "0", "--num_epochs", "1", "--check_gradients", "--allow_ragged_batches",
             "--v", "1", CRANFIELD]

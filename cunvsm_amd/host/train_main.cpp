@@ -254,6 +254,16 @@ class Trainer {
             const float relative_error = std::fabs(gradient_predict - gradient_approx) / std::max(std::fabs(gradient_predict), std::fabs(gradient_approx));
             const float ratio = gradient_approx != 0.f ? gradient_predict / gradient_approx : NAN;
             ++num_checked;
+            // The forward pass is fp32 (the reference's checker runs in its double-precision test build): the two costs
+            // carry ≈3e-8 relative noise each, so the difference quotient resolves a derivative only down to
+            // 3e-8·|cost| / (2ε). A disagreement inside twice that resolution says nothing about the gradient (it shows up
+            // with --l2_entity_normalization, whose gradients are of that size) and is not held against it.
+            const double resolution = 3e-8 * std::max(1.0, std::fabs(static_cast<double>(cost))) / (2.0 * epsilon);
+            if (std::fabs(static_cast<double>(gradient_predict) - gradient_approx) <= 2.0 * resolution) {
+                NVSM_VLOG(2) << "Parameter " << idx << " of " << what << " agrees within the fp32 resolution of the difference quotient (approx="
+                             << gradient_approx << ", predict=" << gradient_predict << ").";
+                return;
+            }
             if (gradient_predict * gradient_approx < 0.f) {
                 NVSM_LOG(ERROR) << "Parameter " << idx << " of " << what << " has gradient with incorrect direction (approx=" << gradient_approx
                                 << ", predict=" << gradient_predict << ", ratio=" << ratio << ", relative error=" << relative_error << ").";

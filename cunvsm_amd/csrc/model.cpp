@@ -27,10 +27,15 @@ struct RcclApi {
     static RcclApi* load() {
         static RcclApi api;
         if (api.handle) return &api;
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // a copy the process already holds (PyTorch's, loaded as "librccl.so") is shared; otherwise ROCm's
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
-            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
             if (api.handle) break;
+        }
+        for (const char* n : names) {
+            if (api.handle) break;
+            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!api.handle) throw Error(NVSM_ERR_DEVICE, std::string("cannot load librccl: ") + dlerror());
         api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));

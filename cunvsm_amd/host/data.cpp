@@ -80,6 +80,19 @@ void DataSource::push_instance(const std::vector<WordIdxType>& features, const s
     ++batch->num_instances_;
 }
 
+// push_instance without the vectors: `features` / `feature_weights` (may be null: all 1) point at window_size values.
+// The batch must have room (the callers check full() first).
+void DataSource::push_window(const WordIdxType* features, const WeightType* feature_weights, ObjectIdxType object_id,
+                             WeightType weight, Batch* batch) {
+    const size_t w = batch->window_size(), at = batch->num_instances_;
+    std::copy(features, features + w, &batch->features_[at * w]);
+    if (feature_weights) std::copy(feature_weights, feature_weights + w, &batch->feature_weights_[at * w]);
+    else std::fill(&batch->feature_weights_[at * w], &batch->feature_weights_[(at + 1) * w], static_cast<WeightType>(1.0));
+    batch->labels_[at] = object_id;
+    batch->weights_[at] = weight;
+    ++batch->num_instances_;
+}
+
 VocabularyT construct_vocabulary(const std::vector<std::string>& words) {
     VocabularyT vocabulary;
     vocabulary["<UNK>"] = 0;

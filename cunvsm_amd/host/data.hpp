@@ -85,6 +85,8 @@ class DataSource : public DataSourceInterface {
     // cpp/data.cu:94-124: copy into the next free slot, or park in the overflow buffer when the batch is full
     void push_instance(const std::vector<WordIdxType>& features, const std::vector<WeightType>& feature_weights,
                        ObjectIdxType object_id, WeightType weight, Batch* batch);
+    void push_window(const WordIdxType* features, const WeightType* feature_weights, ObjectIdxType object_id, WeightType weight,
+                     Batch* batch);
 
     // include/cuNVSM/data.h:236-273: sliding windows of batch->window_size() tokens, `stride` apart
     template <typename Iterable>
@@ -103,6 +105,7 @@ class DataSource : public DataSourceInterface {
 
  protected:
     size_t vocabulary_size_, corpus_size_;
+    bool overflow_empty() const { return overflow_buffer_.empty(); }
     InstancesT overflow_buffer_;
 };
 

@@ -28,6 +28,10 @@ class InstanceGeneratorBase {
     explicit InstanceGeneratorBase(IndexSource* source) : source_(source) { NVSM_CHECK(source_ != nullptr); }
     virtual ~InstanceGeneratorBase() {}
     virtual void generate(InstancesT* instances) = 0;
+    // Optional fast path of IndexSource::next: write the next instances straight into the batch until it is full or the
+    // generator runs dry — the same instances in the same order generate() + push_instance would deliver, without the
+    // two heap allocations per instance and the detour through the overflow deque. false = not implemented.
+    virtual bool fill(Batch* /*batch*/) { return false; }
     virtual bool has_next() const = 0;
     virtual void reset() = 0;
 
@@ -127,6 +131,35 @@ class StochasticInstanceGenerator : public InstanceGeneratorBase {            //
         }
     }
 
+    bool fill(Batch* batch) override {
+        const size_t w = source_->window_size_;
+        if (term_ptr_.empty()) {             // label -> its term list / its length, indexed instead of looked up in the map
+            ObjectIdxType max_label = 0;
+            for (const auto& pair : term_lists_) max_label = std::max(max_label, pair.first);
+            term_ptr_.assign(static_cast<size_t>(max_label) + 1, nullptr);
+            for (const auto& pair : term_lists_) term_ptr_[static_cast<size_t>(pair.first)] = &pair.second;
+        }
+        const std::vector<WeightType>& table = source_->term_weight_table();
+        std::vector<WeightType> fw(table.empty() ? 0 : w);
+        while (!batch->full() && !instance_order_.empty()) {
+            const ObjectIdxType label = std::get<0>(instance_order_.front());
+            const ObjectIdxType term_source_label = std::get<1>(instance_order_.front());
+            const uint16_t position = std::get<2>(instance_order_.front());
+            const std::vector<WordIdxType>* terms = term_ptr_.at(static_cast<size_t>(term_source_label));
+            const std::vector<WordIdxType>* own = term_ptr_.at(static_cast<size_t>(label));
+            NVSM_CHECK(terms != nullptr && own != nullptr);
+            const WordIdxType* window = terms->data() + position;
+            WeightType weight = 1.0;
+            if (weighting_strategy_ == INV_DOC_FREQUENCY)
+                weight = static_cast<WeightType>(std::exp(std::log(avg_document_length_) - std::log(static_cast<double>(static_cast<int64_t>(own->size())))));
+            if (!table.empty())
+                for (size_t j = 0; j < w; ++j) fw[j] = table[static_cast<size_t>(window[j])];
+            source_->push_window(window, table.empty() ? nullptr : fw.data(), label, weight, batch);
+            instance_order_.pop_front();
+        }
+        return true;
+    }
+
     bool has_next() const override { return !instance_order_.empty(); }
 
     void reset() override {
@@ -171,6 +204,7 @@ class StochasticInstanceGenerator : public InstanceGeneratorBase {            //
     const WeightingStrategy weighting_strategy_;
     double avg_document_length_ = 0.0;
     std::map<ObjectIdxType, std::vector<WordIdxType>> term_lists_;
+    std::vector<const std::vector<WordIdxType>*> term_ptr_;
     std::deque<std::tuple<ObjectIdxType, ObjectIdxType, uint16_t>> instance_order_;
     RNG* const rng_;
 };
@@ -200,6 +234,7 @@ void IndexSource::next(Batch* batch) {                                          
     NVSM_CHECK(!term_id_mapping_.empty());
     NVSM_CHECK(batch->window_size() == window_size_);
     DataSource::next(batch);
+    if (overflow_empty() && instance_generator_->fill(batch)) return;
     InstancesT instances;
     while (!batch->full() && has_next()) {
         instance_generator_->generate(&instances);
@@ -375,6 +410,18 @@ void IndexSource::initialize(size_t max_vocabulary_size, size_t min_document_fre
     } else {
         instance_generator_.reset(new StochasticInstanceGenerator(sampling_strategy, weighting_strategy, this, rng));
     }
+}
+
+// compute_term_weights per model term id, evaluated once with that very function (empty under uniform term weighting)
+const std::vector<WeightType>& IndexSource::term_weight_table() const {
+    if (term_weighting_strategy_ != UNIFORM_TERM_WEIGHTING && term_weight_table_.empty()) {
+        size_t n = 0;
+        for (const auto& pair : inv_term_id_to_term_freq_) n = std::max(n, static_cast<size_t>(pair.first) + 1);
+        term_weight_table_.assign(n, static_cast<WeightType>(0));
+        for (const auto& pair : inv_term_id_to_term_freq_)
+            term_weight_table_[pair.first] = compute_term_weights({static_cast<WordIdxType>(pair.first)})[0];
+    }
+    return term_weight_table_;
 }
 
 std::vector<WeightType> IndexSource::compute_term_weights(const std::vector<WordIdxType>& terms) const {

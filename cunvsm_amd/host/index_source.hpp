@@ -54,6 +54,7 @@ class IndexSource : public DataSource {
     std::map<std::string, int64_t> build_document_identifiers_map() const;
 
     std::vector<WeightType> compute_term_weights(const std::vector<WordIdxType>& terms) const;   // data.h:465-490
+    const std::vector<WeightType>& term_weight_table() const;
 
  private:
     friend class InstanceGeneratorBase;
@@ -74,6 +75,7 @@ class IndexSource : public DataSource {
     TermIdMapping term_id_mapping_;
     std::map<size_t, TERMID_T> inv_term_id_mapping_;
     std::map<size_t, int64_t> inv_term_id_to_term_freq_;
+    mutable std::vector<WeightType> term_weight_table_;
     std::vector<int64_t> document_lengths_;
     DocumentIdMapping document_id_mapping_;
     std::map<TERMID_T, size_t> restricted_term_frequency_;     // lazily built when the corpus is a subset of the index

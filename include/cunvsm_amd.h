@@ -30,7 +30,7 @@ typedef struct nvsm_model nvsm_model;
 typedef enum {
     NVSM_OK = 0,
     NVSM_ERR_INVALID_ARGUMENT = 1,
-    NVSM_ERR_UNSUPPORTED = 2,      /* configuration outside the hot-path scope (e.g. l2 normalisers) */
+    NVSM_ERR_UNSUPPORTED = 2,      /* configuration outside the kernels' limits (entity_repr_size > 1024, the reference's own limit) */
     NVSM_ERR_DEVICE = 3,           /* HIP / RCCL error, see nvsm_last_error() */
     NVSM_ERR_STATE = 4,            /* call sequence violated (e.g. compute_gradients before compute_cost) */
     NVSM_ERR_NO_DEVICE = 5         /* no MI355X visible: there is NO CPU fallback */

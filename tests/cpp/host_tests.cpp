@@ -3,6 +3,7 @@
 // cpp/utils_tests.cpp — with the same inputs and the same expected values (numbers only). Driven by
 // tests/test_host_layer.py, which builds this file with g++ and checks the per-test verdicts.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <functional>
@@ -395,6 +396,35 @@ static int probe(int argc, char** argv) {
             for (size_t i = 0; i < batch.num_instances() * 10; ++i) checksum = (checksum * 31 + batch.features()[i]) % 1000000007L;
             batch.clear(); }
         std::printf("\"instances\": %lu, \"batches\": %lu, \"feature_checksum\": %ld}\n", (unsigned long)instances, (unsigned long)batches, checksum);
+        return 0;
+    }
+    if (what == "--time-source" && argc >= 6) {
+        // --time-source <trectext> <window> <batch> <epochs>: instances per second of the training data source alone
+        // (shuffled epochs incl. the per-epoch reset, uniform weighting), single thread
+        TrectextIndex* index = TrectextIndex::from_file(argv[2]);
+        const size_t window = std::stoul(argv[3]), batch_size = std::stoul(argv[4]), epochs = std::stoul(argv[5]);
+        RNG rng; rng.seed(1);
+        const uint64_t max_df = static_cast<uint64_t>(std::ceil(index->documentCount() * 0.5));
+        IndexSource source(index, window, &rng, 60000, 2, max_df, 0, false, false, nullptr, nullptr, true, AUTOMATIC_SAMPLING, UNIFORM);
+        Batch batch(batch_size, window);
+        size_t instances = 0; int64_t checksum = 0;
+        double t_next = 0.0, t_reset = 0.0;
+        for (size_t e = 0; e < epochs; ++e) {
+            auto t0 = std::chrono::steady_clock::now();
+            while (source.has_next()) {
+                source.next(&batch);
+                instances += batch.num_instances();
+                checksum += batch.features()[0] + batch.labels()[batch.num_instances() - 1];
+                batch.clear();
+            }
+            auto t1 = std::chrono::steady_clock::now();
+            source.reset();
+            auto t2 = std::chrono::steady_clock::now();
+            t_next += std::chrono::duration<double>(t1 - t0).count();
+            t_reset += std::chrono::duration<double>(t2 - t1).count();
+        }
+        std::printf("{\"instances\": %lu, \"next_seconds\": %.4f, \"reset_seconds\": %.4f, \"instances_per_second\": %.0f, \"checksum\": %ld}\n",
+                    (unsigned long)instances, t_next, t_reset, instances / (t_next + t_reset), (long)checksum);
         return 0;
     }
     if (what == "--dump-epoch" && argc >= 10) {

@@ -1,12 +1,12 @@
-cd /root/repo
+cd "$(dirname "$0")/.."
 for m in full_adam dense_adam adagrad sgd; do
   python bench.py --steps 30 --warmup 5 --no-cpu-baseline --update-method $m > gpurun_out/bench_$m.json 2> gpurun_out/bench_$m.err
 done
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --uniform-words > gpurun_out/bench_uniform.json 2>&1
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --host-batches > gpurun_out/bench_hostbatches.json 2>&1
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --read-cost-every 1 > gpurun_out/bench_readcost.json 2>&1
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline --num-words 500000 --num-entities 2000000 > gpurun_out/bench_large.json 2>&1
-python bench.py --steps 30 --warmup 5 --no-cpu-baseline --batch 4096 --num-words 200000 --update-method adagrad > gpurun_out/bench_small.json 2>&1
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline --config large_tables > gpurun_out/bench_large.json 2>&1
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline --config lse_small > gpurun_out/bench_small.json 2>&1
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/bench_*.json')):

@@ -102,6 +102,8 @@ def lib():
         "nvsm_update": (C.c_int, [vp, C.c_float, C.c_float]), "nvsm_get_cost": (C.c_int, [vp, P(C.c_float)]), "nvsm_get_cost_f64": (C.c_int, [vp, P(C.c_double)]),
         "nvsm_scaled_regularization_lambda": (C.c_float, [vp]),
         "nvsm_step": (C.c_int, [vp, P(NvsmBatch), vp, C.c_float, P(C.c_float)]),
+        "nvsm_step_deferred": (C.c_int, [vp, P(NvsmBatch), vp, C.c_float, P(i64)]),
+        "nvsm_deferred_cost": (C.c_int, [vp, i64, P(C.c_float)]), "nvsm_wait_inputs": (C.c_int, [vp]),
         "nvsm_tensor_size": (C.c_int, [vp, cp, P(i64)]), "nvsm_get_tensor": (C.c_int, [vp, cp, vp, i64]),
         "nvsm_set_stream": (C.c_int, [vp, vp]), "nvsm_synchronize": (C.c_int, [vp]),
         "nvsm_comm_unique_id": (C.c_int, [vp]), "nvsm_comm_init": (C.c_int, [vp, vp]),

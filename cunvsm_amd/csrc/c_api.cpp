@@ -122,6 +122,16 @@ int nvsm_step(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids,
     return guarded([&] { m->impl.step(*batch, entity_ids, lr, cost); });
 }
 
+int nvsm_step_deferred(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids, float lr, int64_t* ticket) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(batch); NVSM_REQUIRE(ticket);
+    return guarded([&] { *ticket = m->impl.step_deferred(*batch, entity_ids, lr); });
+}
+int nvsm_deferred_cost(nvsm_model* m, int64_t ticket, float* cost) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(cost);
+    return guarded([&] { *cost = m->impl.deferred_cost(ticket); });
+}
+int nvsm_wait_inputs(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.wait_inputs(); }); }
+
 int nvsm_tensor_size(nvsm_model* m, const char* name, int64_t* count) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(count);
     return guarded([&] { *count = m->impl.tensor_size(name); });

@@ -269,6 +269,7 @@ Model::~Model() {
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
     for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_}) if (e) (void)hipEventDestroy(e);
+    for (DeferredCost& d : deferred_) { if (d.ev) (void)hipEventDestroy(d.ev); if (d.host) (void)hipHostFree(d.host); }
     if (comm_ && rccl_) rccl_->CommDestroy(comm_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
@@ -461,6 +462,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
 
     // Row-order (CSR) of both tables for the update, on the side stream: needs only the indices.
     NVSM_HIP_CHECK(hipEventRecord(ev_inputs_, stream_));
+    inputs_recorded_ = true;
     // two side streams: the sorts are latency-bound chains of small launches, so the two tables' builds run next to
     // each other (at batch 4096 one behind the other they were the longest chain of the whole step)
     NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_inputs_, 0));
@@ -840,6 +842,34 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     NVSM_HIP_CHECK(hipGetLastError());
     have_grads_ = false;
     if (cost) *cost = get_cost();
+}
+
+int64_t Model::step_deferred(const nvsm_batch& batch, const int64_t* entity_ids, float lr) {
+    step(batch, entity_ids, lr, nullptr);
+    DeferredCost& d = deferred_[next_ticket_ % NVSM_MAX_DEFERRED];
+    if (!d.host) {
+        NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d.host), sizeof(double), hipHostMallocDefault));
+        NVSM_HIP_CHECK(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
+    }
+    // the loss word is final after the loss kernel (and, data parallel, after the all-reduce in the backward pass): both
+    // are behind us on the main stream
+    NVSM_HIP_CHECK(hipMemcpyAsync(d.host, stats_bwd_, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    NVSM_HIP_CHECK(hipEventRecord(d.ev, stream_));
+    d.batch = static_cast<double>(B_) * (cfg_.world_size > 1 ? cfg_.world_size : 1);
+    d.ticket = next_ticket_;
+    return next_ticket_++;
+}
+
+float Model::deferred_cost(int64_t ticket) {
+    if (ticket < 0 || ticket >= next_ticket_) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown ticket");
+    DeferredCost& d = deferred_[ticket % NVSM_MAX_DEFERRED];
+    if (d.ticket != ticket) throw Error(NVSM_ERR_STATE, "ticket is older than the NVSM_MAX_DEFERRED most recent steps");
+    NVSM_HIP_CHECK(hipEventSynchronize(d.ev));
+    return static_cast<float>(-(*d.host / d.batch));
+}
+
+void Model::wait_inputs() {
+    if (inputs_recorded_) NVSM_HIP_CHECK(hipEventSynchronize(ev_inputs_));
 }
 
 // ---------------------------------------------------------------------------------------------

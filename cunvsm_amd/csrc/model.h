@@ -117,6 +117,9 @@ class Model {
     void get_tensor(const std::string& name, float* dst, int64_t count);
 
     void set_stream(hipStream_t s);
+    int64_t step_deferred(const nvsm_batch& batch, const int64_t* entity_ids, float lr);
+    float deferred_cost(int64_t ticket);
+    void wait_inputs();
     void synchronize();
     void debug_delay(int microseconds);
     void join_T();
@@ -187,6 +190,10 @@ class Model {
     int gemm_slabs_want_ = 128;
 
     bool have_forward_ = false, have_grads_ = false;
+    struct DeferredCost { double* host = nullptr; hipEvent_t ev = nullptr; double batch = 1.0; int64_t ticket = -1; };
+    DeferredCost deferred_[NVSM_MAX_DEFERRED];
+    int64_t next_ticket_ = 0;
+    bool inputs_recorded_ = false;
     double cost_ = 0.0;
     bool cost_valid_ = false;
 

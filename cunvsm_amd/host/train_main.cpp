@@ -155,8 +155,23 @@ class Trainer {
         size_t epoch_num_batches = 0;
         float agg_cost = 0.0;
         const auto iteration_start = std::chrono::steady_clock::now();
+        // The reference reads the loss of every batch right after it (cpp/main.cu:427-444), which idles the GPU while the
+        // host queues the next step's launches. Here the loss of batch k is read one step later, after batch k+1 has been
+        // queued (nvsm_step_deferred), so that a whole step is always queued ahead of the GPU; the aggregate, the
+        // per-batch log line and the order of everything else are unchanged.
+        struct Pending { bool valid = false; int64_t ticket = 0; size_t index = 0; std::chrono::steady_clock::time_point start; };
+        Pending pending;
+        auto finish = [&](Pending& p) {
+            if (!p.valid) return;
+            float cost = 0.f;
+            NVSM_CALL(nvsm_deferred_cost(model_, p.ticket, &cost));
+            agg_cost += cost;
+            log_batch(p.index, cost, data_source, iteration_start, p.start);
+            p.valid = false;
+        };
         while (data_source->has_next()) {
             const auto batch_start = std::chrono::steady_clock::now();
+            NVSM_CALL(nvsm_wait_inputs(model_));        // the previous step has copied this host batch to the device
             batch->clear();
             data_source->next(batch);
             const size_t n = batch->num_instances();
@@ -180,7 +195,15 @@ class Trainer {
                 } else if (backpropagate) {
                     // compute_cost → compute_gradients → update(lr, scaled λ) → get_cost (cpp/main.cu:405-444) as ONE call:
                     // same arithmetic, the independent halves of the backward pass overlapped on two streams
-                    NVSM_CALL(nvsm_step(model_, &b, nullptr, tc_.learning_rate, &cost));
+                    int64_t ticket = 0;
+                    NVSM_CALL(nvsm_step_deferred(model_, &b, nullptr, tc_.learning_rate, &ticket));
+                    finish(pending);
+                    pending.valid = true; pending.ticket = ticket; pending.index = epoch_num_batches; pending.start = batch_start;
+                    windows_ += n;
+                    if (may_dump && FLAGS_dump_every > 0 && epoch_num_batches > 0 && epoch_num_batches % static_cast<size_t>(FLAGS_dump_every) == 0)
+                        dump_model(dump_epoch, std::to_string(epoch_num_batches));
+                    ++epoch_num_batches;
+                    continue;
                 } else {
                     NVSM_CALL(nvsm_compute_cost(model_, &b, nullptr));
                     NVSM_CALL(nvsm_compute_gradients(model_));
@@ -188,22 +211,28 @@ class Trainer {
                 }
                 agg_cost += cost;
                 windows_ += n;
-                if (verbosity() >= 1) {
-                    const double epoch_duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - iteration_start).count();
-                    const double batch_duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - batch_start).count();
-                    const double progress = data_source->progress();
-                    std::string remaining = "unknown time";
-                    if (progress > 0.0 && std::isfinite(progress)) remaining = seconds_to_humanreadable_time((1.0 - progress) * (epoch_duration / progress));
-                    NVSM_LOG(INFO) << "Batch #" << epoch_num_batches << " (" << std::setprecision(8) << progress * 100.0 << "%; " << remaining
-                                   << " remaining): cost=" << cost << ", duration=" << batch_duration;
-                }
+                log_batch(epoch_num_batches, cost, data_source, iteration_start, batch_start);
             }
             if (may_dump && FLAGS_dump_every > 0 && epoch_num_batches > 0 && epoch_num_batches % static_cast<size_t>(FLAGS_dump_every) == 0)
                 dump_model(dump_epoch, std::to_string(epoch_num_batches));
             ++epoch_num_batches;
         }
+        finish(pending);
         NVSM_CHECK(epoch_num_batches > 0) << "No batches to train during epoch";
         return std::make_pair(epoch_num_batches, agg_cost);
+    }
+
+    // the per-batch log line of cpp/main.cu:445-451
+    void log_batch(size_t index, float cost, DataSourceInterface* data_source, std::chrono::steady_clock::time_point iteration_start,
+                   std::chrono::steady_clock::time_point batch_start) {
+        if (verbosity() < 1) return;
+        const double epoch_duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - iteration_start).count();
+        const double batch_duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - batch_start).count();
+        const double progress = data_source->progress();
+        std::string remaining = "unknown time";
+        if (progress > 0.0 && std::isfinite(progress)) remaining = seconds_to_humanreadable_time((1.0 - progress) * (epoch_duration / progress));
+        NVSM_LOG(INFO) << "Batch #" << index << " (" << std::setprecision(8) << progress * 100.0 << "%; " << remaining
+                       << " remaining): cost=" << cost << ", duration=" << batch_duration;
     }
 
     uint64_t windows() const { return windows_; }

@@ -149,6 +149,25 @@ class Model:
         return c.value if want_cost else None
 
     # -- parameters / tensors ----------------------------------------------------------------------
+    def step_deferred(self, batch, learning_rate, entity_ids=None):
+        """nvsm_step + an asynchronous read-back of its loss; returns the ticket for deferred_cost()."""
+        ids = None
+        if entity_ids is not None:
+            ids = np.ascontiguousarray(entity_ids, dtype=np.int64)
+        st = batch.as_struct()
+        self._keep = (batch, ids)
+        t = C.c_int64()
+        check(lib().nvsm_step_deferred(self._h, C.byref(st), ids.ctypes.data if ids is not None else None, float(learning_rate), C.byref(t)))
+        return t.value
+
+    def deferred_cost(self, ticket):
+        c = C.c_float()
+        check(lib().nvsm_deferred_cost(self._h, int(ticket), C.byref(c)))
+        return c.value
+
+    def wait_inputs(self):
+        check(lib().nvsm_wait_inputs(self._h))
+
     def get_param(self, name):
         n = C.c_int64()
         check(lib().nvsm_param_size(self._h, name.encode(), C.byref(n)))

@@ -157,6 +157,17 @@ float nvsm_scaled_regularization_lambda(nvsm_model* m);
  * scaled lambda; fully asynchronous. cost may be NULL (no read-back, no sync). */
 int nvsm_step(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids, float learning_rate, float* cost);
 
+/* The same step for training loops that want the loss of EVERY batch, as cpp/main.cu:427-444 does, without putting the
+ * GPU behind the host: nvsm_step_deferred queues the step plus a device→host copy of its loss word and hands back a
+ * ticket; nvsm_deferred_cost(ticket) waits for that copy only (not for the step's updates). At most
+ * NVSM_MAX_DEFERRED tickets may be outstanding (older ones are overwritten). nvsm_wait_inputs returns once the last
+ * queued step has copied its host batch to the device, i.e. once the caller may refill those host buffers; a loop that
+ * calls it before refilling and reads each loss one step late keeps one whole step queued ahead of the GPU. */
+#define NVSM_MAX_DEFERRED 8
+int nvsm_step_deferred(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids, float learning_rate, int64_t* ticket);
+int nvsm_deferred_cost(nvsm_model* m, int64_t ticket, float* cost);
+int nvsm_wait_inputs(nvsm_model* m);
+
 /* Intermediates / gradients of the last compute_cost / compute_gradients, for parity tests and the
  * gradient checker (Parameters::get_parameter_gradient, cpp/storage.cu:133-183,264-283). Names:
  *   "phrase" [B][dw], "pre" [B][de], "proj" [B][de], "probs" [B*R], "entity_ids" [B*R] (as float),

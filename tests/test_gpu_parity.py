@@ -298,3 +298,30 @@ def test_error_behaviour():
     assert e.value.status == 1
     with pytest.raises(ca.NvsmError):
         g.initialize(0)                                                                 # cpp/main.cu:708
+
+
+def test_deferred_cost_equals_immediate_cost():
+    """nvsm_step_deferred + nvsm_deferred_cost (the trainer's loop: the loss of batch k is read after batch k+1 has been
+    queued) return what nvsm_step returns, and leave the same parameters."""
+    spec = dict(SPECS["nvsm"], update_method="sparse_adam")
+    B = 512
+    o, a, rs = _pair(spec, B, 21)
+    b = gpu_model(spec, B)
+    for n in PARAMS:
+        b.set_param(n, a.get_param(n))
+    batches = [random_batch(spec, rs, B, zipf=True) for _ in range(5)]
+    want = [a.step(ca.Batch(w, l, ww, iw), 1e-3, entity_ids=ids, want_cost=True) for (w, ww, l, iw, ids) in batches]
+    tickets = []
+    for (w, ww, l, iw, ids) in batches:
+        b.wait_inputs()
+        tickets.append(b.step_deferred(ca.Batch(w, l, ww, iw), 1e-3, entity_ids=ids))
+    got = [b.deferred_cost(t) for t in tickets]
+    assert got == want
+    for n in PARAMS:
+        np.testing.assert_array_equal(a.get_param(n), b.get_param(n))
+    with pytest.raises(ca.NvsmError):
+        b.deferred_cost(tickets[-1] + 1)                  # never issued
+    for (w, ww, l, iw, ids) in batches * 2:               # ten more steps: the first tickets fall out of the window
+        b.step_deferred(ca.Batch(w, l, ww, iw), 1e-3, entity_ids=ids)
+    with pytest.raises(ca.NvsmError):
+        b.deferred_cost(tickets[0])

@@ -85,6 +85,16 @@ class Model {
         return c;
     }
 
+    // the same loop body with the loss read back one step late (cpp/main.cu:427-444 without the per-step stall):
+    //   wait_inputs(); refill the host batch; t = step_deferred(batch, lr); cost of the PREVIOUS step = deferred_cost(t_prev)
+    int64_t step_deferred(const Batch& batch, float learning_rate) {
+        int64_t t = 0;
+        check(nvsm_step_deferred(h_, &batch.raw, nullptr, learning_rate, &t));
+        return t;
+    }
+    float deferred_cost(int64_t ticket) { float c = 0.f; check(nvsm_deferred_cost(h_, ticket, &c)); return c; }
+    void wait_inputs() { check(nvsm_wait_inputs(h_)); }
+
     // ModelBase::get_data() (cpp/model.cu:64-93): name → host copy, in the layout write_to_hdf5 expects
     std::map<std::string, std::vector<float>> get_data() {
         static const char* names[] = {"word_representations-representations", "entity_representations-representations",

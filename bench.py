@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default 51200)")
     ap.add_argument("--num-words", type=int, default=None)
     ap.add_argument("--num-entities", type=int, default=None)
+    ap.add_argument("--strong-scaling", action="store_true", help="BASELINE configs[2] read literally: the 51 200-window batch is "
+                    "split over the ranks (51 200 / N each) instead of every rank getting its own 51 200 windows")
     ap.add_argument("--uniform-words", action="store_true", help="uniform instead of Zipf(1) word ids (worst case for caches)")
     ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step (PCIe-inclusive rate)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="full-size steps of the CPU oracle timed for cpu_baseline (≈1 s each on 128 cores)")
@@ -190,6 +192,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     wl = workload(args)
+    if args.strong_scaling and world > 1:
+        wl["batch"] = wl["batch"] // world
     method = args.update_method
     cfg = ca.default_config(num_words=wl["num_words"], num_entities=wl["num_entities"], word_repr_size=wl["word_dim"],
                             entity_repr_size=wl["entity_dim"], window_size=wl["window"],
@@ -329,7 +333,7 @@ def main():
             "metric": "n-gram windows/sec (batch=51200, NVSM config)" if args.config == "nvsm" and B == 51200
                       else "n-gram windows/sec (--config %s, batch=%d)" % (args.config, B), "value": round(value, 1), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if (args.strong_scaling and world > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s synthetic |V|=%d |D|=%d d_word=%d d_doc=256 window=10 neg=16 batch=%d/GPU "
                                    "%s%s %s lambda=1e-2 lr=%g %s word ids, inputs resident in HBM, device negative sampler"
                                    % ("NVSM" if wl["batch_norm"] else "LSE", wl["num_words"], wl["num_entities"], wl["word_dim"], B,

@@ -728,10 +728,11 @@ void Model::update_words(float lr, float sl) {
     }
     if (method == NVSM_ADAGRAD) {
         RowPassArgs s = a;                                             // accumulator pass (updates_adagrad.cu:136-158)
-        s.kind = ROW_SCALAR_ACC; s.sq_src = msq_w_.p; s.dense = 1;
-        s.sc_in = t.sc[t.sc_cur].p; s.sc_out = t.sc[t.sc_cur ^ 1].p;
+        // the row's accumulator is read and written by one lane only (no other lane of the row's group looks at it), so
+        // it is updated in place: rows without entries keep their value without being visited at all
+        s.kind = ROW_SCALAR_ACC; s.sq_src = msq_w_.p; s.dense = 0;
+        s.sc_in = t.sc[t.sc_cur].p; s.sc_out = t.sc[t.sc_cur].p;
         { PROF("adagrad_acc_words"); launch_chunk_pass(c, s, stream_); launch_row_pass(c, s, stream_); }
-        t.sc_cur ^= 1;
         { PROF("adagrad_scale_words"); launch_adagrad_scale(t.sc[t.sc_cur].p, widx_.p, w, B_, 1e-6f, scale_w_.p, stream_); }
         a.kind = ROW_SGD; a.src_scale = scale_w_.p; a.dense = sl > 0.f;
         { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }

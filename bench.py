@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--num-entities", type=int, default=None)
     ap.add_argument("--strong-scaling", action="store_true", help="BASELINE configs[2] read literally: the 51 200-window batch is "
                     "split over the ranks (51 200 / N each) instead of every rank getting its own 51 200 windows")
+    ap.add_argument("--test-shared-gpu", action="store_true", help="test of the N > 1 control flow on a 1-GPU box: every rank on "
+                    "device 0, gloo rendezvous, all-reduces through the host-callback transport (not a measurement)")
     ap.add_argument("--uniform-words", action="store_true", help="uniform instead of Zipf(1) word ids (worst case for caches)")
     ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step (PCIe-inclusive rate)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="full-size steps of the CPU oracle timed for cpu_baseline (≈1 s each on 128 cores)")
@@ -184,12 +186,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.test_shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if args.test_shared_gpu else "nccl", rank=rank, world_size=world)
 
     wl = workload(args)
     if args.strong_scaling and world > 1:
@@ -208,8 +212,10 @@ def main():
     if world > 1:
         # the engine's own RCCL communicator (all-reduces on its stream, no host round trip); if it cannot be built on
         # this node, fall back to torch.distributed through the host-callback transport so that the run still completes
-        ok = torch.zeros(1, device="cuda")
+        ok = torch.zeros(1, device="cpu" if args.test_shared_gpu else "cuda")
         try:
+            if args.test_shared_gpu:
+                raise RuntimeError("shared-GPU test: RCCL cannot put two ranks on one device")
             obj = [comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(obj, src=0)
             model.comm_init(obj[0])
@@ -221,8 +227,12 @@ def main():
             transport = "rccl"
         else:
             from cunvsm_amd import dp
-            model.set_allreduce_callback(dp.torch_allreduce_device(dist, torch.device("cuda", local_rank)))
-            transport = "torch.distributed(nccl) via host callback"
+            if args.test_shared_gpu:
+                model.set_allreduce_callback(dp.torch_allreduce(dist))
+                transport = "torch.distributed(gloo) via host callback"
+            else:
+                model.set_allreduce_callback(dp.torch_allreduce_device(dist, torch.device("cuda", local_rank)))
+                transport = "torch.distributed(nccl) via host callback"
 
     # synthetic batches, resident in HBM before the timed region
     rs = np.random.RandomState(1234 + rank)
@@ -280,7 +290,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.test_shared_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_cost = model.get_cost()

@@ -1,0 +1,60 @@
+"""bench.py's contract (one JSON line from rank 0 with the fields the driver reads), for N = 1 and — control flow only —
+for N = 2: two ranks under torch.distributed.run sharing GPU 0 (`--test-shared-gpu`: gloo rendezvous, all-reduces through
+the host-callback transport), i.e. the barriers, the max-over-ranks timing and the sharded batches of the multi-GPU run
+without the second GPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-steps", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["value"] > 1e6 and abs(d["value"] - 51200 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.3 < roof["frac"] < 1.0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "windows/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_two_ranks_control_flow():
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--test-shared-gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 51200 and d["config"]["parallelism"] == "dp2"
+    assert d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 51200 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    assert d["final_cost"] == d["final_cost"] and d["final_cost"] > 0          # finite global loss

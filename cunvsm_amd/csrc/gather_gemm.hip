@@ -524,31 +524,9 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-__global__ void sample_entities_kernel(const int64_t* __restrict__ labels, int64_t N, int R, uint64_t num_entities,
-                                       uint64_t seed, uint64_t step, int* __restrict__ ids) {
-    for (int64_t j = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; j < N;
-         j += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int64_t b = j / R;
-        const int r = static_cast<int>(j - b * R);
-        if (r == 0) {
-            ids[j] = static_cast<int>(labels[b]);
-        } else {
-            const uint64_t h = splitmix64(splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + static_cast<uint64_t>(j));
-            ids[j] = static_cast<int>(__umul64hi(h, num_entities));
-        }
-    }
-}
-void launch_sample_entities(const int64_t* labels, int64_t B, int R, int64_t num_entities, uint64_t seed,
-                            uint64_t step, int* ids, hipStream_t s) {
-    const int64_t N = B * R;
-    if (N > 0)
-        hipLaunchKernelGGL(sample_entities_kernel, dim3(stream_grid(N, 256)), dim3(256), 0, s, labels, N, R,
-                           static_cast<uint64_t>(num_entities), seed, step, ids);
-}
-
 // One launch for the start of a step in device-sampler mode (instead of memset + narrow + sample: four launches with
 // their boundaries on the critical stream while nothing else is running): zero the step's statistics words, narrow
-// the int64 word ids and draw the document ids. Same per-element arithmetic as the kernels above.
+// the int64 word ids and draw the document ids (splitmix64 above, keyed by seed, step and b·R + r).
 __global__ void step_prologue_kernel(const int64_t* __restrict__ words64, int* __restrict__ widx, int64_t nW,
                                      const int64_t* __restrict__ labels, int64_t N, int R, uint64_t num_entities,
                                      uint64_t seed, uint64_t step, int* __restrict__ ids,

@@ -38,9 +38,6 @@ void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* i
                   float* dgamma, float* grad_bias, double n_global, int64_t rows, int dim, hipStream_t s);
 void launch_colsum_finalize(const double* sums, int dim, float* out, hipStream_t s);   // no-BN grad_bias = Σdy
 
-// ---- negative sampling on device (F2; same distribution as cpp/labels.cu:4-22) ----------------
-void launch_sample_entities(const int64_t* labels, int64_t B, int R, int64_t num_entities, uint64_t seed,
-                            uint64_t step, int* ids, hipStream_t s);
 void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, hipStream_t s);
 void launch_step_prologue(const int64_t* words64, int* widx, int64_t nW, const int64_t* labels, int64_t B, int R,
                           int64_t num_entities, uint64_t seed, uint64_t step, int* ids, double* stats, int nstats,

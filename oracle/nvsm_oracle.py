@@ -26,8 +26,12 @@ PARAM_NAMES = (
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO):
-        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
+    # `make` every time: a no-op when the library is newer than its sources, a rebuild when a source changed
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(_SO):
+            raise
     return _SO
 
 
@@ -75,7 +79,7 @@ def lib():
         "orc_model_update": (C.c_int, [vp, dbl, dbl]), "orc_model_scaled_lambda": (dbl, [vp]),
         "orc_model_set_allreduce": (None, [vp, ALLREDUCE_FN, vp, C.c_int]),
         "orc_model_gradcheck": (C.c_int, [vp, vp, vp, vp, vp, i64, dbl, dbl, P(dbl), P(C.c_int)]),
-        "orc_num_threads": (C.c_int, []),
+        "orc_num_threads": (C.c_int, []), "orc_set_num_threads": (None, [C.c_int]),
         "orc_reps_create": (vp, [i64, i64, C.c_int, C.c_int, dbl, dbl, dbl, C.c_int]), "orc_reps_free": (None, [vp]),
         "orc_reps_fill": (None, [vp, dbl]), "orc_reps_set": (None, [vp, vp]), "orc_reps_get": (i64, [vp, C.c_int, vp]),
         "orc_reps_update": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, dbl, dbl]),

@@ -143,8 +143,9 @@ def cpu_baseline(args, wl, method):
         if s >= warm:
             t_total += dt
     return {"value": B * steps / t_total, "unit": "windows/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
-            "sample": "%d full steps (batch %d) of the fp32 OpenMP oracle after %d warm-up, incl. host negative sampling"
-                      % (steps, B, warm)}
+            "sample": "%d full steps (batch %d) of the fp32 OpenMP oracle after %d warm-up, incl. host negative sampling; OpenMP team = "
+                      "the CPUs the process may use (affinity mask capped by the cgroup quota), %d hardware threads visible"
+                      % (steps, B, warm, os.cpu_count() or 0)}
 
 
 def main():
@@ -163,7 +164,8 @@ def main():
                     "device 0, gloo rendezvous, all-reduces through the host-callback transport (not a measurement)")
     ap.add_argument("--uniform-words", action="store_true", help="uniform instead of Zipf(1) word ids (worst case for caches)")
     ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step (PCIe-inclusive rate)")
-    ap.add_argument("--cpu-steps", type=int, default=10, help="full-size steps of the CPU oracle timed for cpu_baseline (≈1 s each on 128 cores)")
+    ap.add_argument("--cpu-steps", type=int, default=30, help="full-size steps of the CPU oracle timed for cpu_baseline (≈0.3 s each on the "
+                    "16 CPUs the GPU box grants the process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sequential", action="store_true", help="compute_cost / compute_gradients / update as separate calls on one stream "
                     "(un-overlapped per-kernel timings) instead of the fused multi-stream nvsm_step")

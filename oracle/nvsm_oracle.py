@@ -47,6 +47,26 @@ class OrcConfig(C.Structure):
     ]
 
 
+def effective_cpus():
+    """CPUs this process can actually use: the affinity mask capped by the cgroup CPU quota. (The GPU box shows 256
+    hardware threads and grants 16 CPUs of time: an OpenMP team of 256 then runs a step 17x slower than a team of 16.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # v1
+                quota, period = int(f.read()), int(g.read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
 
 _lib = None
@@ -101,7 +121,14 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     _lib = L
+    set_num_threads(0)
     return L
+
+
+def set_num_threads(n):
+    """OpenMP team of the oracle: n threads, capped by effective_cpus(); n <= 0 = every CPU the process may use."""
+    cap = effective_cpus()
+    lib().orc_set_num_threads(cap if n <= 0 else min(int(n), cap))
 
 
 def _p(a):

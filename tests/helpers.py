@@ -31,7 +31,7 @@ def oracle_model(spec, dtype=orc.F64):
     # the OpenMP team: every core for the full-size problems, a handful for the small ones (a parallel region over the
     # 256 hardware threads of the GPU box costs more than a small loop)
     big = max(spec["num_words"] * spec["word_dim"], spec["num_entities"] * spec["entity_dim"]) >= 4_000_000
-    orc.lib().orc_set_num_threads(0 if big else 8)
+    orc.set_num_threads(0 if big else 8)
     return orc.Model(cfg, dtype)
 
 

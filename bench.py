@@ -259,6 +259,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if world > 1:
+        # communicator set-up (connections, first-use kernels) is lazy: two untimed steps take it out of the way even when
+        # the caller asks for no warm-up steps
+        for s in range(2):
+            model.step(pool[s % len(pool)], lr)
     for s in range(args.warmup):
         model.step(pool[s % len(pool)], lr)
     sync_all()

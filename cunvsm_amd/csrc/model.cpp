@@ -799,11 +799,13 @@ void Model::update(float lr, float scaled_lambda) {
     have_grads_ = false;      // gradients are consumed (the reference's optimisers overwrite them too)
 }
 
-// One loop body of iterate_data (cpp/main.cu:400-444). With everything known up front the three independent chains of
-// the backward half run concurrently instead of back to back:
-//   side stream : documents update (needs only the loss kernel's outputs; HBM bound) → dT GEMM + reduce (MFMA bound)
-//                 → projection update (after the dx GEMM has read T)
-//   main stream : batch-norm backward → dx GEMM (MFMA bound) → words update (L2 / HBM bound)
+// One loop body of iterate_data (cpp/main.cu:400-444). With everything known up front the independent chains of the
+// backward half run concurrently instead of back to back:
+//   main stream   : batch-norm backward → dx GEMM (MFMA bound) → words update (L2 / HBM bound)
+//   side stream 1 : [documents CSR build] → documents update (needs only the loss kernel's outputs; HBM bound)
+//   side stream 2 : [words CSR build] → dT GEMM + reduce (MFMA bound) → (all-reduce) → projection update (after the dx
+//                   GEMM has read T)
+// and the two side-stream tails are joined by the NEXT compute_cost where it needs T and E (join_T / join_E), not here.
 // Results are identical to compute_cost; compute_gradients; update — only the interleaving differs.
 void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, float* cost) {
     compute_cost(batch, entity_ids);

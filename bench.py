@@ -328,6 +328,7 @@ def main():
                 ent["algorithmic_GBps"] = round(ab / (avg * 1e-3) / 1e9, 1)
             if k.startswith("gemm_"):
                 ent["TFLOPs"] = round(gemm_flops(wl) / (avg * 1e-3) / 1e12, 1)
+                ent["mfma_frac"] = round(ent["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 3)      # of the 157.3 TF/s fp32 MFMA peak
             breakdown[k] = ent
         # Roofline kernel: the document-embedding gather + loss kernel — the HBM gather the north star names, and the
         # largest kernel of the step that runs with nothing else next to it but the (tiny) side-stream sorts. In the fused

@@ -79,7 +79,6 @@ def algorithmic_bytes(kernel, wl, method):
         "row_pass_words_mv": word_gather + 2 * nV * dw * F,
         "row_pass_words_u": word_gather + 2 * nV * dw * F,
         "adam_u_words": word_gather + B * dw * F,
-        "bn_stats": B * de * F,
         "bn_backward": 3 * B * de * F,
     }
     return table.get(kernel)

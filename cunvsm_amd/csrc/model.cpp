@@ -496,11 +496,11 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
     const double bn_n = (cfg_.world_size > 1 && cfg_.sync_batch_norm) ? B_global : static_cast<double>(B);
     // F6: batch statistics (cudnn_utils.cu:107-124), ε = 1e-4 (objective.cu:114)
-    if (cfg_.batch_normalization) {
-        PROF("bn_stats");
-        if (cfg_.world_size > 1 && cfg_.sync_batch_norm) allreduce_f64(stats_fwd_, 2 * de);
-        // (μ and 1/sqrt(σ²+ε) themselves are evaluated by the loss kernel from these sums)
+    if (cfg_.batch_normalization && cfg_.world_size > 1 && cfg_.sync_batch_norm) {
+        PROF("allreduce_bn_stats");
+        allreduce_f64(stats_fwd_, 2 * de);
     }
+    // (μ and 1/sqrt(σ²+ε) themselves are evaluated by the loss kernel from these sums)
 
     // F7–F16 + B1–B4: fused loss
     join_E();        // the previous step's documents update: reads proj / coef, writes E

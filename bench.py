@@ -238,13 +238,15 @@ def main():
     # synthetic batches, resident in HBM before the timed region
     rs = np.random.RandomState(1234 + rank)
     B, w = wl["batch"], wl["window"]
-    pool = []
+    pool, pinned_keep = [], []
     for _ in range(4):
         words = (rs.randint(0, wl["num_words"], B * w).astype(np.int64) if args.uniform_words
                  else zipf_ids(rs, wl["num_words"], B * w))
         labels = rs.randint(0, wl["num_entities"], B).astype(np.int64)
-        if args.host_batches:
-            pool.append(ca.Batch(words, labels, np.ones(B * w, np.float32), np.ones(B, np.float32)))
+        if args.host_batches:        # page-locked host buffers, as the trainer's (and the reference's) batches are
+            pins = [ca.model.pinned_copy(x) for x in (words, labels, np.ones(B * w, np.float32), np.ones(B, np.float32))]
+            pinned_keep.append(pins)
+            pool.append(ca.Batch(pins[0].array, pins[1].array, pins[2].array, pins[3].array))
         else:
             dev = torch.device("cuda", local_rank)
             pool.append(ca.Batch(torch.from_numpy(words).to(dev), torch.from_numpy(labels).to(dev),

@@ -230,11 +230,13 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         own_stream_ = true;
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, lo));
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux2_stream_, hipStreamNonBlocking, lo));
+        NVSM_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     }
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, hipEventDisableTiming));
-    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_}) NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_copied_, &ev_step_begin_[0], &ev_step_begin_[1]})
+        NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
 
     const int dw = cfg.word_repr_size, de = cfg.entity_repr_size, w = cfg.window_size;
     const int64_t N = B * R_;
@@ -244,7 +246,8 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     if (cfg.update_method != NVSM_SGD) { s0T_.alloc(static_cast<size_t>(de) * dw, true); s0b_.alloc(de, true); }
     if (cfg.update_method == NVSM_ADAM) { s1T_.alloc(static_cast<size_t>(de) * dw, true); s1b_.alloc(de, true); }
 
-    in_words_.alloc(B * w); in_labels_.alloc(B); in_ids64_.alloc(N); in_wwts_.alloc(B * w); in_instw_.alloc(B);
+    for (int p = 0; p < 2; ++p) { in_words_[p].alloc(B * w); in_labels_[p].alloc(B); in_wwts_[p].alloc(B * w); in_instw_[p].alloc(B); }
+    in_ids64_.alloc(N);
     widx_.alloc(B * w); ids_.alloc(N); iota_.alloc(std::max<int64_t>(B * w, N));
     launch_iota(iota_.p, static_cast<int64_t>(iota_.n), stream_);
     phrase_.alloc(B * dw); phrase_alt_.alloc(B * dw); phrase_p_ = phrase_.p; pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
@@ -268,7 +271,8 @@ Model::~Model() {
     if (ev_csr_ents_) (void)hipEventDestroy(ev_csr_ents_);
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
-    for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_, ev_copied_, ev_step_begin_[0], ev_step_begin_[1]}) if (e) (void)hipEventDestroy(e);
+    if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
     for (DeferredCost& d : deferred_) { if (d.ev) (void)hipEventDestroy(d.ev); if (d.host) (void)hipHostFree(d.host); }
     if (comm_ && rccl_) rccl_->CommDestroy(comm_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
@@ -285,6 +289,7 @@ void Model::synchronize() {
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(aux_stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(aux2_stream_));
+    NVSM_HIP_CHECK(hipStreamSynchronize(copy_stream_));
     E_pending_ = T_pending_ = false;
 }
 
@@ -413,20 +418,32 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             wwts_ = batch.feature_weights;
             instw_ = batch.weights;
         } else {
-            NVSM_HIP_CHECK(hipMemcpyAsync(in_words_.p, batch.features, B * w * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
-            NVSM_HIP_CHECK(hipMemcpyAsync(in_labels_.p, batch.labels, B * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
-            words_dev = in_words_.p;
-            labels_dev_ = in_labels_.p;
+            // Host batch: the four arrays go to the device on a copy stream of their own, into the staging set the step
+            // before last used — so the copies of step k run while step k-1 is still computing (the caller, running
+            // ahead, has usually queued them by then) instead of sitting in front of step k on the main stream.
+            // ev_step_begin_[p] was recorded on the main stream when the previous step's compute_cost started, i.e. behind
+            // everything the step before that one — the last reader of this staging set — had queued there.
+            const int p = in_parity_ ^= 1;
+            NVSM_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_step_begin_[p ^ 1], 0));
+            NVSM_HIP_CHECK(hipEventRecord(ev_step_begin_[p], stream_));
+            NVSM_HIP_CHECK(hipMemcpyAsync(in_words_[p].p, batch.features, B * w * sizeof(int64_t), hipMemcpyHostToDevice, copy_stream_));
+            NVSM_HIP_CHECK(hipMemcpyAsync(in_labels_[p].p, batch.labels, B * sizeof(int64_t), hipMemcpyHostToDevice, copy_stream_));
+            words_dev = in_words_[p].p;
+            labels_dev_ = in_labels_[p].p;
             wwts_ = nullptr; instw_ = nullptr;
             if (batch.feature_weights) {
-                NVSM_HIP_CHECK(hipMemcpyAsync(in_wwts_.p, batch.feature_weights, B * w * sizeof(float), hipMemcpyHostToDevice, stream_));
-                wwts_ = in_wwts_.p;
+                NVSM_HIP_CHECK(hipMemcpyAsync(in_wwts_[p].p, batch.feature_weights, B * w * sizeof(float), hipMemcpyHostToDevice, copy_stream_));
+                wwts_ = in_wwts_[p].p;
             }
             if (batch.weights) {
-                NVSM_HIP_CHECK(hipMemcpyAsync(in_instw_.p, batch.weights, B * sizeof(float), hipMemcpyHostToDevice, stream_));
-                instw_ = in_instw_.p;
+                NVSM_HIP_CHECK(hipMemcpyAsync(in_instw_[p].p, batch.weights, B * sizeof(float), hipMemcpyHostToDevice, copy_stream_));
+                instw_ = in_instw_[p].p;
             }
+            NVSM_HIP_CHECK(hipEventRecord(ev_copied_, copy_stream_));
+            NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_copied_, 0));
+            copied_recorded_ = true;
         }
+        last_batch_on_host_ = !batch.on_device;
         if (!fused_prologue) launch_narrow_i64(words_dev, widx_.p, B * w, stream_);
     }
 
@@ -872,7 +889,11 @@ float Model::deferred_cost(int64_t ticket) {
 }
 
 void Model::wait_inputs() {
-    if (inputs_recorded_) NVSM_HIP_CHECK(hipEventSynchronize(ev_inputs_));
+    // a host batch has been consumed once the copy stream is through with it; a device-resident one once the step's
+    // prologue and gather have read it (ev_inputs_ sits behind the prologue; the feature weights are read later still,
+    // but device-resident batches are the caller's to keep alive until the step has run)
+    if (last_batch_on_host_) { if (copied_recorded_) NVSM_HIP_CHECK(hipEventSynchronize(ev_copied_)); }
+    else if (inputs_recorded_) NVSM_HIP_CHECK(hipEventSynchronize(ev_inputs_));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -167,8 +167,12 @@ class Model {
     uint64_t t_transform_ = 1;
 
     // per-step inputs
-    DevBuf<int64_t> in_words_, in_labels_, in_ids64_;
-    DevBuf<float> in_wwts_, in_instw_;
+    DevBuf<int64_t> in_words_[2], in_labels_[2], in_ids64_;      // host batches: two staging sets (see compute_cost)
+    DevBuf<float> in_wwts_[2], in_instw_[2];
+    int in_parity_ = 0;
+    hipStream_t copy_stream_ = nullptr;
+    hipEvent_t ev_copied_ = nullptr, ev_step_begin_[2] = {nullptr, nullptr};
+    bool copied_recorded_ = false, last_batch_on_host_ = false;
     DevBuf<int> widx_, ids_, iota_;
     const float* wwts_ = nullptr;     // device pointer or null
     const float* instw_ = nullptr;

@@ -46,6 +46,35 @@ def default_config(**overrides):
     return cfg
 
 
+class PinnedArray:
+    """A numpy array over page-locked host memory from nvsm_host_alloc — what the reference's Batch allocates with
+    cudaHostAlloc (cpp/data.cu:8-40): host→device copies from it are asynchronous. `.array` is the numpy view."""
+
+    def __init__(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape))
+        self._ptr = C.c_void_p()
+        check(lib().nvsm_host_alloc(max(1, n * dtype.itemsize), C.byref(self._ptr)))
+        buf = (C.c_char * (n * dtype.itemsize)).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                lib().nvsm_host_free(self._ptr)
+                self._ptr = None
+        except Exception:   # pragma: no cover  (interpreter shutdown)
+            pass
+
+
+def pinned_copy(a):
+    """Copy of `a` in page-locked memory; keep the returned PinnedArray alive as long as its .array is in use."""
+    a = np.asarray(a)
+    p = PinnedArray(a.shape, a.dtype)
+    p.array[...] = a
+    return p
+
+
 class Batch:
     """TextEntity::Batch (include/cuNVSM/data.h:114-177): features [B*w] int64, feature_weights [B*w] float,
     labels [B] int64, weights [B] float. Arrays may be numpy (host) or torch CUDA tensors (already in HBM)."""

@@ -122,6 +122,7 @@ class Model {
     void wait_inputs();
     void synchronize();
     void debug_delay(int microseconds);
+    void draw_reference_negatives(const int64_t* labels, int64_t B, int64_t* ids);
     void join_T();
     void join_E();
     void join_aux() { join_T(); join_E(); }

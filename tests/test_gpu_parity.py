@@ -106,6 +106,30 @@ def test_initialize_and_host_sampler_match_reference_rng():
     assert g.rng_state == rng.state
 
 
+@pytest.mark.parametrize("num_entities", [1, 2, 3, 7, 1000, 65536, 100000, 1234567, 16777217])
+@pytest.mark.parametrize("seed", [1, 2147483646])
+def test_host_sampler_replays_std_uniform_int_distribution(num_entities, seed):
+    """The engine's written-out replay of `std::uniform_int_distribution<long>(0, |D|-1)(minstd_rand0)` (model.cpp:
+    draw_reference_negatives) against the oracle, which makes the std:: calls themselves: same ids and the same generator
+    state afterwards, over table sizes that exercise the rejection loop and the quotient's rounding (three batches each)."""
+    spec = dict(num_words=5, num_entities=num_entities, word_dim=1, entity_dim=1, window=1, num_random=20)
+    B = 257
+    g = gpu_model(spec, B, sampler=ca.SAMPLER_HOST_MINSTD)
+    g.initialize(3)
+    g.rng_state = seed
+    rng = orc.Rng(3)
+    rng.state = seed
+    rs = np.random.RandomState(num_entities % 1000)
+    for _ in range(3):
+        words, ww, labels, iw, _ = random_batch(spec, rs, B)
+        g.compute_cost(ca.Batch(words, labels, ww, iw))
+        expect = rng.generate_labels(labels, num_entities, 20)
+        got = g.get_tensor("entity_ids").astype(np.int64)
+        if num_entities <= (1 << 24):                    # get_tensor hands ids back as float32: exact up to 2^24
+            np.testing.assert_array_equal(got, expect)
+        assert g.rng_state == rng.state
+
+
 # ---------------------------------------------------------------------------------------------
 # the reference's own end-to-end KAT (cpp/model_tests.cu:341-466) through the HIP path
 # ---------------------------------------------------------------------------------------------

@@ -349,3 +349,45 @@ def test_deferred_cost_equals_immediate_cost():
         b.step_deferred(ca.Batch(w, l, ww, iw), 1e-3, entity_ids=ids)
     with pytest.raises(ca.NvsmError):
         b.deferred_cost(tickets[0])
+
+
+def test_mixed_host_and_device_batches_ragged_sizes_back_to_back():
+    """Thirty fused steps queued without a host wait — host batches (page-locked and pageable) and device-resident
+    batches interleaved, batch sizes changing from step to step — leave exactly the parameters that separate, fully
+    ordered calls leave (double-buffered host staging on the copy stream, deferred side-stream joins, ragged batches)."""
+    import torch
+    spec = dict(SPECS["nvsm"], update_method="sparse_adam")
+    Bmax = 1536
+    rs = np.random.RandomState(99)
+    params = random_params(spec, rs)
+    a, b = gpu_model(spec, Bmax, sampler=ca.SAMPLER_DEVICE), gpu_model(spec, Bmax, sampler=ca.SAMPLER_DEVICE)
+    for m in (a, b):
+        m.initialize(11)
+        load_params(m, params, True)
+    dev = torch.device("cuda", 0)
+    plan, keep = [], []
+    for s in range(30):
+        B = int(rs.choice([1, 7, 256, 1000, 1024, 1536]))
+        words, ww, labels, iw, _ = random_batch(spec, rs, B, zipf=True)
+        kind = s % 3
+        if kind == 0:
+            fused = ca.Batch(words, labels, ww, iw)                                   # pageable host memory
+        elif kind == 1:
+            pins = [ca.model.pinned_copy(x) for x in (words, labels, ww, iw)]
+            keep.append(pins)
+            fused = ca.Batch(pins[0].array, pins[1].array, pins[2].array, pins[3].array)
+        else:
+            fused = ca.Batch(torch.from_numpy(words).to(dev), torch.from_numpy(labels).to(dev),
+                             torch.from_numpy(ww).to(dev), torch.from_numpy(iw).to(dev))
+        plan.append((fused, ca.Batch(words, labels, ww, iw)))
+    tickets = [b.step_deferred(fused, 1e-3) for fused, _ in plan]
+    costs_b = [b.deferred_cost(t) for t in tickets[-8:]]
+    costs_a = []
+    for _, host in plan:
+        a.compute_cost(host)
+        a.compute_gradients()
+        costs_a.append(a.get_cost())
+        a.update(1e-3)
+    assert costs_b == costs_a[-8:]
+    for n in PARAMS:
+        np.testing.assert_array_equal(a.get_param(n), b.get_param(n))

@@ -1,4 +1,4 @@
-"""Randomised sweep of the HIP path against the fp64 oracle: 40 seeded configurations drawn over table sizes (from a
+"""Randomised sweep of the HIP path against the fp64 oracle: 120 seeded configurations drawn over table sizes (from a
 single row to tables much larger than the batch), odd and vectorisable dimensions, window 1…12, 1…20 negatives, batches
 of 1…700 windows, both nonlinearities, batch-norm, biased negatives, λ ∈ {0, 0.01}, all five update methods and —
 now and then — the optional L2 normalisers. Two optimiser steps each; same tolerances as tests/test_gpu_parity.py."""
@@ -41,7 +41,7 @@ def draw_spec(rs):
     return spec, B
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(120))
 def test_random_configuration(seed):
     rs = np.random.RandomState(1000 + seed)
     spec, B = draw_spec(rs)

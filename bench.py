@@ -5,12 +5,19 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one rank per GPU,
+rendezvous on 127.0.0.1, a free port), so both call forms work.
+
 One "step" = one pass of the hot path (compute_cost → compute_gradients → update, negatives sampled on
 device) over one synthetic batch of 51 200 windows per GPU that is already resident in HBM. Workload =
 BASELINE.json configs[1]: |V| = 50k, |D| = 100k, d_word = 300, d_doc = 256, window 10, 16 negatives,
 batch 51 200, hard_tanh + batch-norm, Adam (sparse_adam; --update-method selects the others), λ = 1e-2,
-lr = 1e-3, Zipf(1) word ids, uniform document ids, all weights 1. Weak scaling: every rank gets its own
-51 200-window batch; the dense projection gradient is all-reduced over RCCL each step.
+lr = 1e-3, Zipf(1) word ids, uniform document ids, all weights 1. `value` is the weak-scaling figure (every rank
+gets its own 51 200-window batch; the dense projection gradient and the batch-norm statistics are all-reduced over
+RCCL each step); with N > 1 the line also carries `strong` — SURVEY.md §8d row 3, the 51 200-window batch split
+51 200 / N per rank — measured in the same run. With N = 1 it also carries `value_readback_every_step` (the loss
+read back after every step, as the reference's loop does, cpp/main.cu:427-444) and `value_host_batches` (page-locked
+host batches handed over each step, PCIe inclusive) — never used for `value`.
 
 Rank 0 prints ONE JSON line. `roofline` is for the document-embedding gather + loss kernel (the largest HBM
 gather of the step), timed with HIP events on the engine's stream inside the timed region; `kernel_breakdown`
@@ -90,18 +97,28 @@ PMC_KERNEL = {"loss_fused": "loss_rows_kernel", "row_pass_entities": "row_pass_k
               "gather_mean_words": "gather_mean_kernel", "adam_u_words": "adam_u_kernel"}
 
 
-def pmc_traffic(kernel):
+def workload_signature(wl, method, uniform_words):
+    """What a PMC summary must have been taken on to say anything about this run's kernels."""
+    return "V%d_D%d_dw%d_de%d_w%d_k%d_B%d_%s_%s" % (wl["num_words"], wl["num_entities"], wl["word_dim"], wl["entity_dim"],
+                                                     wl["window"], wl["num_random"], wl["batch"], method,
+                                                     "uniform" if uniform_words else "zipf")
+
+
+def pmc_traffic(kernel, signature):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_hbm_pmc.json,
     written by tools/profile_round.sh from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
-    Counters cannot be read from inside the process; None when no summary is present."""
+    Counters cannot be read from inside the process. None unless that summary was taken on exactly this workload
+    (its "workload" key equals `signature`): a figure measured on another configuration says nothing about this one."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")))
     pref = PMC_KERNEL.get(kernel)
     if not files or not pref:
         return None, None
     with open(files[-1]) as f:
-        ks = json.load(f)["kernels"]
-    for name, e in ks.items():
+        js = json.load(f)
+    if js.get("workload") != signature:
+        return None, None
+    for name, e in js["kernels"].items():
         if name.startswith(pref):
             return int(e["fetch_bytes_corrected"] + e["write_bytes"]), os.path.basename(files[-1])
     return None, None
@@ -147,6 +164,22 @@ def cpu_baseline(args, wl, method):
                       % (steps, B, warm, os.cpu_count() or 0)}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-execute under torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1 and a free port. Rank 0's JSON line goes to this process's stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,12 +190,14 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default 51200)")
     ap.add_argument("--num-words", type=int, default=None)
     ap.add_argument("--num-entities", type=int, default=None)
-    ap.add_argument("--strong-scaling", action="store_true", help="BASELINE configs[2] read literally: the 51 200-window batch is "
-                    "split over the ranks (51 200 / N each) instead of every rank getting its own 51 200 windows")
+    ap.add_argument("--strong-scaling", action="store_true", help="make the strong split (51 200 / N windows per rank, SURVEY §8d row 3) "
+                    "the headline `value` instead of the weak one; both are always measured and reported when N > 1")
     ap.add_argument("--test-shared-gpu", action="store_true", help="test of the N > 1 control flow on a 1-GPU box: every rank on "
                     "device 0, gloo rendezvous, all-reduces through the host-callback transport (not a measurement)")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous only (gloo, no GPU): proves that the N-rank launch works")
     ap.add_argument("--uniform-words", action="store_true", help="uniform instead of Zipf(1) word ids (worst case for caches)")
-    ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step (PCIe-inclusive rate)")
+    ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step in the MAIN timed region too")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the read-back / host-batch / strong-scaling legs")
     ap.add_argument("--cpu-steps", type=int, default=30, help="full-size steps of the CPU oracle timed for cpu_baseline (≈0.3 s each on the "
                     "16 CPUs the GPU box grants the process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -175,20 +210,42 @@ def main():
     ap.add_argument("--read-cost-every", type=int, default=0, help="read the loss back every n steps (0 = never inside the timed region)")
     args = ap.parse_args()
 
-    import torch
-    import cunvsm_amd as ca
-    from cunvsm_amd.model import comm_unique_id
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+
+    import torch
+    if args.launch_check:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            n = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            n = 1
+        if rank == 0:
+            print(json.dumps({"launch_check": n, "n_gpus": world}), flush=True)
+        return
+
+    import cunvsm_amd as ca
+    from cunvsm_amd.model import comm_unique_id
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if args.test_shared_gpu:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d but only %d GPU(s) are visible (--test-shared-gpu exercises the N-rank control flow on one)"
+                         % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -197,8 +254,6 @@ def main():
         dist.init_process_group("gloo" if args.test_shared_gpu else "nccl", rank=rank, world_size=world)
 
     wl = workload(args)
-    if args.strong_scaling and world > 1:
-        wl["batch"] = wl["batch"] // world
     method = args.update_method
     cfg = ca.default_config(num_words=wl["num_words"], num_entities=wl["num_entities"], word_repr_size=wl["word_dim"],
                             entity_repr_size=wl["entity_dim"], window_size=wl["window"],
@@ -209,9 +264,9 @@ def main():
                             world_size=world, rank=rank, sync_batch_norm=1)
     model = ca.Model(cfg)
     model.initialize(1)                     # --seed 1 (scripts/functions.sh:393); identical replicas on every rank
-    transport = "single"
+    transport, comm_ranks = "single", 0
     if world > 1:
-        # the engine's own RCCL communicator (all-reduces on its stream, no host round trip); if it cannot be built on
+        # the engine's own RCCL communicator (all-reduces on its streams, no host round trip); if it cannot be built on
         # this node, fall back to torch.distributed through the host-callback transport so that the run still completes
         ok = torch.zeros(1, device="cpu" if args.test_shared_gpu else "cuda")
         try:
@@ -226,6 +281,7 @@ def main():
         dist.all_reduce(ok)
         if int(ok.item()) == world:
             transport = "rccl"
+            comm_ranks = model.comm_size()      # ncclCommCount
         else:
             from cunvsm_amd import dp
             if args.test_shared_gpu:
@@ -236,22 +292,29 @@ def main():
                 transport = "torch.distributed(nccl) via host callback"
 
     # synthetic batches, resident in HBM before the timed region
-    rs = np.random.RandomState(1234 + rank)
-    B, w = wl["batch"], wl["window"]
-    pool, pinned_keep = [], []
-    for _ in range(4):
-        words = (rs.randint(0, wl["num_words"], B * w).astype(np.int64) if args.uniform_words
-                 else zipf_ids(rs, wl["num_words"], B * w))
-        labels = rs.randint(0, wl["num_entities"], B).astype(np.int64)
-        if args.host_batches:        # page-locked host buffers, as the trainer's (and the reference's) batches are
-            pins = [ca.model.pinned_copy(x) for x in (words, labels, np.ones(B * w, np.float32), np.ones(B, np.float32))]
-            pinned_keep.append(pins)
-            pool.append(ca.Batch(pins[0].array, pins[1].array, pins[2].array, pins[3].array))
-        else:
-            dev = torch.device("cuda", local_rank)
-            pool.append(ca.Batch(torch.from_numpy(words).to(dev), torch.from_numpy(labels).to(dev),
-                                 torch.ones(B * w, dtype=torch.float32, device=dev),
-                                 torch.ones(B, dtype=torch.float32, device=dev)))
+    w = wl["window"]
+    dev = torch.device("cuda", local_rank)
+    pinned_keep = []
+
+    def make_pool(B, seed, host):
+        rs = np.random.RandomState(seed + rank)
+        pool = []
+        for _ in range(4):
+            words = (rs.randint(0, wl["num_words"], B * w).astype(np.int64) if args.uniform_words
+                     else zipf_ids(rs, wl["num_words"], B * w))
+            labels = rs.randint(0, wl["num_entities"], B).astype(np.int64)
+            if host:        # page-locked host buffers, as the trainer's (and the reference's) batches are
+                pins = [ca.model.pinned_copy(x) for x in (words, labels, np.ones(B * w, np.float32), np.ones(B, np.float32))]
+                pinned_keep.append(pins)
+                pool.append(ca.Batch(pins[0].array, pins[1].array, pins[2].array, pins[3].array))
+            else:
+                pool.append(ca.Batch(torch.from_numpy(words).to(dev), torch.from_numpy(labels).to(dev),
+                                     torch.ones(B * w, dtype=torch.float32, device=dev),
+                                     torch.ones(B, dtype=torch.float32, device=dev)))
+        return pool
+
+    B = wl["batch"]
+    pool = make_pool(B, 1234, args.host_batches)
     lr = wl["lr"]
 
     def sync_all():
@@ -260,47 +323,51 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    if world > 1:
-        # communicator set-up (connections, first-use kernels) is lazy: two untimed steps take it out of the way even when
-        # the caller asks for no warm-up steps
-        for s in range(2):
-            model.step(pool[s % len(pool)], lr)
-    for s in range(args.warmup):
-        model.step(pool[s % len(pool)], lr)
-    sync_all()
-    def run_steps(n):
+    def run_steps(n, batches, read_every=0):
         for s in range(n):
-            want = args.read_cost_every > 0 and (s + 1) % args.read_cost_every == 0
+            want = read_every > 0 and (s + 1) % read_every == 0
             if args.gate_us:
                 model.debug_delay(args.gate_us)
             if args.sequential:
-                model.compute_cost(pool[s % len(pool)])
+                model.compute_cost(batches[s % len(batches)])
                 model.compute_gradients()
                 model.update(lr)
                 if want:
                     model.get_cost()
             else:
-                model.step(pool[s % len(pool)], lr, want_cost=want)
+                model.step(batches[s % len(batches)], lr, want_cost=want)
 
-    # Timed region: HIP events around the roofline kernel only (two records per step). Events around every kernel
-    # group (~50 records per step) cost ≈5 % of the step, so the full per-kernel breakdown comes from a second,
-    # untimed pass over the same batches (--profile-all puts it back into the timed region).
-    ROOFLINE_KERNEL = "loss_fused"
+    def timed(n, batches, read_every=0):
+        """EXACTLY n steps between barrier + synchronize on both sides; MAX over ranks."""
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(n, batches, read_every)
+        model.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.test_shared_gpu else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    if world > 1:
+        # communicator set-up (connections, first-use kernels) is lazy: two untimed steps take it out of the way even when
+        # the caller asks for no warm-up steps
+        run_steps(2, pool)
+    run_steps(args.warmup, pool)
+
+    # Timed region: HIP events around the two gather kernels only (the document gather + loss kernel and the word
+    # gather-mean: four records per step). Events around every kernel group (~50 records per step) cost ≈5 % of the step,
+    # so the full per-kernel breakdown comes from a second, untimed pass over the same batches (--profile-all puts it back
+    # into the timed region).
+    ROOFLINE_KERNEL, GATHER_KERNEL = "loss_fused", "gather_mean_words"
     model.profile_enable(not args.no_profile)
-    model.profile_select(None if args.profile_all else ROOFLINE_KERNEL)
+    model.profile_select(None if args.profile_all else ROOFLINE_KERNEL + "," + GATHER_KERNEL)
     model.profile_reset()
-    sync_all()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    model.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.test_shared_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(args.steps, pool, args.read_cost_every)
     final_cost = model.get_cost()
     prof_timed = model.profile()
     prof = prof_timed
@@ -309,14 +376,43 @@ def main():
         breakdown_steps = min(args.steps, 20)
         model.profile_select(None)
         model.profile_reset()
-        run_steps(breakdown_steps)          # every rank takes part (the collectives are in the step)
+        run_steps(breakdown_steps, pool)          # every rank takes part (the collectives are in the step)
         sync_all()
         prof = model.profile()
     model.profile_enable(False)
 
+    # ---- secondary legs, same model, same number of steps, no events -------------------------------------------
+    extra = {}
+    if not args.no_extra_legs and not args.sequential and not args.gate_us:
+        if world == 1:
+            # (a) loss read back after EVERY step, as iterate_data does (cpp/main.cu:427-444; SURVEY §8d "with the loss read
+            #     back every step")
+            run_steps(2, pool, 1)
+            dt = timed(args.steps, pool, 1)
+            extra["value_readback_every_step"] = round(B * args.steps / dt, 1)
+            # (b) page-locked HOST batches handed over each step: PCIe-inclusive (never `value`)
+            if not args.host_batches:
+                hpool = make_pool(B, 1234, True)
+                run_steps(3, hpool)
+                dt = timed(args.steps, hpool)
+                extra["value_host_batches"] = round(B * args.steps / dt, 1)
+        elif B % world == 0:
+            # (c) strong split of the same global batch: 51 200 / N windows per rank (BASELINE configs[2])
+            Bs = B // world
+            spool = make_pool(Bs, 4321, args.host_batches)
+            run_steps(3, spool)
+            dt = timed(args.steps, spool)
+            extra["strong"] = {"value": round(B * args.steps / dt, 1), "unit": "windows/s", "ms_per_step": round(dt * 1e3 / args.steps, 4),
+                               "scaling": "strong", "global_batch": B, "batch_per_rank": Bs, "steps": args.steps}
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = B * world * args.steps / elapsed
+        weak = {"value": round(value, 1), "unit": "windows/s", "ms_per_step": round(ms_per_step, 4), "scaling": "weak",
+                "global_batch": B * world, "batch_per_rank": B, "steps": args.steps}
+        scaling = "weak"
+        if args.strong_scaling and "strong" in extra:
+            value, ms_per_step, scaling = extra["strong"]["value"], extra["strong"]["ms_per_step"], "strong"
         # dominant kernel group and its roofline
         breakdown = {}
         for k, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
@@ -335,37 +431,59 @@ def main():
         # largest kernel of the step that runs with nothing else next to it but the (tiny) side-stream sorts. In the fused
         # step the documents update / dT GEMM overlap the dx GEMM / words update on a second stream; their event-timed
         # durations (marked "overlapped") include the time they share the chip and are not per-kernel roofline figures.
-        for k in (() if args.sequential else ("chunk_pass_entities", "row_pass_entities", "gemm_bwd_T", "transform_update", "csr_entities", "csr_words")):
+        for k in (() if args.sequential else ("update_entities", "chunk_pass_entities", "row_pass_entities", "gemm_bwd_T", "transform_update", "csr_entities", "csr_words")):
             if k in breakdown:
                 breakdown[k]["overlapped"] = True
-        dom = ROOFLINE_KERNEL if prof_timed.get(ROOFLINE_KERNEL, (0, 0))[1] else None
-        roofline = None
-        if dom:
+        have = lambda k: prof_timed.get(k, (0, 0))[1] > 0
+        roofline = roofline_gather = None
+        sig = workload_signature(wl, method, args.uniform_words)
+        if have(ROOFLINE_KERNEL):
+            dom = ROOFLINE_KERNEL
             ab = algorithmic_bytes(dom, wl, method)
             avg = round(prof_timed[dom][0] / prof_timed[dom][1], 4)      # HIP events inside the timed region
             ach = ab / (avg * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic(dom)
+            traffic, traffic_src = pmc_traffic(dom, sig)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg}
+                        "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg,
+                        "bytes": "document gather B*(k+1)*d_doc*4 + pre/proj/dy 3*B*d_doc*4"}
+            if have(GATHER_KERNEL):
+                # SURVEY §8d's own figure: gather bytes only — (w*d_word + (k+1)*d_doc)*4 = 29 408 B per window at the NVSM
+                # shape — over the two kernels that do the gathering (word gather-mean + document gather/loss)
+                R = wl["num_random"] + 1
+                gb = B * (w * wl["word_dim"] + R * wl["entity_dim"]) * 4
+                t2 = avg + prof_timed[GATHER_KERNEL][0] / prof_timed[GATHER_KERNEL][1]
+                ach2 = gb / (t2 * 1e-3) / 1e9
+                roofline_gather = {"kernels": [GATHER_KERNEL, dom], "bound": "hbm", "achieved": round(ach2, 1), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBS, 4), "traffic": None,
+                                   "algorithmic_bytes_per_step": gb, "bytes_per_window": gb // B, "avg_ms": round(t2, 4),
+                                   "doc_gather_only_frac": round(B * R * wl["entity_dim"] * 4 / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out = {
             "metric": "n-gram windows/sec (batch=51200, NVSM config)" if args.config == "nvsm" and B == 51200
                       else "n-gram windows/sec (--config %s, batch=%d)" % (args.config, B), "value": round(value, 1), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong" if (args.strong_scaling and world > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s synthetic |V|=%d |D|=%d d_word=%d d_doc=256 window=10 neg=16 batch=%d/GPU "
-                                   "%s%s %s lambda=1e-2 lr=%g %s word ids, inputs resident in HBM, device negative sampler"
-                                   % ("NVSM" if wl["batch_norm"] else "LSE", wl["num_words"], wl["num_entities"], wl["word_dim"], B,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s synthetic |V|=%d |D|=%d d_word=%d d_doc=%d window=%d neg=%d batch=%d/GPU "
+                                   "%s%s %s lambda=1e-2 lr=%g %s word ids, inputs %s, device negative sampler"
+                                   % ("NVSM" if wl["batch_norm"] else "LSE", wl["num_words"], wl["num_entities"], wl["word_dim"],
+                                      wl["entity_dim"], w, wl["num_random"], B,
                                       wl["nonlinearity"], "+BN" if wl["batch_norm"] else "", method, wl["lr"],
-                                      "uniform" if args.uniform_words else "Zipf(1)"),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "update_method": method, "collectives": transport,
-                       "inputs": "host" if args.host_batches else "hbm", "step": "sequential calls" if args.sequential else "fused nvsm_step"},
+                                      "uniform" if args.uniform_words else "Zipf(1)",
+                                      "handed over as page-locked host buffers" if args.host_batches else "resident in HBM"),
+                       "global_batch": B * world if scaling == "weak" else B, "parallelism": "dp%d" % world, "update_method": method,
+                       "collectives": transport, "comm_ranks": comm_ranks,
+                       "inputs": "host" if args.host_batches else "hbm", "step": "sequential calls" if args.sequential else "fused nvsm_step",
+                       "workload_signature": sig},
             "roofline": roofline,
+            "roofline_gather": roofline_gather,
             "kernel_breakdown": breakdown,
             "kernel_breakdown_source": ("timed region" if args.profile_all else
                                         "separate untimed pass of %d steps with events around every kernel group" % breakdown_steps),
             "final_cost": round(float(final_cost), 6),
         }
+        if world > 1:
+            out["weak"] = weak
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, wl, method)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

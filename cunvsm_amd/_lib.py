@@ -108,6 +108,8 @@ def lib():
         "nvsm_set_stream": (C.c_int, [vp, vp]), "nvsm_synchronize": (C.c_int, [vp]),
         "nvsm_comm_unique_id": (C.c_int, [vp]), "nvsm_comm_init": (C.c_int, [vp, vp]),
         "nvsm_set_allreduce_callback": (C.c_int, [vp, ALLREDUCE_FN, vp]),
+        "nvsm_comm_size": (C.c_int, [vp, P(C.c_int)]), "nvsm_dp_average_tables": (C.c_int, [vp]),
+        "nvsm_range_push": (None, [cp]), "nvsm_range_pop": (None, []),
         "nvsm_profile_enable": (C.c_int, [vp, C.c_int]), "nvsm_profile_reset": (C.c_int, [vp]),
         "nvsm_profile_names": (C.c_int, [vp, vp, i64]), "nvsm_profile_select": (C.c_int, [vp, cp]), "nvsm_debug_delay": (C.c_int, [vp, C.c_int]),
         "nvsm_profile_get": (C.c_int, [vp, cp, P(C.c_double), P(i64)]),

@@ -8,6 +8,8 @@
 namespace cunvsm {
 void rccl_unique_id(char id[128]);
 void rccl_selftest(int device);
+void range_push(const char* name);
+void range_pop();
 }
 
 using cunvsm::Error;
@@ -146,6 +148,10 @@ int nvsm_synchronize(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->i
 
 int nvsm_comm_unique_id(char id[128]) { NVSM_REQUIRE(id); return guarded([&] { cunvsm::rccl_unique_id(id); }); }
 int nvsm_comm_init(nvsm_model* m, const char id[128]) { NVSM_REQUIRE(m); NVSM_REQUIRE(id); return guarded([&] { m->impl.comm_init(id); }); }
+int nvsm_comm_size(nvsm_model* m, int* ranks) { NVSM_REQUIRE(m); NVSM_REQUIRE(ranks); return guarded([&] { *ranks = m->impl.comm_ranks(); }); }
+int nvsm_dp_average_tables(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.average_tables(); }); }
+void nvsm_range_push(const char* name) { if (name) cunvsm::range_push(name); }
+void nvsm_range_pop(void) { cunvsm::range_pop(); }
 int nvsm_comm_selftest(int device) { return guarded([&] { cunvsm::rccl_selftest(device); }); }
 int nvsm_set_allreduce_callback(nvsm_model* m, nvsm_allreduce_fn fn, void* user) {
     NVSM_REQUIRE(m);
@@ -214,7 +220,7 @@ int nvsm_debug_gather_mean(int64_t num_rows, int dim, const float* table, const 
         NVSM_HIP_CHECK(hipMemcpy(T.p, table, T.n * sizeof(float), hipMemcpyHostToDevice));
         NVSM_HIP_CHECK(hipMemcpy(I64.p, idx, I64.n * sizeof(int64_t), hipMemcpyHostToDevice));
         if (wts) { W.alloc(num_out * window); NVSM_HIP_CHECK(hipMemcpy(W.p, wts, W.n * sizeof(float), hipMemcpyHostToDevice)); }
-        cunvsm::launch_narrow_i64(I64.p, I.p, num_out * window, nullptr);
+        cunvsm::launch_narrow_i64(I64.p, I.p, num_out * window, num_rows, nullptr, 0, nullptr);
         cunvsm::launch_gather_mean(T.p, dim, I.p, wts ? W.p : nullptr, window, num_out, O.p, nullptr);
         NVSM_HIP_CHECK(hipDeviceSynchronize());
         NVSM_HIP_CHECK(hipMemcpy(out, O.p, O.n * sizeof(float), hipMemcpyDeviceToHost));

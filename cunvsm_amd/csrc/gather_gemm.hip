@@ -488,13 +488,45 @@ void launch_splitk_reduce(const float* partial, int slabs, size_t stride, float*
 // =============================================================================================
 // small utilities
 // =============================================================================================
-__global__ void narrow_i64_kernel(const int64_t* __restrict__ src, int* __restrict__ dst, int64_t n) {
+// int64 ids of the ABI → int32, range-checked against the table they index (cpp/params.cu:75-95 and
+// cpp/storage.cu:37-49 index the tables with them unchecked): an id outside [0, limit) is replaced by row 0 and
+// `code` is stored into *err_flag — a word of page-locked host memory the engine inspects at its next
+// synchronisation point (NVSM_ERR_INVALID_ARGUMENT). The store only happens on a bad id.
+__global__ void narrow_i64_kernel(const int64_t* __restrict__ src, int* __restrict__ dst, int64_t n, int64_t limit,
+                                  int* __restrict__ err_flag, int code) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        int64_t v = src[i];
+        if (static_cast<uint64_t>(v) >= static_cast<uint64_t>(limit)) {
+            if (err_flag) *err_flag = code;
+            v = 0;
+        }
+        dst[i] = static_cast<int>(v);
+    }
+}
+void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, int64_t limit, int* err_flag, int code, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(narrow_i64_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, src, dst, n, limit, err_flag, code);
+}
+
+// NVSM_DEBUG: the reference's CHECK_MATRIX (cpp/objective.cu:134,152 …) — any non-finite element stores `code`
+__global__ void check_finite_kernel(const float* __restrict__ x, int64_t n, int* __restrict__ err_flag, int code) {
+    bool bad = false;
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x)
-        dst[i] = static_cast<int>(src[i]);
+        bad |= !isfinite(x[i]);
+    if (bad) *err_flag = code;
 }
-void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(narrow_i64_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, src, dst, n);
+void launch_check_finite(const float* x, int64_t n, int* err_flag, int code, hipStream_t s) {
+    if (n > 0 && x) hipLaunchKernelGGL(check_finite_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, x, n, err_flag, code);
+}
+
+__global__ void scale_kernel(float* __restrict__ x, int64_t n, float a) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        x[i] *= a;
+}
+void launch_scale(float* x, int64_t n, float a, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, x, n, a);
 }
 
 __global__ void delay_kernel(long long ticks) {
@@ -528,18 +560,24 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 // their boundaries on the critical stream while nothing else is running): zero the step's statistics words, narrow
 // the int64 word ids and draw the document ids (splitmix64 above, keyed by seed, step and b·R + r).
 __global__ void step_prologue_kernel(const int64_t* __restrict__ words64, int* __restrict__ widx, int64_t nW,
-                                     const int64_t* __restrict__ labels, int64_t N, int R, uint64_t num_entities,
-                                     uint64_t seed, uint64_t step, int* __restrict__ ids,
-                                     double* __restrict__ stats, int nstats) {
+                                     const int64_t* __restrict__ labels, int64_t N, int R, uint64_t num_words,
+                                     uint64_t num_entities, uint64_t seed, uint64_t step, int* __restrict__ ids,
+                                     double* __restrict__ stats, int nstats, int* __restrict__ err_flag) {
     const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     if (tid < nstats) stats[tid] = 0.0;
-    for (int64_t i = tid; i < nW; i += stride) widx[i] = static_cast<int>(words64[i]);
+    for (int64_t i = tid; i < nW; i += stride) {
+        int64_t v = words64[i];
+        if (static_cast<uint64_t>(v) >= num_words) { *err_flag = NVSM_BAD_WORD_ID; v = 0; }      // see narrow_i64_kernel
+        widx[i] = static_cast<int>(v);
+    }
     for (int64_t j = tid; j < N; j += stride) {
         const int64_t b = j / R;
         const int r = static_cast<int>(j - b * R);
         if (r == 0) {
-            ids[j] = static_cast<int>(labels[b]);
+            int64_t v = labels[b];
+            if (static_cast<uint64_t>(v) >= num_entities) { *err_flag = NVSM_BAD_ENTITY_ID; v = 0; }
+            ids[j] = static_cast<int>(v);
         } else {
             const uint64_t h = splitmix64(splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + static_cast<uint64_t>(j));
             ids[j] = static_cast<int>(__umul64hi(h, num_entities));
@@ -547,14 +585,15 @@ __global__ void step_prologue_kernel(const int64_t* __restrict__ words64, int* _
     }
 }
 void launch_step_prologue(const int64_t* words64, int* widx, int64_t nW, const int64_t* labels, int64_t B, int R,
-                          int64_t num_entities, uint64_t seed, uint64_t step, int* ids, double* stats, int nstats,
-                          hipStream_t s) {
+                          int64_t num_words, int64_t num_entities, uint64_t seed, uint64_t step, int* ids, double* stats,
+                          int nstats, int* err_flag, hipStream_t s) {
     const int64_t N = B * R;
     int grid = stream_grid(N > nW ? N : nW, 256);
     const int need = (nstats + 255) / 256;
     if (grid < need) grid = need;
     hipLaunchKernelGGL(step_prologue_kernel, dim3(grid), dim3(256), 0, s, words64, widx, nW, labels, N, R,
-                       static_cast<uint64_t>(num_entities), seed, step, ids, stats, nstats);
+                       static_cast<uint64_t>(num_words), static_cast<uint64_t>(num_entities), seed, step, ids, stats, nstats,
+                       err_flag);
 }
 
 }  // namespace cunvsm

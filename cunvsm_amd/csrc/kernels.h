@@ -38,10 +38,15 @@ void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* i
                   float* dgamma, float* grad_bias, double n_global, int64_t rows, int dim, hipStream_t s);
 void launch_colsum_finalize(const double* sums, int dim, float* out, hipStream_t s);   // no-BN grad_bias = Σdy
 
-void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, hipStream_t s);
+// codes a kernel stores into the engine's error word (page-locked host memory, read at the next synchronisation point)
+enum { NVSM_BAD_WORD_ID = 1, NVSM_BAD_ENTITY_ID = 2, NVSM_NONFINITE_BASE = 16 };
+// ids outside [0, limit) become row 0 and raise `code` in *err_flag (err_flag may be null: tests of single kernels)
+void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, int64_t limit, int* err_flag, int code, hipStream_t s);
 void launch_step_prologue(const int64_t* words64, int* widx, int64_t nW, const int64_t* labels, int64_t B, int R,
-                          int64_t num_entities, uint64_t seed, uint64_t step, int* ids, double* stats, int nstats,
-                          hipStream_t s);
+                          int64_t num_words, int64_t num_entities, uint64_t seed, uint64_t step, int* ids, double* stats,
+                          int nstats, int* err_flag, hipStream_t s);
+void launch_check_finite(const float* x, int64_t n, int* err_flag, int code, hipStream_t s);   // NVSM_DEBUG (CHECK_MATRIX)
+void launch_scale(float* x, int64_t n, float a, hipStream_t s);      // x *= a (replica averaging)
 void launch_delay(int microseconds, hipStream_t s);      // one wave spinning on the 100 MHz wall clock (profiling aid)
 void launch_iota(int* dst, int64_t n, hipStream_t s);
 

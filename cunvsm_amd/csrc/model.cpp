@@ -21,6 +21,7 @@ struct RcclApi {
     int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     static constexpr int kFloat32 = 7, kFloat64 = 8, kSum = 0;   // ncclFloat32, ncclFloat64, ncclSum
 
@@ -43,6 +44,7 @@ struct RcclApi {
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.handle, "ncclCommCount"));
         if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy)
             throw Error(NVSM_ERR_DEVICE, "librccl lacks the expected nccl* symbols");
         return &api;
@@ -103,11 +105,57 @@ void rccl_unique_id(char id[128]) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// roctx ranges (the reference brackets Epoch / Batch / FetchData / ComputeCost / ComputeGradients / UpdateParameters with
+// nvtxRangePush/Pop, cpp/main.cu:386-431, and every function with PROFILE_FUNCTION): resolved at run time from
+// librocprofiler-sdk-roctx so that a rocprofv3 --marker-trace run shows the same ranges plus one per kernel group.
+// Without the library (or with NVSM_ROCTX=0) the calls are no-ops.
+// ---------------------------------------------------------------------------------------------
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    static Roctx& get() {
+        static Roctx r = [] {
+            Roctx x;
+            const char* off = std::getenv("NVSM_ROCTX");
+            if (off && off[0] == '0') return x;
+            void* h = nullptr;
+            for (const char* n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1",
+                                  "libroctx64.so", "libroctx64.so.4"}) {
+                h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (h) break;
+            }
+            if (!h) return x;
+            x.push = reinterpret_cast<decltype(x.push)>(dlsym(h, "roctxRangePushA"));
+            x.pop = reinterpret_cast<decltype(x.pop)>(dlsym(h, "roctxRangePop"));
+            if (!x.push || !x.pop) x.push = nullptr, x.pop = nullptr;
+            return x;
+        }();
+        return r;
+    }
+};
+void range_push(const char* name) { Roctx& r = Roctx::get(); if (r.push) r.push(name); }
+void range_pop() { Roctx& r = Roctx::get(); if (r.pop) r.pop(); }
+struct RangeScope {
+    explicit RangeScope(const char* name) { range_push(name); }
+    ~RangeScope() { range_pop(); }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Profiler: HIP events on the handle's stream around each kernel group
 // ---------------------------------------------------------------------------------------------
 void Profiler::begin(const char* name, hipStream_t s) {
     if (!enabled) return;
-    if (!only.empty() && only != name) return;
+    if (!only.empty()) {                       // comma-separated list of the kernel groups to time
+        const size_t len = std::strlen(name);
+        bool hit = false;
+        for (size_t pos = 0; pos <= only.size() && !hit;) {
+            size_t end = only.find(',', pos);
+            if (end == std::string::npos) end = only.size();
+            hit = (end - pos == len) && only.compare(pos, len, name) == 0;
+            pos = end + 1;
+        }
+        if (!hit) return;
+    }
     Slot& sl = slots_[name];
     if (sl.used == sl.ev.size()) {
         hipEvent_t a, b;
@@ -153,8 +201,8 @@ Profiler::~Profiler() {
 
 struct ProfScope {
     Profiler& p; hipStream_t s;
-    ProfScope(Profiler& p_, const char* name, hipStream_t s_) : p(p_), s(s_) { p.begin(name, s); }
-    ~ProfScope() { p.end(s); }
+    ProfScope(Profiler& p_, const char* name, hipStream_t s_) : p(p_), s(s_) { range_push(name); p.begin(name, s); }
+    ~ProfScope() { p.end(s); range_pop(); }
 };
 #define PROF(name) ProfScope _prof_scope(prof, name, stream_)
 #define PROF_ON(name, strm) ProfScope _prof_scope(prof, name, strm)
@@ -235,8 +283,12 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, hipEventDisableTiming));
-    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_copied_, &ev_step_begin_[0], &ev_step_begin_[1]})
+    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_copied_, &ev_step_begin_[0], &ev_step_begin_[1],
+                          &ev_host_ids_[0], &ev_host_ids_[1]})
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&err_host_), sizeof(int), hipHostMallocDefault));
+    *err_host_ = 0;
+    { const char* d = std::getenv("NVSM_DEBUG"); debug_ = d && d[0] && d[0] != '0'; }
 
     const int dw = cfg.word_repr_size, de = cfg.entity_repr_size, w = cfg.window_size;
     const int64_t N = B * R_;
@@ -248,6 +300,9 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
 
     for (int p = 0; p < 2; ++p) { in_words_[p].alloc(B * w); in_labels_[p].alloc(B); in_wwts_[p].alloc(B * w); in_instw_[p].alloc(B); }
     in_ids64_.alloc(N);
+    if (cfg.sampler == NVSM_SAMPLER_HOST_MINSTD)
+        for (int p = 0; p < 2; ++p) NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_ids_pin_[p]), N * sizeof(int64_t), hipHostMallocDefault));
+    if (cfg.world_size > 1) loss_tmp_.alloc(1, true);
     widx_.alloc(B * w); ids_.alloc(N); iota_.alloc(std::max<int64_t>(B * w, N));
     launch_iota(iota_.p, static_cast<int64_t>(iota_.n), stream_);
     phrase_.alloc(B * dw); phrase_alt_.alloc(B * dw); phrase_p_ = phrase_.p; pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
@@ -271,7 +326,10 @@ Model::~Model() {
     if (ev_csr_ents_) (void)hipEventDestroy(ev_csr_ents_);
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
-    for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_, ev_copied_, ev_step_begin_[0], ev_step_begin_[1]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_, ev_copied_, ev_step_begin_[0], ev_step_begin_[1],
+                         ev_host_ids_[0], ev_host_ids_[1]}) if (e) (void)hipEventDestroy(e);
+    for (int p = 0; p < 2; ++p) if (host_ids_pin_[p]) (void)hipHostFree(host_ids_pin_[p]);
+    if (err_host_) (void)hipHostFree(err_host_);
     if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
     for (DeferredCost& d : deferred_) { if (d.ev) (void)hipEventDestroy(d.ev); if (d.host) (void)hipHostFree(d.host); }
     if (comm_ && rccl_) rccl_->CommDestroy(comm_);
@@ -282,7 +340,13 @@ void Model::set_stream(hipStream_t s) {
     synchronize();
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
     if (s) { stream_ = s; own_stream_ = false; }
-    else { NVSM_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); own_stream_ = true; }
+    else {
+        // back to a stream of the handle's own, at the highest priority like the one the constructor made
+        int lo = 0, hi = 0;
+        NVSM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        NVSM_HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+        own_stream_ = true;
+    }
 }
 
 void Model::synchronize() {
@@ -291,6 +355,28 @@ void Model::synchronize() {
     NVSM_HIP_CHECK(hipStreamSynchronize(aux2_stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(copy_stream_));
     E_pending_ = T_pending_ = false;
+    raise_device_error();
+}
+
+// Kernels report bad input ids (and, with NVSM_DEBUG=1, non-finite intermediates) by storing a code into a page-locked
+// host word; every host-side wait of the engine looks at it afterwards. The offending ids were replaced by row 0 on the
+// device, so nothing was written out of bounds; the step's numbers are meaningless and the caller is told so.
+void Model::raise_device_error() {
+    const int code = *static_cast<volatile int*>(err_host_);
+    if (code == 0) return;
+    *err_host_ = 0;
+    if (code == NVSM_BAD_WORD_ID) throw Error(NVSM_ERR_INVALID_ARGUMENT, "a word id of the batch is outside [0, num_words)");
+    if (code == NVSM_BAD_ENTITY_ID) throw Error(NVSM_ERR_INVALID_ARGUMENT, "a document id of the batch is outside [0, num_entities)");
+    static const char* const names[] = {"phrase", "pre (projection)", "proj", "probs", "grad_proj", "grad_phrase", "grad_transform",
+                                        "word_representations", "entity_representations", "transform"};
+    const int which = code - NVSM_NONFINITE_BASE;
+    throw Error(NVSM_ERR_DEVICE, std::string("NVSM_DEBUG: non-finite values in ") +
+                                 ((which >= 0 && which < 10) ? names[which] : "an intermediate"));
+}
+
+// NVSM_DEBUG=1 — CHECK_MATRIX of the reference's debug build (cpp/objective.cu:134,141,152 …)
+void Model::debug_check(const float* x, int64_t n, int which) {
+    if (debug_) launch_check_finite(x, n, err_host_, NVSM_NONFINITE_BASE + which, stream_);
 }
 
 // nvsm_step leaves the side streams' tails (documents update; dT GEMM + projection update) running when it returns, so
@@ -350,6 +436,28 @@ void Model::comm_init(const char id[128]) {
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
     const int rc = rccl_->CommInitRank(&comm_, cfg_.world_size, u, cfg_.rank);
     if (rc != 0) throw Error(NVSM_ERR_DEVICE, std::string("ncclCommInitRank: ") + (rccl_->GetErrorString ? rccl_->GetErrorString(rc) : "error"));
+    comm_ranks_ = cfg_.world_size;
+    if (rccl_->CommCount) { int n = 0; if (rccl_->CommCount(comm_, &n) == 0) comm_ranks_ = n; }
+}
+
+// Data parallel: the embedding tables are updated rank-locally (north_star "sparse embedding rows stay
+// GPU-local"), so the replicas drift apart. This replaces every replica's W and E by the mean over ranks (parameter
+// averaging; the optimiser state stays rank-local) — a collective every rank must call; the trainer calls it before each
+// model dump and at the end of every epoch so that what rank 0 writes carries all ranks' updates.
+void Model::average_tables() {
+    if (cfg_.world_size <= 1) return;
+    NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    synchronize();
+    const float inv = 1.0f / static_cast<float>(cfg_.world_size);
+    for (TableState* t : {&words_, &ents_}) {
+        const int64_t n = static_cast<int64_t>(t->P.n);
+        // chunks keep the callback transport's host staging bounded; RCCL takes them as they come
+        const int64_t chunk = int64_t(1) << 24;
+        for (int64_t off = 0; off < n; off += chunk)
+            allreduce_f32(t->P.p + off, std::min(chunk, n - off), stream_);
+        launch_scale(t->P.p, n, inv, stream_);
+    }
+    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
 void Model::allreduce_f64(double* dev, int64_t n) {
@@ -440,7 +548,17 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     B_ = B;
     have_forward_ = have_grads_ = false;
     cost_valid_ = false;
+    loss_reduced_ = false;
+    RangeScope range_cc("ComputeCost");                 // cpp/main.cu:409
     if (cfg_.l2_normalize_entity_reprs) join_E();      // that documents update still reads ids_, which the prologue rewrites
+    // The previous step's CSR builds (radix sorts on the side streams) read ids_ / widx_, which this step's prologue is
+    // about to rewrite: the main stream must be behind them. In steady state both are long finished (update() / step()
+    // joined them before the row passes), so the waits cost nothing; they matter for compute_cost; compute_cost without
+    // an update in between and for the documents build, which step() never joins on the main stream.
+    if (inputs_recorded_) {
+        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
+        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
+    }
 
     // device-sampler mode: zeroing the statistics, narrowing the word ids and drawing the document ids are one launch
     const bool fused_prologue = !entity_ids && cfg_.sampler != NVSM_SAMPLER_HOST_MINSTD;
@@ -483,7 +601,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             copied_recorded_ = true;
         }
         last_batch_on_host_ = !batch.on_device;
-        if (!fused_prologue) launch_narrow_i64(words_dev, widx_.p, B * w, stream_);
+        if (!fused_prologue) launch_narrow_i64(words_dev, widx_.p, B * w, cfg_.num_words, err_host_, NVSM_BAD_WORD_ID, stream_);
     }
 
     // F2: target + negative document ids (objective.cu:63-89 → labels.cu:4-22)
@@ -491,23 +609,30 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         PROF("sample_entities");
         if (entity_ids) {
             NVSM_HIP_CHECK(hipMemcpyAsync(in_ids64_.p, entity_ids, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
-            launch_narrow_i64(in_ids64_.p, ids_.p, N, stream_);
+            launch_narrow_i64(in_ids64_.p, ids_.p, N, cfg_.num_entities, err_host_, NVSM_BAD_ENTITY_ID, stream_);
         } else if (cfg_.sampler == NVSM_SAMPLER_HOST_MINSTD) {
             host_labels_.resize(B);
             if (batch.on_device) {
-                NVSM_HIP_CHECK(hipMemcpyAsync(host_labels_.data(), batch.labels, B * sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
-                NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+                // device-resident labels: read back on the copy stream — the host waits for these B words only, not for
+                // whatever the main stream still has queued
+                NVSM_HIP_CHECK(hipMemcpyAsync(host_labels_.data(), batch.labels, B * sizeof(int64_t), hipMemcpyDeviceToHost, copy_stream_));
+                NVSM_HIP_CHECK(hipStreamSynchronize(copy_stream_));
             } else {
                 std::memcpy(host_labels_.data(), batch.labels, B * sizeof(int64_t));
             }
-            host_ids_.resize(N);
-            draw_reference_negatives(host_labels_.data(), B, host_ids_.data());
-            NVSM_HIP_CHECK(hipMemcpyAsync(in_ids64_.p, host_ids_.data(), N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
-            NVSM_HIP_CHECK(hipStreamSynchronize(stream_));           // host_ids_ is pageable and reused next step
-            launch_narrow_i64(in_ids64_.p, ids_.p, N, stream_);
+            // page-locked, two of them: this one was last read by the copy of the step before last (its event has long
+            // fired), so the host never waits for the stream here and a deferred-loss loop stays one step ahead of the GPU
+            const int hp = host_ids_parity_ ^= 1;
+            if (host_ids_used_[hp]) NVSM_HIP_CHECK(hipEventSynchronize(ev_host_ids_[hp]));
+            draw_reference_negatives(host_labels_.data(), B, host_ids_pin_[hp]);
+            NVSM_HIP_CHECK(hipMemcpyAsync(in_ids64_.p, host_ids_pin_[hp], N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+            NVSM_HIP_CHECK(hipEventRecord(ev_host_ids_[hp], stream_));
+            host_ids_used_[hp] = true;
+            launch_narrow_i64(in_ids64_.p, ids_.p, N, cfg_.num_entities, err_host_, NVSM_BAD_ENTITY_ID, stream_);
         } else {
-            launch_step_prologue(words_dev, widx_.p, B * w, labels_dev_, B, R_, cfg_.num_entities,
-                                 device_seed_ + 0x9E37u * cfg_.rank, step_count_, ids_.p, stats_.p, static_cast<int>(stats_.n), stream_);
+            launch_step_prologue(words_dev, widx_.p, B * w, labels_dev_, B, R_, cfg_.num_words, cfg_.num_entities,
+                                 device_seed_ + 0x9E37u * cfg_.rank, step_count_, ids_.p, stats_.p, static_cast<int>(stats_.n),
+                                 err_host_, stream_);
         }
     }
     ++step_count_;
@@ -534,6 +659,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         // optional phrase normaliser (objective.cu:136-142): the raw means stay cached for its backward pass
         if (l2p) launch_l2_rows_forward(phrase_raw_.p, B, dw, phrase_p_, phrase_norms_.p, stream_);
     }
+    debug_check(phrase_p_, B * dw, 0);                  // CHECK_MATRIX(*result->phrase_reprs_), objective.cu:134,141
 
     // F5: projection GEMM  pre[B][de] = phrase[B][dw] · Tt[dw][de] (+ b when no BN)   (params.cu:417-421)
     // F6 (first half): with batch-norm the column sums Σx, Σx² of the projection ride in the GEMM epilogue
@@ -547,6 +673,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
     const double bn_n = (cfg_.world_size > 1 && cfg_.sync_batch_norm) ? B_global : static_cast<double>(B);
+    debug_check(pre_.p, B * de, 1);                     // CHECK_MATRIX(*result->word_projections_), objective.cu:152
     // F6: batch statistics (cudnn_utils.cu:107-124), ε = 1e-4 (objective.cu:114)
     if (cfg_.batch_normalization && cfg_.world_size > 1 && cfg_.sync_batch_norm) {
         PROF("allreduce_bn_stats");
@@ -582,6 +709,13 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     }
     NVSM_HIP_CHECK(hipGetLastError());      // a failed launch of any kernel above surfaces here, not at the next sync
     have_forward_ = true;
+    if (debug_) {
+        debug_check(proj_.p, B * de, 2); debug_check(probs_.p, N, 3); debug_check(dy_.p, B * de, 4);
+        debug_check(words_.P.p, static_cast<int64_t>(words_.P.n), 7); debug_check(ents_.P.p, static_cast<int64_t>(ents_.P.n), 8);
+        debug_check(T_.p, static_cast<int64_t>(T_.n), 9);
+        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        raise_device_error();                // ids out of range / non-finite values are reported by the call that saw them
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -590,10 +724,17 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
 void Model::compute_gradients() {
     if (!have_forward_) throw Error(NVSM_ERR_STATE, "compute_gradients requires compute_cost");
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    RangeScope range_cg("ComputeGradients");            // cpp/main.cu:414
     backward_dx();
     backward_T(stream_);
     NVSM_HIP_CHECK(hipGetLastError());
     have_grads_ = true;
+    if (debug_) {
+        debug_check(gphrase_.p, B_ * cfg_.word_repr_size, 5);
+        debug_check(gT_.p, static_cast<int64_t>(gT_.n), 6);
+        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        raise_device_error();
+    }
 }
 
 void Model::backward_dx() {
@@ -638,6 +779,7 @@ void Model::backward_dx() {
         else if (need_msq) launch_sum_parts(msq_parts_.p, gemm_rowsq_parts(dw), B, msq_w_.p, B, stream_);
         NVSM_HIP_CHECK(hipEventRecord(ev_bwdx_, stream_));      // last reader of T before its update
     }
+    if (dp) loss_reduced_ = true;
 }
 
 // B6: ∂T (stored [dw][de]) = phraseᵀ[dw x B] · dx[B x de], split-K over the batch   (params.cu:526-531)
@@ -671,11 +813,18 @@ float Model::get_cost() {
     if (!have_forward_) throw Error(NVSM_ERR_STATE, "get_cost requires compute_cost");
     if (!cost_valid_) {
         double s = 0.0;
-        if (cfg_.world_size > 1 && !have_grads_) {
-            // before compute_gradients the loss word has not been all-reduced yet: local contribution only
+        const double* src = stats_bwd_;
+        if (cfg_.world_size > 1 && !loss_reduced_) {
+            // Data parallel, before the backward pass has all-reduced [loss | Σdy | Σdy·x̂]: the loss word still holds this
+            // rank's share only. All-reduce a copy (a collective: every rank must make the same call, as every rank makes the
+            // same compute_cost / compute_gradients calls) and leave the word itself to the backward pass.
+            NVSM_HIP_CHECK(hipMemcpyAsync(loss_tmp_.p, stats_bwd_, sizeof(double), hipMemcpyDeviceToDevice, stream_));
+            allreduce_f64(loss_tmp_.p, 1);
+            src = loss_tmp_.p;
         }
-        NVSM_HIP_CHECK(hipMemcpyAsync(&s, stats_bwd_, sizeof(double), hipMemcpyDeviceToHost, stream_));
+        NVSM_HIP_CHECK(hipMemcpyAsync(&s, src, sizeof(double), hipMemcpyDeviceToHost, stream_));
         NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        raise_device_error();
         const double Bg = static_cast<double>(B_) * (cfg_.world_size > 1 ? cfg_.world_size : 1);
         cost_ = -(s / Bg);
         cost_valid_ = true;
@@ -842,6 +991,7 @@ void Model::update(float lr, float scaled_lambda) {
     if (!have_grads_) throw Error(NVSM_ERR_STATE, "update requires compute_gradients");
     if (lr < 0.f || scaled_lambda < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");   // storage.cu:62-63
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
+    RangeScope range_up("UpdateParameters");            // cpp/main.cu:429
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));     // join the side-stream CSR builds
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
     update_entities(lr, scaled_lambda, stream_);
@@ -870,6 +1020,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     // collectives on the main stream (dT GEMM + all-reduce + update no longer overlap the words update).
     static const bool t_on_main = std::getenv("NVSM_DP_T_ON_MAIN") != nullptr;
     const bool dp = cfg_.world_size > 1 && t_on_main;
+    RangeScope range_bu("ComputeGradients+UpdateParameters");      // cpp/main.cu:414,429 — one interleaved region here
     NVSM_HIP_CHECK(hipEventRecord(ev_loss_, stream_));
     // side stream 1 (behind the documents CSR build): the documents update, HBM-bound — next to the MFMA-bound dx GEMM
     // now, and free to run on next to the next step's projection GEMM; the next loss kernel joins it
@@ -920,6 +1071,7 @@ float Model::deferred_cost(int64_t ticket) {
     DeferredCost& d = deferred_[ticket % NVSM_MAX_DEFERRED];
     if (d.ticket != ticket) throw Error(NVSM_ERR_STATE, "ticket is older than the NVSM_MAX_DEFERRED most recent steps");
     NVSM_HIP_CHECK(hipEventSynchronize(d.ev));
+    raise_device_error();
     return static_cast<float>(-(*d.host / d.batch));
 }
 

@@ -60,7 +60,7 @@ struct RcclApi;
 class Profiler {
  public:
     bool enabled = false;
-    std::string only;          // when not empty, only this kernel group is timed (two events per step instead of ~50)
+    std::string only;          // when not empty, only these kernel groups (comma-separated) are timed (a few events per step instead of ~50)
     void begin(const char* name, hipStream_t s);
     void end(hipStream_t s);
     void reset();
@@ -127,6 +127,8 @@ class Model {
     void join_E();
     void join_aux() { join_T(); join_E(); }
     void comm_init(const char id[128]);
+    void average_tables();                 // data parallel: mean of the replicas' embedding tables (nvsm_dp_average_tables)
+    int comm_ranks() const { return comm_ranks_; }
     void set_allreduce_callback(nvsm_allreduce_fn fn, void* user) { ar_fn_ = fn; ar_user_ = user; }
 
     Profiler prof;
@@ -144,6 +146,8 @@ class Model {
     void update_transform(float lr, float sl, hipStream_t s);
     void allreduce_f64(double* dev, int64_t n);
     void allreduce_f32(float* dev, int64_t n, hipStream_t s);
+    void raise_device_error();             // throws when a kernel has flagged bad ids / non-finite values since the last check
+    void debug_check(const float* x, int64_t n, int which);
     void alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entries);
     float adam_bc(uint64_t t) const;
 
@@ -178,7 +182,15 @@ class Model {
     const float* wwts_ = nullptr;     // device pointer or null
     const float* instw_ = nullptr;
     const int64_t* labels_dev_ = nullptr;
-    std::vector<int64_t> host_labels_, host_ids_;
+    std::vector<int64_t> host_labels_;
+    // host sampler: two page-locked id buffers, each guarded by the event of the copy that last read it, so that
+    // compute_cost never waits for the stream (the step before last has long released the buffer it reuses)
+    int64_t* host_ids_pin_[2] = {nullptr, nullptr};
+    hipEvent_t ev_host_ids_[2] = {nullptr, nullptr};
+    bool host_ids_used_[2] = {false, false};
+    int host_ids_parity_ = 0;
+    int* err_host_ = nullptr;         // page-locked error word written by kernels (kernels.h: NVSM_BAD_*, NVSM_NONFINITE_BASE)
+    bool debug_ = false;              // NVSM_DEBUG=1: finite checks of every intermediate + a sync after each call
     int64_t B_ = 0;                   // instances of the current batch (this rank)
 
     // intermediates
@@ -201,10 +213,13 @@ class Model {
     bool inputs_recorded_ = false;
     double cost_ = 0.0;
     bool cost_valid_ = false;
+    bool loss_reduced_ = false;       // data parallel: the loss word has been all-reduced (by the backward pass)
 
     // data parallel
     RcclApi* rccl_ = nullptr;
     void* comm_ = nullptr;
+    int comm_ranks_ = 0;              // ncclCommCount of the communicator (0 = none)
+    DevBuf<double> loss_tmp_;         // data parallel get_cost before compute_gradients: all-reduced copy of the loss word
     nvsm_allreduce_fn ar_fn_ = nullptr;
     void* ar_user_ = nullptr;
     std::vector<double> ar_host_;

@@ -4,12 +4,18 @@
 //
 // Differences, all forced by what exists on this platform:
 //   * <path to Indri index> is either an Indri 5.x repository directory, read without libindri (host/indri_index.hpp;
-//     no docno look-ups, so --document_list needs the TREC-text form), or the TREC-text collection file itself, indexed
+//     --document_list resolves docnos through the repository's docno look-up files), or the TREC-text collection file itself, indexed
 //     in memory on start-up (host/trectext_index.hpp).
 //   * only TextEntity::Objective (LSE / NVSM) is accelerated: non-zero --entity_similarity_weight /
 //     --term_similarity_weight and the l2 normalisers are refused with a clear message.
-//   * extensions: --stopwords, --device, --sampler {host,device}, --allow_ragged_batches.
+//   * extensions: --stopwords, --device, --sampler {host,device}, --allow_ragged_batches, and data parallelism over RCCL
+//     (--gpus N spawns one process per GPU; or --world_size / --rank [or WORLD_SIZE / RANK / LOCAL_RANK] under any launcher).
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <thread>
 
 #include <chrono>
 #include <cmath>
@@ -39,7 +45,8 @@ double FLAGS_regularization_lambda, FLAGS_learning_rate, FLAGS_max_document_freq
 bool FLAGS_bias_negative_samples, FLAGS_l2_phrase_normalization, FLAGS_l2_entity_normalization, FLAGS_batch_normalization,
     FLAGS_include_oov, FLAGS_compute_initial_cost, FLAGS_check_gradients, FLAGS_no_shuffle, FLAGS_dump_initial_model,
     FLAGS_allow_ragged_batches, FLAGS_logtostderr, FLAGS_alsologtostderr;
-int64_t FLAGS_dump_every, FLAGS_v, FLAGS_device, FLAGS_minloglevel;
+int64_t FLAGS_dump_every, FLAGS_v, FLAGS_device, FLAGS_minloglevel, FLAGS_gpus, FLAGS_world_size, FLAGS_rank;
+std::string FLAGS_comm_id_file;
 
 void define_flags(Flags* f) {      // names, defaults and help strings of cpp/main.cu:15-76
     f->define_uint64("num_epochs", &FLAGS_num_epochs, 100000, "Number of training iterations.");
@@ -67,7 +74,9 @@ void define_flags(Flags* f) {      // names, defaults and help strings of cpp/ma
     f->define_double("max_document_frequency", &FLAGS_max_document_frequency, 0.5, "Maximum document frequency of term in order to be retained by vocabulary filtering. If smaller than 1.0, then max_document_frequency is interpreted as relative to the index size; otherwise, it is considered an absolute threshold.");
     f->define_bool("include_oov", &FLAGS_include_oov, false, "Whether to include a special-purpose OoV token for term positions with a filtered dictionary term.");
     f->define_bool("compute_initial_cost", &FLAGS_compute_initial_cost, false, "Compute the cost before any learning is performed.");
-    f->define_bool("check_gradients", &FLAGS_check_gradients, false, "Enable gradient checking. CAUTION: this will lead to insanely slow learning.");
+    f->define_bool("check_gradients", &FLAGS_check_gradients, false, "Enable gradient checking. CAUTION: this will lead to insanely slow learning. "
+                   "(Central differences with epsilon 1e-2 rather than the reference's 1e-4: the forward pass runs in fp32 — costs are read from the fp64 "
+                   "device accumulator — and a disagreement within twice the fp32 resolution of the difference quotient is not held against a gradient.)");
     f->define_bool("no_shuffle", &FLAGS_no_shuffle, false, "Do not shuffle the training set.");
     f->define_bool("dump_initial_model", &FLAGS_dump_initial_model, false, "Dump the model after random initialization, but before training.");
     f->define_int64("dump_every", &FLAGS_dump_every, 0, "Number of batches that should be processed before the model is dumped during a single epoch. The model is always dumped at the end of every epoch.");
@@ -76,7 +85,15 @@ void define_flags(Flags* f) {      // names, defaults and help strings of cpp/ma
     f->define_string("output", &FLAGS_output, "", "Path to output model.");
     // extensions
     f->define_string("stopwords", &FLAGS_stopwords, "", "Stop list applied while indexing the collection (Indri <word> parameter file or plain words).");
-    f->define_int64("device", &FLAGS_device, 0, "HIP device ordinal.");
+    f->define_int64("device", &FLAGS_device, -1, "HIP device ordinal (default: LOCAL_RANK, else the rank, else 0).");
+    f->define_int64("gpus", &FLAGS_gpus, 1, "Data parallel over this many GPUs of the node: the trainer starts one process per GPU (ranks 0..N-1 on devices "
+                    "0..N-1). Every global batch of --batch_size windows is split into N contiguous slices; the projection / bias / batch-norm "
+                    "gradients are all-reduced over RCCL each step, the embedding tables are updated rank-locally and averaged over the ranks at the "
+                    "end of every epoch and before every model dump (rank 0 writes the outputs).");
+    f->define_int64("world_size", &FLAGS_world_size, 0, "Data-parallel ranks when an external launcher starts them (default: WORLD_SIZE, else 1).");
+    f->define_int64("rank", &FLAGS_rank, -1, "This process's rank (default: RANK, else 0).");
+    f->define_string("comm_id_file", &FLAGS_comm_id_file, "", "File through which rank 0 hands the RCCL unique id to the other ranks "
+                     "(default: /tmp/cunvsm_comm_<MASTER_PORT or parent pid>).");
     f->define_string("sampler", &FLAGS_sampler, "host", "Negative sampler: host (minstd_rand0, draw-for-draw the reference) or device.");
     f->define_bool("allow_ragged_batches", &FLAGS_allow_ragged_batches, false, "Train on batches whose size is not a multiple of 1024 instead of skipping them as the reference does.");
     // glog's own options that the reference's scripts pass
@@ -125,12 +142,15 @@ struct TrainConfig {
 
 class Trainer {
  public:
-    Trainer(nvsm_model* model, const TrainConfig& tc, int64_t num_words, int64_t num_entities, int dw, int de)
-        : model_(model), tc_(tc), num_words_(num_words), num_entities_(num_entities), dw_(dw), de_(de) {}
+    Trainer(nvsm_model* model, const TrainConfig& tc, int64_t num_words, int64_t num_entities, int dw, int de, int world_size, int rank)
+        : model_(model), tc_(tc), num_words_(num_words), num_entities_(num_entities), dw_(dw), de_(de), world_size_(world_size), rank_(rank) {}
 
     // DumpModelFn (cpp/main.cu:335-364) + write_to_hdf5 (include/cuNVSM/lse_hdf5_inl.h)
     void dump_model(size_t epoch, const std::string& identifier) {
-        if (FLAGS_output.empty()) return;
+        // data parallel: the replicas' tables have drifted apart (rank-local sparse updates): what is written is their mean,
+        // and every replica continues from it. A collective — every rank gets here at the same batch.
+        if (world_size_ > 1) NVSM_CALL(nvsm_dp_average_tables(model_));
+        if (FLAGS_output.empty() || rank_ != 0) return;
         std::stringstream ss;
         ss << FLAGS_output << "_" << epoch;
         if (!identifier.empty()) ss << "_" << identifier;
@@ -169,18 +189,26 @@ class Trainer {
             log_batch(p.index, cost, data_source, iteration_start, p.start);
             p.valid = false;
         };
+        struct Range { explicit Range(const char* n) { nvsm_range_push(n); } ~Range() { nvsm_range_pop(); } };
         while (data_source->has_next()) {
+            Range batch_range("Batch");                                                   // nvtxRangePush("Batch"), cpp/main.cu:386
             const auto batch_start = std::chrono::steady_clock::now();
             NVSM_CALL(nvsm_wait_inputs(model_));        // the previous step has copied this host batch to the device
             batch->clear();
-            data_source->next(batch);
-            const size_t n = batch->num_instances();
-            if (n % 1024 != 0 && !FLAGS_allow_ragged_batches) {                        // maxThreadsPerBlock, :392-398
-                NVSM_LOG(ERROR) << "Skipping Batch #" << epoch_num_batches << " as it is not a multiple of " << 1024 << " (" << n << " instances).";
-            } else if (n > 0) {
+            { Range fetch_range("FetchData"); data_source->next(batch); }                 // :388-390
+            const size_t n_global = batch->num_instances();
+            const size_t G = static_cast<size_t>(world_size_);
+            if (n_global % 1024 != 0 && !FLAGS_allow_ragged_batches) {                        // maxThreadsPerBlock, :392-398
+                NVSM_LOG(ERROR) << "Skipping Batch #" << epoch_num_batches << " as it is not a multiple of " << 1024 << " (" << n_global << " instances).";
+            } else if (n_global % G != 0) {
+                NVSM_LOG(ERROR) << "Skipping Batch #" << epoch_num_batches << " as it does not split evenly over " << G << " ranks (" << n_global << " instances).";
+            } else if (n_global > 0) {
+                // data parallel: every rank reads the same global batch (same seed, same stream) and trains on its contiguous
+                // slice [rank·n/G, (rank+1)·n/G)
+                const size_t n = n_global / G, lo = n * static_cast<size_t>(rank_), w = static_cast<size_t>(tc_.window_size);
                 nvsm_batch b;
-                b.features = batch->features(); b.feature_weights = batch->feature_weights();
-                b.labels = batch->labels(); b.weights = batch->weights();
+                b.features = batch->features() + lo * w; b.feature_weights = batch->feature_weights() + lo * w;
+                b.labels = batch->labels() + lo; b.weights = batch->weights() + lo;
                 b.num_instances = static_cast<int64_t>(n); b.on_device = 0;
                 float cost = 0.f;
                 if (FLAGS_check_gradients) {
@@ -199,7 +227,7 @@ class Trainer {
                     NVSM_CALL(nvsm_step_deferred(model_, &b, nullptr, tc_.learning_rate, &ticket));
                     finish(pending);
                     pending.valid = true; pending.ticket = ticket; pending.index = epoch_num_batches; pending.start = batch_start;
-                    windows_ += n;
+                    windows_ += n_global;
                     if (may_dump && FLAGS_dump_every > 0 && epoch_num_batches > 0 && epoch_num_batches % static_cast<size_t>(FLAGS_dump_every) == 0)
                         dump_model(dump_epoch, std::to_string(epoch_num_batches));
                     ++epoch_num_batches;
@@ -210,7 +238,7 @@ class Trainer {
                     NVSM_CALL(nvsm_get_cost(model_, &cost));
                 }
                 agg_cost += cost;
-                windows_ += n;
+                windows_ += n_global;
                 log_batch(epoch_num_batches, cost, data_source, iteration_start, batch_start);
             }
             if (may_dump && FLAGS_dump_every > 0 && epoch_num_batches > 0 && epoch_num_batches % static_cast<size_t>(FLAGS_dump_every) == 0)
@@ -323,6 +351,7 @@ class Trainer {
     TrainConfig tc_;
     int64_t num_words_, num_entities_;
     int dw_, de_;
+    int world_size_, rank_;
     uint64_t windows_ = 0;
 };
 
@@ -353,6 +382,46 @@ int run(int argc, char** argv) {
     NVSM_CHECK(FEATURE_WEIGHTING_STRATEGIES.count(FLAGS_feature_weighting)) << "Please specify a valid --feature_weighting.";
     NVSM_CHECK(NONLINEARITIES.count(FLAGS_nonlinearity)) << "Please specify a valid --nonlinearity.";
     NVSM_CHECK(FLAGS_sampler == "host" || FLAGS_sampler == "device") << "--sampler must be host or device.";
+
+    // ---- data parallelism: --gpus N spawns the ranks; otherwise world size / rank come from the flags or the launcher's environment
+    auto env_int = [](const char* name, int64_t dflt) { const char* v = std::getenv(name); return (v && *v) ? static_cast<int64_t>(std::atoll(v)) : dflt; };
+    if (FLAGS_gpus > 1 && FLAGS_world_size == 0 && !std::getenv("WORLD_SIZE")) {
+        if (nvsm_device_count() < FLAGS_gpus) NVSM_LOG(FATAL) << "--gpus " << FLAGS_gpus << " but only " << nvsm_device_count() << " HIP device(s) are visible.";
+        // re-execute this binary once per GPU with explicit --world_size / --rank / --device / --comm_id_file (the children
+        // initialise HIP themselves; the parent only waits)
+        const std::string id_file = FLAGS_comm_id_file.empty() ? "/tmp/cunvsm_comm_" + std::to_string(getpid()) : FLAGS_comm_id_file;
+        std::remove(id_file.c_str());
+        std::vector<pid_t> kids;
+        for (int64_t r = 0; r < FLAGS_gpus; ++r) {
+            const pid_t pid = fork();
+            NVSM_CHECK(pid >= 0) << "fork failed";
+            if (pid == 0) {
+                std::vector<std::string> av(argv, argv + argc);
+                av.push_back("--world_size=" + std::to_string(FLAGS_gpus)); av.push_back("--rank=" + std::to_string(r));
+                av.push_back("--device=" + std::to_string(r)); av.push_back("--comm_id_file=" + id_file);
+                std::vector<char*> cav;
+                for (std::string& a : av) cav.push_back(&a[0]);
+                cav.push_back(nullptr);
+                execv("/proc/self/exe", cav.data());
+                std::perror("execv");
+                _exit(127);
+            }
+            kids.push_back(pid);
+        }
+        int rc = 0;
+        for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1; }
+        std::remove(id_file.c_str());
+        return rc;
+    }
+    const int world_size = static_cast<int>(FLAGS_world_size > 0 ? FLAGS_world_size : env_int("WORLD_SIZE", 1));
+    const int rank = static_cast<int>(FLAGS_rank >= 0 ? FLAGS_rank : env_int("RANK", 0));
+    NVSM_CHECK(world_size >= 1 && rank >= 0 && rank < world_size) << "bad --world_size / --rank";
+    if (FLAGS_device < 0) FLAGS_device = world_size > 1 ? env_int("LOCAL_RANK", rank) : 0;
+    if (world_size > 1) {
+        NVSM_CHECK(FLAGS_batch_size % static_cast<uint64_t>(world_size) == 0) << "--batch_size must be a multiple of the number of ranks.";
+        NVSM_CHECK(!FLAGS_check_gradients) << "--check_gradients is a single-GPU diagnostic.";
+        if (rank != 0 && FLAGS_v < 2) { FLAGS_v = 0; verbosity() = 0; }       // rank 0 narrates
+    }
 
     const std::string repository_path = args[1];
     std::unique_ptr<IndexInterface> index;
@@ -452,11 +521,40 @@ int run(int argc, char** argv) {
     cfg.window_size = static_cast<int32_t>(tc.window_size); cfg.num_random_entities = static_cast<int32_t>(tc.num_random_entities);
     cfg.regularization_lambda = tc.regularization_lambda;
     cfg.update_method = tc.update_method; cfg.adam_mode = tc.adam_mode;
-    cfg.max_batch_size = static_cast<int32_t>(tc.batch_size);
+    cfg.max_batch_size = static_cast<int32_t>(tc.batch_size / static_cast<uint64_t>(world_size));      // this rank's slice
+    cfg.world_size = world_size; cfg.rank = rank; cfg.sync_batch_norm = 1;
     cfg.device = static_cast<int32_t>(FLAGS_device);
     cfg.sampler = FLAGS_sampler == "host" ? NVSM_SAMPLER_HOST_MINSTD : NVSM_SAMPLER_DEVICE;
     nvsm_model* model = nullptr;
     NVSM_CALL(nvsm_create(&cfg, &model));
+    if (world_size > 1) {
+        // RCCL bootstrap without a rendezvous service: rank 0 publishes the 128-byte ncclUniqueId through a file (written
+        // under a temporary name and renamed, so a reader never sees half of it); ncclCommInitRank is itself a barrier, so
+        // once it returns on rank 0 every rank has read the file and it can go.
+        std::string id_file = FLAGS_comm_id_file;
+        if (id_file.empty()) id_file = "/tmp/cunvsm_comm_" + std::to_string(env_int("MASTER_PORT", static_cast<int64_t>(getppid())));
+        char id[128];
+        if (rank == 0) {
+            NVSM_CALL(nvsm_comm_unique_id(id));
+            const std::string tmp = id_file + ".tmp";
+            { std::ofstream f(tmp, std::ios::binary); f.write(id, 128); NVSM_CHECK(f.good()) << "cannot write " << tmp; }
+            NVSM_CHECK(std::rename(tmp.c_str(), id_file.c_str()) == 0) << "cannot publish " << id_file;
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 6000 && !got; ++tries) {       // up to 10 minutes: rank 0 may still be indexing the collection
+                std::ifstream f(id_file, std::ios::binary);
+                if (f.good() && f.read(id, 128) && f.gcount() == 128) got = true;
+                else std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+            NVSM_CHECK(got) << "rank " << rank << ": no RCCL id appeared in " << id_file;
+        }
+        NVSM_CALL(nvsm_comm_init(model, id));
+        if (rank == 0) std::remove(id_file.c_str());
+        int ranks = 0;
+        NVSM_CALL(nvsm_comm_size(model, &ranks));
+        NVSM_LOG(INFO) << "Data parallel: rank " << rank << " of " << world_size << " on device " << FLAGS_device << " (RCCL communicator of " << ranks
+                       << " ranks); " << cfg.max_batch_size << " of every " << tc.batch_size << " windows.";
+    }
     // model.initialize(rng): the SAME generator the data source has just drawn from (cpp/main.cu:497-520)
     NVSM_CALL(nvsm_rng_set_state(model, rng_state(rng)));
     NVSM_CALL(nvsm_initialize_from_rng_state(model));
@@ -466,7 +564,7 @@ int run(int argc, char** argv) {
     NVSM_LOG(INFO) << "Initialized cuNVSM with " << num_parameters << " parameters for training on " << vocabulary_size << " words and "
                    << corpus_size << " objects.";
 
-    if (!FLAGS_output.empty()) {                                                         // :527-537
+    if (!FLAGS_output.empty() && rank == 0) {                                            // :527-537
         std::ofstream meta_file(FLAGS_output + "_meta", std::ios::binary);
         const std::string wire = meta.SerializeAsString();
         meta_file.write(wire.data(), static_cast<std::streamsize>(wire.size()));
@@ -474,7 +572,7 @@ int run(int argc, char** argv) {
     }
 
     Trainer trainer(model, tc, static_cast<int64_t>(vocabulary_size), static_cast<int64_t>(corpus_size),
-                    static_cast<int>(FLAGS_word_repr_size), static_cast<int>(FLAGS_entity_repr_size));
+                    static_cast<int>(FLAGS_word_repr_size), static_cast<int>(FLAGS_entity_repr_size), world_size, rank);
     Batch batch(tc.batch_size, tc.window_size);
     std::vector<float> epoch_costs;
 
@@ -498,6 +596,7 @@ int run(int argc, char** argv) {
     const auto start = std::chrono::steady_clock::now();
     size_t num_batches = 0;
     for (size_t epoch = 1; epoch <= tc.num_epochs; ++epoch) {                            // :575-620
+        nvsm_range_push("Epoch");                                                        // :577
         const auto epoch_start = std::chrono::steady_clock::now();
         const uint64_t windows_before = trainer.windows();
         const auto r = trainer.iterate_data(true, data_source.get(), &batch, epoch, true);
@@ -510,6 +609,7 @@ int run(int argc, char** argv) {
         NVSM_VLOG(1) << "Epoch #" << epoch << ": " << (trainer.windows() - windows_before) / epoch_duration << " n-gram windows/second";
         trainer.dump_model(epoch, "");
         reset_data_source();
+        nvsm_range_pop();
     }
     NVSM_CALL(nvsm_synchronize(model));
     data_source.reset();

@@ -103,6 +103,18 @@ class Batch:
             return None
         return a.data_ptr() if self.on_device else a.ctypes.data
 
+    def check_shapes(self, window_size):
+        """The ABI takes bare pointers: the element counts it will read are asserted here (include/cunvsm_amd.h,
+        index contract). Id RANGES are checked on the device."""
+        size = (lambda a: int(a.numel())) if self.on_device else (lambda a: int(a.size))
+        B = self.num_instances
+        if size(self.features) != B * window_size:
+            raise ValueError("features holds %d ids, expected num_instances * window_size = %d" % (size(self.features), B * window_size))
+        if self.feature_weights is not None and size(self.feature_weights) != B * window_size:
+            raise ValueError("feature_weights holds %d values, expected %d" % (size(self.feature_weights), B * window_size))
+        if self.weights is not None and size(self.weights) != B:
+            raise ValueError("weights holds %d values, expected %d" % (size(self.weights), B))
+
     def as_struct(self):
         return NvsmBatch(self._ptr(self.features), self._ptr(self.feature_weights), self._ptr(self.labels),
                          self._ptr(self.weights), self.num_instances, int(self.on_device))
@@ -145,10 +157,16 @@ class Model:
         ids = None
         if entity_ids is not None:
             ids = np.ascontiguousarray(entity_ids, dtype=np.int64)
-            assert ids.size == batch.num_instances * (self.cfg.num_random_entities + 1)
-        st = batch.as_struct()
+        st = self._checked(batch, ids)
         self._keep = (batch, ids)
         check(lib().nvsm_compute_cost(self._h, C.byref(st), None if ids is None else ids.ctypes.data))
+
+    def _checked(self, batch, ids):
+        batch.check_shapes(self.cfg.window_size)
+        if ids is not None and ids.size != batch.num_instances * (self.cfg.num_random_entities + 1):
+            raise ValueError("entity_ids holds %d ids, expected num_instances * (num_random_entities + 1) = %d"
+                             % (ids.size, batch.num_instances * (self.cfg.num_random_entities + 1)))
+        return batch.as_struct()
 
     def compute_gradients(self):
         check(lib().nvsm_compute_gradients(self._h))
@@ -170,7 +188,7 @@ class Model:
         ids = None
         if entity_ids is not None:
             ids = np.ascontiguousarray(entity_ids, dtype=np.int64)
-        st = batch.as_struct()
+        st = self._checked(batch, ids)
         self._keep = (batch, ids)
         c = C.c_float()
         check(lib().nvsm_step(self._h, C.byref(st), None if ids is None else ids.ctypes.data, learning_rate,
@@ -183,7 +201,7 @@ class Model:
         ids = None
         if entity_ids is not None:
             ids = np.ascontiguousarray(entity_ids, dtype=np.int64)
-        st = batch.as_struct()
+        st = self._checked(batch, ids)
         self._keep = (batch, ids)
         t = C.c_int64()
         check(lib().nvsm_step_deferred(self._h, C.byref(st), ids.ctypes.data if ids is not None else None, float(learning_rate), C.byref(t)))
@@ -229,6 +247,16 @@ class Model:
     def comm_init(self, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         check(lib().nvsm_comm_init(self._h, buf))
+
+    def comm_size(self):
+        """Ranks of the engine's RCCL communicator as ncclCommCount reports them (0: none built)."""
+        n = C.c_int()
+        check(lib().nvsm_comm_size(self._h, C.byref(n)))
+        return n.value
+
+    def dp_average_tables(self):
+        """Collective: word / document tables ← mean over the ranks' replicas (see include/cunvsm_amd.h)."""
+        check(lib().nvsm_dp_average_tables(self._h))
 
     def set_allreduce_callback(self, fn):
         """fn(numpy float64 array) must sum the array in place across ranks."""

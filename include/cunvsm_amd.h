@@ -137,6 +137,15 @@ int nvsm_set_param(nvsm_model* m, const char* name, const float* host_src, int64
 /* Storage::increment_parameter(idx, epsilon) (cpp/storage.cu:123-131,252-264): the gradient checker's poke. */
 int nvsm_increment_parameter(nvsm_model* m, const char* name, int64_t index, float delta);
 
+/* Index contract (the reference indexes its tables with these ids unchecked, cpp/params.cu:75-95, cpp/storage.cu:37-49):
+ * every word id must be in [0, num_words), every label / entity id in [0, num_entities). The arrays must hold
+ * num_instances * window_size (features, feature_weights), num_instances (labels, weights) and
+ * num_instances * (num_random_entities + 1) (entity_ids) elements. Ids are checked ON THE DEVICE when they are narrowed
+ * to 32 bits: an id out of range is replaced by row 0 (nothing is ever read or written out of bounds) and the NEXT
+ * host-side wait of the handle — nvsm_get_cost, nvsm_deferred_cost, nvsm_synchronize, nvsm_get_param / nvsm_get_tensor —
+ * returns NVSM_ERR_INVALID_ARGUMENT once; the numbers of that step are meaningless. With the environment variable
+ * NVSM_DEBUG=1 (the reference's debug build: CHECK_MATRIX, cpp/objective.cu:134,152) compute_cost / compute_gradients
+ * additionally verify that every intermediate and parameter is finite and report at once (NVSM_ERR_DEVICE). */
 /* Model::compute_cost(batch, rng) (cpp/model.cu:135-143 → cpp/objective.cu:30-313).
  * entity_ids: optional [num_instances * (num_random_entities + 1)] int64 HOST array laid out as
  * generate_labels does ([label, neg_1..neg_k] per instance); NULL ⇒ sampled per cfg.sampler. */
@@ -177,15 +186,33 @@ int nvsm_wait_inputs(nvsm_model* m);
 int nvsm_tensor_size(nvsm_model* m, const char* name, int64_t* count);
 int nvsm_get_tensor(nvsm_model* m, const char* name, float* host_dst, int64_t count);
 
-/* Streams: all work of a handle runs on one HIP stream (the reference collapses to one stream too,
- * cpp/model.cu:13-14). NULL stream = the handle's own stream. */
+/* Streams. A handle issues its work on FOUR HIP streams of its own device: the main stream (highest priority: the step's
+ * critical chain), two side streams (lowest priority: the batch → row-order sorts, and — in nvsm_step — the documents
+ * update and the ∂T GEMM + projection update, which keep running after nvsm_step has returned and are joined by the next
+ * step where it needs their results) and a copy stream (host batches → HBM). The reference collapses to one stream,
+ * cpp/model.cu:13-14. nvsm_set_stream replaces the MAIN stream only (the caller's stream keeps its own priority; the
+ * side streams still order themselves against it with events); NULL = a fresh highest-priority stream of the handle's
+ * own. nvsm_synchronize waits for all four and reports any error a kernel has flagged since the last wait. */
 int nvsm_set_stream(nvsm_model* m, void* hip_stream);
 int nvsm_synchronize(nvsm_model* m);
 
 /* Data parallelism over RCCL / xGMI: one all-reduce of [grad_transform | grad_bias] per
- * step (+ two of the batch-norm statistics when sync_batch_norm). The 128-byte id is ncclUniqueId. */
+ * step (+ two of the batch-norm statistics when sync_batch_norm). The 128-byte id is ncclUniqueId.
+ * SEMANTICS — read before training with world_size > 1: only the dense projection, its bias and the batch-norm
+ * statistics are reduced; the word and document tables (and their optimiser state) are updated from each rank's own
+ * shard ("sparse embedding rows stay GPU-local"), so the replicas of the tables drift apart and an N-rank run does
+ * NOT follow the single-GPU trajectory (the loss and the dense gradients of a step given equal tables do, exactly).
+ * nvsm_dp_average_tables replaces every replica's tables by their mean over the ranks; cuNVSMTrainModel calls it at the
+ * end of every epoch and before every model dump, so that what rank 0 writes carries every rank's updates. A caller
+ * that checkpoints one rank without it drops the other ranks' embedding updates.
+ * nvsm_get_cost with world_size > 1 is a collective when called before nvsm_compute_gradients (it all-reduces a copy of
+ * the loss word); every rank must make the same sequence of calls. */
 int nvsm_comm_unique_id(char id[128]);
 int nvsm_comm_init(nvsm_model* m, const char id[128]);
+/* ncclCommCount of the handle's communicator (0 = none was built) */
+int nvsm_comm_size(nvsm_model* m, int* ranks);
+/* collective: W, E ← mean over ranks (synchronises the handle) */
+int nvsm_dp_average_tables(nvsm_model* m);
 /* Alternative transport for tests: the library hands a HOST double buffer to the callback, which must
  * sum it in place across ranks (e.g. torch.distributed gloo). */
 typedef int (*nvsm_allreduce_fn)(double* host_buf, int64_t count, void* user);
@@ -198,13 +225,19 @@ int nvsm_comm_selftest(int device);
  * roofline leg). enable=1 records around every launch of subsequent steps (adds sync points at
  * read-out only). nvsm_profile_get returns accumulated milliseconds and launch counts per kernel name;
  * names are listed by nvsm_profile_names (NUL-separated, double-NUL terminated). The ~50 event records of a fully
- * profiled step cost ≈5 % of its time (measured); nvsm_profile_select(name) restricts recording to one kernel group
+ * profiled step cost ≈5 % of its time (measured); nvsm_profile_select(names) restricts recording to the comma-separated kernel groups
  * (NULL or "" = all) so that a timed region can carry the roofline kernel's events only. */
 int nvsm_profile_enable(nvsm_model* m, int enable);
 int nvsm_profile_select(nvsm_model* m, const char* kernel);
 int nvsm_profile_reset(nvsm_model* m);
 int nvsm_profile_names(nvsm_model* m, char* buf, int64_t buf_bytes);
 int nvsm_profile_get(nvsm_model* m, const char* kernel, double* total_ms, int64_t* launches);
+
+/* roctx ranges (the reference's nvtxRangePush / nvtxRangePop, cpp/main.cu:386-431): forwarded to
+ * librocprofiler-sdk-roctx when it can be loaded, no-ops otherwise. The library itself brackets ComputeCost /
+ * ComputeGradients / UpdateParameters and every kernel group; the trainer adds Epoch / Batch / FetchData. */
+void nvsm_range_push(const char* name);
+void nvsm_range_pop(void);
 
 /* Debug / unit-test hooks for individual kernels (tests only; not part of the drop-in surface). */
 int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const float* hostB, float* hostC);

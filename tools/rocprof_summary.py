@@ -2,7 +2,9 @@
 """Condenses rocprofv3 rocpd (.db) outputs into the small text summaries committed under profiles/.
 
   tools/rocprof_summary.py stats  <stats.db>                 -> per-kernel calls / total / average / %
-  tools/rocprof_summary.py pmc    <fetch.db> <write.db>      -> per-kernel FETCH_SIZE / WRITE_SIZE per launch
+  tools/rocprof_summary.py pmc    <fetch.db> <write.db> [out.json [workload signature]] -> per-kernel FETCH_SIZE / WRITE_SIZE per launch
+  tools/rocprof_summary.py mfma   <mfma.db> [out.json]      -> per-kernel counter-based MFMA utilisation
+  tools/rocprof_summary.py timeline <stats.db> [marker]     -> start / duration / queue of every kernel of one step
 FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM); the pmc summary
 prints both the raw counter and the doubled ("corrected") read bytes.
 """
@@ -34,7 +36,42 @@ def stats(path):
     print("%-92s %8d %12.1f" % ("TOTAL", sum(a[0] for a in agg.values()), total / 1e3))
 
 
-def pmc(fetch_path, write_path, json_path=None):
+def mfma(path, json_path=None, cu_num=256):
+    """Counter-based MFMA utilisation per kernel: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
+    GRBM_GUI_ACTIVE. MfmaUtil = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * CU_NUM * 4) (derived_counters.xml, the gfx94x
+    formula the gfx950 tool falls back to); flops = SQ_INSTS_VALU_MFMA_MOPS_F32 * 512."""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+    ncol = next((c for c in ("counter_name", "name") if c in cols), None)
+    if ncol is None:
+        print("columns:", cols); return
+    agg = {}
+    for kname, cname, n, val, dur in db.execute(
+            "select kernel_name, %s, count(*), avg(value), avg(duration) from counters_collection group by kernel_name, %s" % (ncol, ncol)):
+        e = agg.setdefault(short(kname), {"launches": n, "avg_us": dur / 1e3})
+        e[cname] = e.get(cname, 0.0) + val
+    rows = []
+    for k, e in agg.items():
+        busy, mops, gui = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), e.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0), e.get("GRBM_GUI_ACTIVE", 0.0)
+        if mops <= 0:
+            continue
+        e["mfma_util_pct"] = 100.0 * busy / (gui * cu_num * 4) if gui else None
+        e["mfma_flops"] = mops * 512
+        e["TFLOPs_under_pmc"] = mops * 512 / (e["avg_us"] * 1e-6) / 1e12 if e["avg_us"] else None
+        rows.append((k, e))
+    print("%-70s %7s %10s %14s %14s %12s" % ("kernel", "calls", "avg_us", "MFMA GFLOP", "MfmaUtil %", "TF/s (pmc run)"))
+    for k, e in sorted(rows, key=lambda kv: -kv[1]["mfma_flops"]):
+        print("%-70s %7d %10.2f %14.3f %14.1f %12.1f" % (k[:70], e["launches"], e["avg_us"], e["mfma_flops"] / 1e9,
+                                                         e["mfma_util_pct"] or 0.0, e["TFLOPs_under_pmc"] or 0.0))
+    if json_path:
+        import json
+        with open(json_path, "w") as f:
+            json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE; "
+                               "MfmaUtil = 100*BUSY/(GUI_ACTIVE*256 CUs*4); the fp32 MFMA peak is 157.3 TF/s",
+                       "kernels": {k: e for k, e in rows}}, f, indent=1, sort_keys=True)
+
+
+def pmc(fetch_path, write_path, json_path=None, workload=None):
     out = {}
     for path, col in ((fetch_path, 0), (write_path, 1)):
         db = sqlite3.connect(path)
@@ -51,7 +88,8 @@ def pmc(fetch_path, write_path, json_path=None):
         js = {k: {"launches": e[0], "fetch_bytes_corrected": 2 * e[1] * 1024, "write_bytes": e[2] * 1024, "avg_us": e[3] / 1e3}
               for k, e in out.items()}
         with open(json_path, "w") as f:
-            json.dump({"note": "per-launch HBM-side bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); "
+            json.dump({"workload": workload,
+                       "note": "per-launch HBM-side bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); "
                                "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads), "
                                "WRITE_SIZE as reported", "kernels": js}, f, indent=1, sort_keys=True)
     print("%-70s %7s %14s %16s %14s %10s %12s" % ("kernel", "calls", "FETCH_KB/launch", "FETCHx2_MB(corr)", "WRITE_KB/launch", "avg_us", "HBM_GB/s(corr)"))
@@ -83,5 +121,7 @@ if __name__ == "__main__":
         timeline(sys.argv[2], *(sys.argv[3:4]))
     elif sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None, sys.argv[5] if len(sys.argv) > 5 else None)

@@ -209,6 +209,41 @@ int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const 
     });
 }
 
+int nvsm_debug_sort(int64_t n, int bits, const int32_t* keys, int32_t* keys_out, int32_t* vals_out, int repeats, float* avg_ms) {
+    NVSM_REQUIRE(keys); NVSM_REQUIRE(keys_out); NVSM_REQUIRE(vals_out);
+    return guarded([&] {
+        if (n <= 0) return;
+        cunvsm::DevBuf<int> K, KO, VO;
+        cunvsm::DevBuf<char> tmp;
+        K.alloc(n); KO.alloc(n); VO.alloc(n);
+        const size_t tb = cunvsm::sort_pairs_temp_bytes(n, bits);
+        tmp.alloc(tb, true);
+        int* err = nullptr;
+        NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&err), sizeof(int), hipHostMallocDefault));
+        *err = 0;
+        uint64_t epoch = 0;
+        NVSM_HIP_CHECK(hipMemcpy(K.p, keys, n * sizeof(int), hipMemcpyHostToDevice));
+        hipEvent_t e0, e1;
+        NVSM_HIP_CHECK(hipEventCreate(&e0)); NVSM_HIP_CHECK(hipEventCreate(&e1));
+        cunvsm::sort_pairs(tmp.p, tb, &epoch, K.p, KO.p, nullptr, VO.p, n, bits, err, nullptr);      // warm-up
+        NVSM_HIP_CHECK(hipEventRecord(e0, nullptr));
+        const int reps = repeats > 0 ? repeats : 1;
+        for (int r = 0; r < reps; ++r)      // repeats: the arrival counter keeps growing across calls
+            cunvsm::sort_pairs(tmp.p, tb, &epoch, K.p, KO.p, nullptr, VO.p, n, bits, err, nullptr);
+        NVSM_HIP_CHECK(hipEventRecord(e1, nullptr));
+        NVSM_HIP_CHECK(hipDeviceSynchronize());
+        float ms = 0.f;
+        NVSM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (avg_ms) *avg_ms = ms / reps;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        const int code = *err;
+        (void)hipHostFree(err);
+        if (code) throw Error(NVSM_ERR_DEVICE, "sort reported an error");
+        NVSM_HIP_CHECK(hipMemcpy(keys_out, KO.p, n * sizeof(int), hipMemcpyDeviceToHost));
+        NVSM_HIP_CHECK(hipMemcpy(vals_out, VO.p, n * sizeof(int), hipMemcpyDeviceToHost));
+    });
+}
+
 int nvsm_debug_gather_mean(int64_t num_rows, int dim, const float* table, const int64_t* idx, const float* wts,
                            int window, int64_t num_out, float* out) {
     NVSM_REQUIRE(table); NVSM_REQUIRE(idx); NVSM_REQUIRE(out);

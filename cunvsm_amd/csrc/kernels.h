@@ -39,7 +39,7 @@ void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* i
 void launch_colsum_finalize(const double* sums, int dim, float* out, hipStream_t s);   // no-BN grad_bias = Σdy
 
 // codes a kernel stores into the engine's error word (page-locked host memory, read at the next synchronisation point)
-enum { NVSM_BAD_WORD_ID = 1, NVSM_BAD_ENTITY_ID = 2, NVSM_NONFINITE_BASE = 16 };
+enum { NVSM_BAD_WORD_ID = 1, NVSM_BAD_ENTITY_ID = 2, NVSM_SORT_TIMEOUT = 3, NVSM_NONFINITE_BASE = 16 };
 // ids outside [0, limit) become row 0 and raise `code` in *err_flag (err_flag may be null: tests of single kernels)
 void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, int64_t limit, int* err_flag, int code, hipStream_t s);
 void launch_step_prologue(const int64_t* words64, int* widx, int64_t nW, const int64_t* labels, int64_t B, int R,
@@ -95,9 +95,12 @@ void launch_materialize_grad_entity_l2(const float* coef, const float* proj, con
                                        int de, float* out, float* msq, hipStream_t s);
 
 // ---- batch → CSR by table row (replaces the atomic scatter of update_repr_kernel, cpp/storage.cu:37-49)
+// Stable radix sort of (key, value) pairs by the low `bits` bits of the key (sort.hip). `temp` must be zero-filled ONCE when
+// allocated; *epoch (host, starts at 0, one per workspace) is the value its arrival counter has reached. vals_in may be
+// null (= 0, 1, 2, …). err_flag: the engine's error word (a grid-wide wait that never completes stores NVSM_SORT_TIMEOUT).
 size_t sort_pairs_temp_bytes(int64_t n, int bits);
-void sort_pairs(void* temp, size_t temp_bytes, const int* keys_in, int* keys_out, const int* vals_in, int* vals_out,
-                int64_t n, int bits, hipStream_t s);
+void sort_pairs(void* temp, size_t temp_bytes, uint64_t* epoch, const int* keys_in, int* keys_out, const int* vals_in,
+                int* vals_out, int64_t n, int bits, int* err_flag, hipStream_t s);
 struct Csr {
     int* sorted_key;      // [n]
     int* sorted_entry;    // [n]  entry ids ordered by row (stable)
@@ -120,6 +123,7 @@ struct Csr {
 };
 constexpr int kChunk = 64;    // entries per level-1 chunk of a long row
 constexpr int kFan = 64;      // level-1 partials per level-2 chunk
+
 void launch_csr_build(const Csr& c, hipStream_t s);   // bounds + long-row chunk list, from sorted_key
 bool row_pass_split(const Csr& c);                    // rows >= entries: touched-row list + streaming pass over the rest
 

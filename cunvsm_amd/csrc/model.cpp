@@ -239,7 +239,7 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
     t.partial2_q.alloc(t.max_chunks2, true);
     t.sort_bits = bits_for(rows);
     t.sort_temp_bytes = sort_pairs_temp_bytes(max_entries, t.sort_bits);
-    t.sort_temp.alloc(t.sort_temp_bytes + 16);
+    t.sort_temp.alloc(t.sort_temp_bytes, true);      // zero once: the arrival counter only ever grows
 }
 
 Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1), rng_(1) {
@@ -284,7 +284,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, hipEventDisableTiming));
     for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_copied_, &ev_step_begin_[0], &ev_step_begin_[1],
-                          &ev_host_ids_[0], &ev_host_ids_[1]})
+                          &ev_host_ids_[0], &ev_host_ids_[1], &ev_gathered_})
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&err_host_), sizeof(int), hipHostMallocDefault));
     *err_host_ = 0;
@@ -303,8 +303,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     if (cfg.sampler == NVSM_SAMPLER_HOST_MINSTD)
         for (int p = 0; p < 2; ++p) NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_ids_pin_[p]), N * sizeof(int64_t), hipHostMallocDefault));
     if (cfg.world_size > 1) loss_tmp_.alloc(1, true);
-    widx_.alloc(B * w); ids_.alloc(N); iota_.alloc(std::max<int64_t>(B * w, N));
-    launch_iota(iota_.p, static_cast<int64_t>(iota_.n), stream_);
+    widx_.alloc(B * w); ids_.alloc(N);
     phrase_.alloc(B * dw); phrase_alt_.alloc(B * dw); phrase_p_ = phrase_.p; pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
     if (cfg.l2_normalize_phrase_reprs) { phrase_raw_.alloc(B * dw); phrase_norms_.alloc(B); }
     if (cfg.l2_normalize_entity_reprs) { grad_entity_.alloc(N * de); ge_msq_.alloc(N); }
@@ -327,7 +326,7 @@ Model::~Model() {
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
     for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_, ev_copied_, ev_step_begin_[0], ev_step_begin_[1],
-                         ev_host_ids_[0], ev_host_ids_[1]}) if (e) (void)hipEventDestroy(e);
+                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_}) if (e) (void)hipEventDestroy(e);
     for (int p = 0; p < 2; ++p) if (host_ids_pin_[p]) (void)hipHostFree(host_ids_pin_[p]);
     if (err_host_) (void)hipHostFree(err_host_);
     if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
@@ -367,6 +366,7 @@ void Model::raise_device_error() {
     *err_host_ = 0;
     if (code == NVSM_BAD_WORD_ID) throw Error(NVSM_ERR_INVALID_ARGUMENT, "a word id of the batch is outside [0, num_words)");
     if (code == NVSM_BAD_ENTITY_ID) throw Error(NVSM_ERR_INVALID_ARGUMENT, "a document id of the batch is outside [0, num_entities)");
+    if (code == NVSM_SORT_TIMEOUT) throw Error(NVSM_ERR_DEVICE, "the row sort's grid-wide wait timed out (workgroups not co-resident?)");
     static const char* const names[] = {"phrase", "pre (projection)", "proj", "probs", "grad_proj", "grad_phrase", "grad_transform",
                                         "word_representations", "entity_representations", "transform"};
     const int which = code - NVSM_NONFINITE_BASE;
@@ -637,17 +637,21 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     }
     ++step_count_;
 
-    // Row-order (CSR) of both tables for the update, on the side stream: needs only the indices.
+    // Row-order (CSR) of both tables for the update, on the side streams: needs only the indices.
     NVSM_HIP_CHECK(hipEventRecord(ev_inputs_, stream_));
     inputs_recorded_ = true;
     // two side streams: the sorts are latency-bound chains of small launches, so the two tables' builds run next to
     // each other (at batch 4096 one behind the other they were the longest chain of the whole step)
-    NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_inputs_, 0));
-    NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_inputs_, 0));
-    { PROF_ON("csr_entities", aux_stream_); build_csr(ents_, ids_.p, N, aux_stream_); }
-    NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, aux_stream_));
-    { PROF_ON("csr_words", aux2_stream_); build_csr(words_, widx_.p, B * w, aux2_stream_); }
-    NVSM_HIP_CHECK(hipEventRecord(ev_csr_, aux2_stream_));
+    static const int csr_after = [] { const char* e = std::getenv("NVSM_CSR_AFTER"); return e ? std::atoi(e) : 0; }();
+    auto launch_csr_builds = [&](hipEvent_t after) {
+        NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, after, 0));
+        NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, after, 0));
+        { PROF_ON("csr_entities", aux_stream_); build_csr(ents_, ids_.p, N, aux_stream_); }
+        NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, aux_stream_));
+        { PROF_ON("csr_words", aux2_stream_); build_csr(words_, widx_.p, B * w, aux2_stream_); }
+        NVSM_HIP_CHECK(hipEventRecord(ev_csr_, aux2_stream_));
+    };
+    if (csr_after == 0) launch_csr_builds(ev_inputs_);
 
     // F3: phrase representations (objective.cu:126-130). The previous step's dT GEMM may still be reading its phrase
     // matrix on the side stream: write the other one.
@@ -659,6 +663,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         // optional phrase normaliser (objective.cu:136-142): the raw means stay cached for its backward pass
         if (l2p) launch_l2_rows_forward(phrase_raw_.p, B, dw, phrase_p_, phrase_norms_.p, stream_);
     }
+    if (csr_after == 1) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     debug_check(phrase_p_, B * dw, 0);                  // CHECK_MATRIX(*result->phrase_reprs_), objective.cu:134,141
 
     // F5: projection GEMM  pre[B][de] = phrase[B][dw] · Tt[dw][de] (+ b when no BN)   (params.cu:417-421)
@@ -673,6 +678,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
     const double bn_n = (cfg_.world_size > 1 && cfg_.sync_batch_norm) ? B_global : static_cast<double>(B);
+    if (csr_after == 2) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     debug_check(pre_.p, B * de, 1);                     // CHECK_MATRIX(*result->word_projections_), objective.cu:152
     // F6: batch statistics (cudnn_utils.cu:107-124), ε = 1e-4 (objective.cu:114)
     if (cfg_.batch_normalization && cfg_.world_size > 1 && cfg_.sync_batch_norm) {
@@ -707,6 +713,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         a.inv_de = static_cast<float>(std::exp(-std::log(static_cast<double>(de))));
         launch_loss(a, stream_);
     }
+    if (csr_after == 3) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     NVSM_HIP_CHECK(hipGetLastError());      // a failed launch of any kernel above surfaces here, not at the next sync
     have_forward_ = true;
     if (debug_) {
@@ -854,7 +861,7 @@ Csr Model::csr_of(TableState& t, int64_t n) {
 }
 
 void Model::build_csr(TableState& t, const int* keys, int64_t n, hipStream_t s) {
-    sort_pairs(t.sort_temp.p, t.sort_temp_bytes, keys, t.sorted_key.p, iota_.p, t.sorted_entry.p, n, t.sort_bits, s);
+    sort_pairs(t.sort_temp.p, t.sort_temp_bytes, &t.sort_epoch, keys, t.sorted_key.p, nullptr, t.sorted_entry.p, n, t.sort_bits, err_host_, s);
     launch_csr_build(csr_of(t, n), s);
 }
 
@@ -1025,10 +1032,16 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     // side stream 1 (behind the documents CSR build): the documents update, HBM-bound — next to the MFMA-bound dx GEMM
     // now, and free to run on next to the next step's projection GEMM; the next loss kernel joins it
     NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_loss_, 0));
+    // ... but only once the dx GEMM is through at large batches: next to the MFMA-bound GEMM the row pass (100 k short-lived
+    // waves) keeps the GEMM's workgroups from becoming resident — measured at B = 51 200: dx GEMM 132 → 203 us, dT GEMM
+    // 195 → 402 us, step 1.099 → 1.126 ms. (NVSM_DOCS_AFTER_DX=0/1 overrides.)
+    static const int docs_after_dx_env = [] { const char* e = std::getenv("NVSM_DOCS_AFTER_DX"); return e ? std::atoi(e) : -1; }();
+    const bool docs_after_dx = docs_after_dx_env >= 0 ? docs_after_dx_env != 0 : B_ >= 16384;
+    if (docs_after_dx) { backward_dx(); NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_bwdx_, 0)); }
     update_entities(lr, sl, aux_stream_);
     NVSM_HIP_CHECK(hipEventRecord(ev_E_done_, aux_stream_));
     E_pending_ = true;
-    backward_dx();
+    if (!docs_after_dx) backward_dx();
     if (dp) {
         backward_T(stream_);
     } else {

@@ -82,10 +82,11 @@ struct TableState {           // one embedding table + its optimiser state + its
     // CSR workspace
     DevBuf<int> sorted_key, sorted_entry, chunk_base, chunk_desc, chunk2_base, chunk2_desc;
     DevBuf<int> touched;      // rows with entries (Csr::touched)
-    DevBuf<int> csr_zeroed;   // [row_begin (rows) | row_end (rows) | num_chunks (2)]: one memset per step clears all three
+    DevBuf<int> csr_zeroed;   // [row_begin (rows) | row_end (rows) | num_chunks (2) | num_touched]: one memset per step clears them all
     DevBuf<float> partial, partial_q, partial2, partial2_q;
     DevBuf<char> sort_temp;
     size_t sort_temp_bytes = 0;
+    uint64_t sort_epoch = 0;      // value the workspace's grid-barrier arrival counter has reached (sort.hip)
     int sort_bits = 1;
     int max_chunks = 0, max_chunks2 = 0;
     int64_t max_entries = 0;
@@ -163,6 +164,7 @@ class Model {
     hipEvent_t ev_inputs_ = nullptr, ev_csr_ = nullptr;
     // fused step(): the documents update (HBM bound) and the dT GEMM (MFMA bound) run on the side stream next to the
     // dx GEMM and the words update on the main stream
+    hipEvent_t ev_gathered_ = nullptr;
     hipEvent_t ev_loss_ = nullptr, ev_dx_ = nullptr, ev_bwdx_ = nullptr, ev_E_done_ = nullptr, ev_T_done_ = nullptr;
     std::minstd_rand0 rng_;           // include/cuNVSM/base.h:36
     uint64_t device_seed_ = 1, step_count_ = 0;
@@ -178,7 +180,7 @@ class Model {
     hipStream_t copy_stream_ = nullptr;
     hipEvent_t ev_copied_ = nullptr, ev_step_begin_[2] = {nullptr, nullptr};
     bool copied_recorded_ = false, last_batch_on_host_ = false;
-    DevBuf<int> widx_, ids_, iota_;
+    DevBuf<int> widx_, ids_;
     const float* wwts_ = nullptr;     // device pointer or null
     const float* instw_ = nullptr;
     const int64_t* labels_dev_ = nullptr;

@@ -244,6 +244,8 @@ int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const 
 /* Queues a kernel on the handle's stream that spins for `microseconds` of GPU wall clock: profiling runs put it in
  * front of a step so that the host has queued the whole step before the GPU starts it (tools/rocprof_summary.py timeline). */
 int nvsm_debug_delay(nvsm_model* m, int microseconds);
+/* the stable (row, entry) radix sort alone: keys of `bits` significant bits in, sorted keys + their original positions out */
+int nvsm_debug_sort(int64_t n, int bits, const int32_t* keys, int32_t* keys_out, int32_t* vals_out, int repeats, float* avg_ms);
 int nvsm_debug_gather_mean(int64_t num_rows, int dim, const float* table, const int64_t* idx, const float* wts,
                            int window, int64_t num_out, float* out);
 

@@ -69,6 +69,7 @@ IndriDiskIndex* IndriDiskIndex::open(const std::string& repository_path) {
     const std::string dir = repository_path + "/index/" + index_name + "/";
 
     std::unique_ptr<IndriDiskIndex> idx(new IndriDiskIndex);
+    idx->repository_path_ = repository_path;
     const std::string manifest = read_file(dir + "manifest");
     const std::string corpus = xml_value(manifest, "corpus");
     if (corpus.empty() || xml_value(manifest, "type") != "DiskIndex") NVSM_LOG(FATAL) << "Unable to open Indri index: " << dir << "manifest is not a DiskIndex manifest";
@@ -174,14 +175,94 @@ TERMID_T IndriDiskIndex::term(const std::string& t) {
     return it == by_string_.end() ? 0 : it->second;
 }
 
-std::vector<DOCID_T> IndriDiskIndex::documentIDsFromDocno(const std::vector<std::string>&) {
-    NVSM_LOG(FATAL) << "document lists need the repository's docno key files, which this reader does not decode";
-    return {};
+// ---------------------------------------------------------------------------------------------------------------------
+// docno look-ups: collection/forwardLookup0 (document id → docno) and collection/reverseLookup0 (docno → document id),
+// what QueryEnvironment::documentIDsFromMetadata("docno", …) and CompressedCollection::retrieveMetadatum(doc, "docno")
+// read (cpp/data_indri.cpp:695,571-589). Both are Lemur "Keyfile" B-trees of 4 KiB pages. Layout as established on the
+// reference's own repository (test_data/Brown_index/collection, 500 documents ca01 … cr09 ↔ ids 1 … 500):
+//   leaf page   u16be record count | u16be bytes used | u16be prefix length L | u16be level (0 = leaf) | … 28 bytes of
+//               header in all; then `count` u16be record offsets (relative to byte 28 of the page, records grow down from
+//               the page end, table order = key order); the last L bytes of the page are the key prefix all records of
+//               the page share and do not repeat
+//   record      u8 key-suffix length, suffix, u8 value length, value
+//   forward     key = the id as six base-64 digits, most significant first, each OR 0x40 ("@@@@Eq" = 369); value =
+//               the docno, NUL-terminated
+//   reverse     key = the docno; value = the id as little-endian int32
+// Index (level > 0) pages are not needed: every leaf of the file is visited once and the pairs go into hash maps.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t kKeyfilePage = 4096, kKeyfileHeader = 28;
+
+template <typename Fn>
+void for_each_keyfile_record(const std::string& file, const std::string& path, Fn&& fn) {
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(file.data());
+    auto be16 = [](const unsigned char* p) { return static_cast<size_t>(p[0]) << 8 | p[1]; };
+    for (size_t page = kKeyfilePage; page + kKeyfilePage <= file.size(); page += kKeyfilePage) {     // page 0 is the file header
+        const unsigned char* pg = base + page;
+        const size_t count = be16(pg), prefix_len = be16(pg + 4), level = be16(pg + 6);
+        if (count == 0 || level != 0) continue;
+        if (kKeyfileHeader + 2 * count + prefix_len > kKeyfilePage) continue;                        // not a leaf page
+        const std::string prefix(reinterpret_cast<const char*>(pg + kKeyfilePage - prefix_len), prefix_len);
+        for (size_t i = 0; i < count; ++i) {
+            const size_t at = kKeyfileHeader + be16(pg + kKeyfileHeader + 2 * i);
+            NVSM_CHECK(at + 2 <= kKeyfilePage) << path << ": record offset outside its page";
+            const size_t klen = pg[at];
+            NVSM_CHECK(at + 1 + klen + 1 <= kKeyfilePage) << path << ": key runs over the page end";
+            const size_t vlen = pg[at + 1 + klen];
+            NVSM_CHECK(vlen < 128) << path << ": values of 128 bytes or more are not supported by this reader";
+            NVSM_CHECK(at + 1 + klen + 1 + vlen <= kKeyfilePage) << path << ": value runs over the page end";
+            fn(prefix + std::string(reinterpret_cast<const char*>(pg + at + 1), klen), pg + at + 1 + klen + 1, vlen);
+        }
+    }
+}
+}  // namespace
+
+void IndriDiskIndex::load_docno_lookups() {
+    if (docnos_loaded_) return;
+    docnos_loaded_ = true;
+    const std::string fwd_path = repository_path_ + "/collection/forwardLookup0", rev_path = repository_path_ + "/collection/reverseLookup0";
+    const std::string fwd = read_file(fwd_path, false), rev = read_file(rev_path, false);
+    if (fwd.empty() || rev.empty())
+        NVSM_LOG(FATAL) << "the repository has no docno look-up files (" << fwd_path << ", " << rev_path
+                        << "): it was built without <metadata><forward>docno</forward><backward>docno</backward></metadata>";
+    for_each_keyfile_record(fwd, fwd_path, [&](const std::string& key, const unsigned char* value, size_t vlen) {
+        int64_t id = 0;
+        for (const char c : key) {
+            NVSM_CHECK((static_cast<unsigned char>(c) & 0xc0) == 0x40) << fwd_path << ": unexpected key byte";
+            id = id * 64 + (static_cast<unsigned char>(c) & 0x3f);
+        }
+        size_t n = vlen;
+        while (n > 0 && value[n - 1] == 0) --n;                    // stored NUL-terminated
+        docno_of_[static_cast<DOCID_T>(id)] = std::string(reinterpret_cast<const char*>(value), n);
+    });
+    for_each_keyfile_record(rev, rev_path, [&](const std::string& key, const unsigned char* value, size_t vlen) {
+        NVSM_CHECK(vlen == 4) << rev_path << ": document ids are expected as 4-byte integers";
+        uint32_t id = 0;
+        std::memcpy(&id, value, 4);
+        id_of_docno_[key] = static_cast<DOCID_T>(id);
+    });
+    NVSM_CHECK(docno_of_.size() == total_documents_ && id_of_docno_.size() == total_documents_)
+        << "docno look-up files hold " << docno_of_.size() << " / " << id_of_docno_.size() << " entries for " << total_documents_ << " documents";
 }
 
-std::string IndriDiskIndex::docno(DOCID_T) {
-    NVSM_LOG(FATAL) << "docno look-ups need the repository's docno key files, which this reader does not decode";
-    return std::string();
+// QueryEnvironment::documentIDsFromMetadata("docno", list) (cpp/data_indri.cpp:695): one id per listed docno, in list order
+std::vector<DOCID_T> IndriDiskIndex::documentIDsFromDocno(const std::vector<std::string>& docnos) {
+    load_docno_lookups();
+    std::vector<DOCID_T> ids;
+    ids.reserve(docnos.size());
+    for (const std::string& d : docnos) {
+        const auto hit = id_of_docno_.find(d);
+        if (hit == id_of_docno_.end()) NVSM_LOG(FATAL) << "document list names " << d << ", which the index does not hold";
+        ids.push_back(hit->second);
+    }
+    return ids;
+}
+
+std::string IndriDiskIndex::docno(DOCID_T doc) {
+    load_docno_lookups();
+    const auto hit = docno_of_.find(doc);
+    NVSM_CHECK(hit != docno_of_.end()) << "no docno for document " << doc;
+    return hit->second;
 }
 
 }  // namespace nvsm_host

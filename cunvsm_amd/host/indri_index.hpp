@@ -15,8 +15,8 @@
 //                       totalCount, documentCount, maxDocLen, minDocLen, localID, invertedOffset, invertedLength;
 //                       termID = localID + number of frequent terms; leaves are stored in key order
 //   RVL                 little-endian base-128, the LAST byte of a number has bit 7 set
-// The docno lookups (collection/{forward,reverse}Lookup0, a different key-file format) are not read: --document_list
-// is refused for Indri repositories.
+//   collection/forwardLookup0, reverseLookup0   docno ↔ document id (Lemur Keyfile B-trees; layout in indri_index.cpp),
+//                       read on the first docno look-up (--document_list, build_document_identifiers_map)
 #pragma once
 
 #include <unordered_map>
@@ -46,6 +46,11 @@ class IndriDiskIndex : public IndexInterface {
 
  private:
     IndriDiskIndex() {}
+    void load_docno_lookups();
+    std::string repository_path_;
+    bool docnos_loaded_ = false;
+    std::unordered_map<DOCID_T, std::string> docno_of_;
+    std::unordered_map<std::string, DOCID_T> id_of_docno_;
     DOCID_T document_base_ = 1, document_maximum_ = 1;
     uint64_t total_documents_ = 0, unique_terms_ = 0, total_terms_ = 0;
     std::vector<uint32_t> document_lengths_;

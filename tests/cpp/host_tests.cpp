@@ -493,6 +493,39 @@ static void test_IndriSource_Brown() {
     if (!(str_instances == want)) for (const auto& kv : str_instances) std::printf("      got %zu: %s\n", kv.first, kv.second.c_str());
 }
 
+// ---- --document_list on an Indri repository: QueryEnvironment::documentIDsFromMetadata("docno", …) (cpp/data_indri.cpp:695)
+// and retrieveMetadatum(doc, "docno") (:571-589) through the repository's own docno key files. The Brown repository holds
+// the 500 Brown-corpus files ca01 … cr09 in that order as documents 1 … 500. ----
+static void test_IndriRepository_docno_lookups() {
+    if (g_brown_path.empty()) { std::printf("    (skipped: NVSM_BROWN_INDEX not set)\n"); return; }
+    std::unique_ptr<IndriDiskIndex> index(IndriDiskIndex::open(g_brown_path));
+    const std::vector<DOCID_T> ids = index->documentIDsFromDocno({"ca01", "cj75", "cr09", "ca44", "cb01", "cj76"});
+    EXPECT_VEC(ids, 1, 369, 500, 44, 45, 370);
+    EXPECT_EQ(index->docno(1), std::string("ca01"));
+    EXPECT_EQ(index->docno(369), std::string("cj75"));
+    EXPECT_EQ(index->docno(500), std::string("cr09"));
+    // every document: forward and reverse files agree
+    for (DOCID_T d = index->documentBase(); d < index->documentMaximum(); ++d) {
+        const std::vector<DOCID_T> back = index->documentIDsFromDocno({index->docno(d)});
+        EXPECT_EQ(back.size(), 1u);
+        if (back.size() == 1) EXPECT_EQ(back[0], d);
+    }
+    bool died = false;
+    try { index->documentIDsFromDocno({"zz99"}); } catch (const FatalError&) { died = true; }
+    EXPECT_TRUE(died);
+
+    // a document list selects and ORDERS the corpus (model ids follow the list), cpp/data_indri.cpp:693-717
+    RNG rng;
+    const std::vector<std::string> list = {"cr09", "ca01", "cj75"};
+    IndexSource source(IndriDiskIndex::open(g_brown_path), 16, &rng, 0, 0, 0, 0, false, false, &list, nullptr, false, NONE);
+    EXPECT_EQ(source.corpus_size(), 3u);
+    const IndexSource::DocumentIdMapping want_docs = {{0, 500}, {1, 1}, {2, 369}};
+    EXPECT_TRUE(source.document_id_mapping() == want_docs);
+    const std::map<std::string, int64_t> by_docno = source.build_document_identifiers_map();
+    const std::map<std::string, int64_t> want_by_docno = {{"cr09", 0}, {"ca01", 1}, {"cj75", 2}};
+    EXPECT_TRUE(by_docno == want_by_docno);
+}
+
 int main(int argc, char** argv) {
     log_to_stderr() = false;
     if (const char* e = std::getenv("NVSM_BROWN_INDEX")) g_brown_path = e;
@@ -516,6 +549,7 @@ int main(int argc, char** argv) {
         {"Metadata.roundtrip", test_Metadata_roundtrip},
         {"TrectextIndex.end_to_end", test_TrectextIndex},
         {"IndriSourceTest.Brown", test_IndriSource_Brown},
+        {"IndriRepository.docno_lookups", test_IndriRepository_docno_lookups},
     };
     int failed_tests = 0;
     for (const auto& t : tests) {

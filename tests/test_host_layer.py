@@ -29,7 +29,7 @@ CASES = [
     "IndriSourceTest.StochasticIndriSource", "IndriSourceTest.StochasticIndriSource_Resampling",
     "IndriSourceTest.StochasticIndriSource_SelfInformation",
     "MetaSourceTest.AsyncSource", "MetaSourceTest.RepeatingSource",
-    "Base.utils", "Batch.swap", "Metadata.roundtrip", "TrectextIndex.end_to_end", "IndriSourceTest.Brown",
+    "Base.utils", "Batch.swap", "Metadata.roundtrip", "TrectextIndex.end_to_end", "IndriSourceTest.Brown", "IndriRepository.docno_lookups",
 ]
 
 

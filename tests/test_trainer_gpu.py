@@ -116,6 +116,37 @@ def test_trains_from_the_indri_repository(tmp_path):
     assert meta.total_terms > 300000
 
 
+def test_document_list_on_the_indri_repository(tmp_path):
+    """--document_list with docnos resolved through the repository's own key files (cpp/data_indri.cpp:693-717): the model's
+    documents are the listed ones, in list order."""
+    brown = os.path.join(ROOT, "tests", "golden", "Brown_index")
+    docnos = ["cj%02d" % i for i in range(80, 0, -1)] + ["ca01", "cr09"]
+    lst = tmp_path / "docs.txt"
+    lst.write_text("\n".join(docnos) + "\n")
+    out = str(tmp_path / "brown_list")
+    r = run_trainer(["--word_repr_size", "32", "--entity_repr_size", "16", "--window_size", "8", "--num_random_entities", "3", "--seed", "1",
+                     "--update_method", "sgd", "--batch_size", "1024", "--nonlinearity", "tanh", "--weighting", "uniform",
+                     "--document_list", str(lst), "--num_epochs", "1", "--output", out, brown])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "corpus size=82" in r.stderr
+    meta = parse_metadata(out + "_meta")
+    # cj01 … cj80 are documents 295 … 374 of the repository, ca01 is 1, cr09 is 500
+    assert [o.index_object_id for o in meta.object] == list(range(374, 294, -1)) + [1, 500]
+    assert [o.model_object_id for o in meta.object] == list(range(82))
+    bad = tmp_path / "bad.txt"
+    bad.write_text("ca01\nnot_a_docno\n")
+    r = run_trainer(["--seed", "1", "--update_method", "sgd", "--nonlinearity", "tanh", "--document_list", str(bad), brown])
+    assert r.returncode == 1 and "not_a_docno" in r.stderr
+
+
+def test_multi_gpu_flags_fail_cleanly_on_one_gpu(tmp_path):
+    """--gpus N spawns one rank per GPU; on the 1-GPU box it must refuse with a clear message instead of hanging."""
+    r = run_trainer(["--gpus", "2", "--seed", "1", "--update_method", "sgd", "--nonlinearity", "tanh", CRANFIELD], timeout=120)
+    assert r.returncode == 1 and "--gpus 2 but only 1 HIP device" in r.stderr
+    r = run_trainer(["--world_size", "2", "--rank", "2", "--seed", "1", "--update_method", "sgd", "--nonlinearity", "tanh", CRANFIELD], timeout=120)
+    assert r.returncode == 1 and "bad --world_size / --rank" in r.stderr
+
+
 def test_rccl_selftest_and_pinned_alloc():
     import ctypes as C
     import cunvsm_amd as ca

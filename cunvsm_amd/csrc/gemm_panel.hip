@@ -13,6 +13,8 @@
 #include "kernels.h"
 #include "device_utils.h"
 
+#include <cstdlib>
+
 namespace cunvsm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -235,6 +237,13 @@ bool launch_gemm_panel(int a_layout, int b_layout, const float* A, const float* 
     // dT 90 us vs 114 us tiled; dx·T (N = 300) 107 vs 109 us. Inside the step only dT keeps its gain: the forward
     // GEMM overlaps the side-stream sort, and a grid that needs every workgroup slot of the chip (458 of 512) gets a
     // second scheduling round as soon as anything else is resident (136 us in-step) — it stays on the 800-tile kernel.
+    static const int panel_fwd = [] { const char* e = std::getenv("NVSM_PANEL_FWD"); return e ? std::atoi(e) : 0; }();
+    if (panel_fwd && a_layout == 0 && b_layout == 0 && slabs == 1 && N == 256 && M >= 16384) {
+        g.npanels = 1;
+        if (panel_fwd == 1) { g.mpanels = (M + 207) / 208; launch_panel<0, 0, 13, 4, 32>(g, s); }
+        else { g.mpanels = (M + 111) / 112; launch_panel<0, 0, 7, 4, 32>(g, s); }
+        return true;
+    }
     if (a_layout == 1 && b_layout == 0 && slabs >= 64 && N <= 256 && N > 128 && M <= 320 && M > 160) {  // dT, split-K slabs
         g.mpanels = 2; g.npanels = 1;
         launch_panel<1, 0, 10, 4, 32>(g, s);                    // (2 row halves) x slabs workgroups, 160 accumulators

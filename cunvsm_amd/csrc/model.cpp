@@ -643,13 +643,23 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // two side streams: the sorts are latency-bound chains of small launches, so the two tables' builds run next to
     // each other (at batch 4096 one behind the other they were the longest chain of the whole step)
     static const int csr_after = [] { const char* e = std::getenv("NVSM_CSR_AFTER"); return e ? std::atoi(e) : 0; }();
+    // Which side stream builds which table's CSR. Side stream 1 still carries the PREVIOUS step's documents update when this
+    // step begins (it runs ~150 us into it), so a sort queued there starts late and lands on the loss kernel; side stream 2
+    // (dT GEMM + projection update of the previous step) is free by then. NVSM_SORT_LAYOUT: 0 = documents on side stream 1,
+    // words on 2 (round 1); 1 = both on 2, words first (default); 2 = both on 2, documents first; 3 = documents on 2, words
+    // on 1. Measured at the bench shape (two interleaved rounds, M windows/s | loss-kernel fraction of 8 TB/s):
+    // 0: 45.10 | 0.73   1: 45.55 | 0.75   2: 45.24 | 0.80   3: 45.18 | 0.81; started only after the word gather
+    // (NVSM_CSR_AFTER=1) layout 1 gives 44.9 | 0.76 with the word gather back at its stand-alone 67 us.
+    static const int sort_layout = [] { const char* e = std::getenv("NVSM_SORT_LAYOUT"); return e ? std::atoi(e) : 1; }();
     auto launch_csr_builds = [&](hipEvent_t after) {
+        hipStream_t se = (sort_layout == 0) ? aux_stream_ : aux2_stream_;
+        hipStream_t sw = (sort_layout == 3) ? aux_stream_ : aux2_stream_;
         NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, after, 0));
         NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, after, 0));
-        { PROF_ON("csr_entities", aux_stream_); build_csr(ents_, ids_.p, N, aux_stream_); }
-        NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, aux_stream_));
-        { PROF_ON("csr_words", aux2_stream_); build_csr(words_, widx_.p, B * w, aux2_stream_); }
-        NVSM_HIP_CHECK(hipEventRecord(ev_csr_, aux2_stream_));
+        auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, ids_.p, N, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
+        auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, widx_.p, B * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
+        if (sort_layout == 1) { wrds(); ents(); } else { ents(); wrds(); }
+        if (se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
     };
     if (csr_after == 0) launch_csr_builds(ev_inputs_);
 
@@ -876,7 +886,7 @@ static void fill_adam_consts(RowPassArgs& a, float bc, float sl) {
     a.c_reg = static_cast<float>((1.0 - b1) * static_cast<double>(sl));            // updates_adam.cu:208-212
 }
 
-void Model::update_entities(float lr, float sl, hipStream_t strm) {
+void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row_pass_after) {
     const int64_t N = B_ * R_;
     const int de = cfg_.entity_repr_size;
     TableState& t = ents_;
@@ -911,6 +921,8 @@ void Model::update_entities(float lr, float sl, hipStream_t strm) {
     // (Capping this grid so that GEMM workgroups of the other stream find free registers on every CU was measured in
     // the fused step: 1.30 -> 1.31-1.33 ms, no gain; RowPassArgs::max_blocks stays 0.)
     { PROF_ON("chunk_pass_entities", strm); launch_chunk_pass(c, a, strm); }
+    // the (usually empty) chunk passes only need the loss kernel's outputs; the row pass may be held back further
+    if (row_pass_after) NVSM_HIP_CHECK(hipStreamWaitEvent(strm, row_pass_after, 0));
     { PROF_ON("row_pass_entities", strm); launch_row_pass(c, a, strm); }
     if (swap_sc) t.sc_cur ^= 1;
 }
@@ -1037,8 +1049,8 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     // 195 → 402 us, step 1.099 → 1.126 ms. (NVSM_DOCS_AFTER_DX=0/1 overrides.)
     static const int docs_after_dx_env = [] { const char* e = std::getenv("NVSM_DOCS_AFTER_DX"); return e ? std::atoi(e) : -1; }();
     const bool docs_after_dx = docs_after_dx_env >= 0 ? docs_after_dx_env != 0 : B_ >= 16384;
-    if (docs_after_dx) { backward_dx(); NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_bwdx_, 0)); }
-    update_entities(lr, sl, aux_stream_);
+    if (docs_after_dx) backward_dx();
+    update_entities(lr, sl, aux_stream_, docs_after_dx ? ev_bwdx_ : nullptr);
     NVSM_HIP_CHECK(hipEventRecord(ev_E_done_, aux_stream_));
     E_pending_ = true;
     if (!docs_after_dx) backward_dx();

@@ -142,7 +142,7 @@ class Model {
     Csr csr_of(TableState& t, int64_t n);
     void backward_dx();                                  // B5, B7, B9 on the main stream
     void backward_T(hipStream_t s);                      // B6 (+ its all-reduce)
-    void update_entities(float lr, float sl, hipStream_t s);
+    void update_entities(float lr, float sl, hipStream_t s, hipEvent_t row_pass_after = nullptr);
     void update_words(float lr, float sl);
     void update_transform(float lr, float sl, hipStream_t s);
     void allreduce_f64(double* dev, int64_t n);

@@ -6,14 +6,14 @@
 // 2^18 rows, three up to 2^27), no workspace memsets:
 //   * at most 128 workgroups of 8 waves, all co-resident (256 CUs); wave gw owns the contiguous entries
 //     [gw·per_wave, (gw+1)·per_wave), so "workgroup, wave, round, lane" order IS ascending entry order;
-//   * phase 1 — count: per round of 64 entries the lanes holding the same digit find each other with one ballot per digit
-//     bit (no LDS atomics, no contention on Zipf-hot rows); the lowest lane of each group adds the group size to the
-//     wave's private LDS counter;
+//   * phase 1 — count: one LDS atomic per entry into the wave's private per-digit counters (order does not matter here);
 //   * the workgroup publishes its per-digit totals, all workgroups meet at a grid-wide arrival counter (agent-scope
 //     release / acquire; the counter only ever grows — the host passes the value to wait for — so nothing is zeroed
 //     between launches), then every workgroup turns the published totals into its own scatter bases: digit base
 //     (exclusive scan over digits) + the entries of the same digit in earlier workgroups + in earlier waves;
-//   * phase 2 — scatter: the same ballots again give each entry its rank inside its group.
+//   * phase 2 — scatter: per round of 64 entries the lanes holding the same digit find each other with one ballot per digit
+//     bit (no atomics: the rank of an entry among its equals must be its lane order, which makes the sort stable); the
+//     lowest lane of each group advances the wave's counter by the group size.
 // (rocPRIM's Onesweep, which this replaces, took 9 launches + 17 workspace memsets per step for the two tables and was
 //  the reason the documents update could not start when the loss kernel finished.)
 #include "kernels.h"
@@ -73,11 +73,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_pass_kernel(
         }
 #pragma unroll
         for (int u = 0; u < kSortUnroll; ++u) {
-            if (r0 + u * 64 >= end) break;                          // wave-uniform
             const bool valid = (r0 + u * 64 + lane) < end;
             const uint32_t d = (static_cast<uint32_t>(key[u]) >> shift) & mask;
-            const uint64_t peers = match_digit(d, D, __ballot(valid));
-            if (valid && (peers & lt) == 0) cnt[w][d] += __popcll(peers);
+            // counting needs no order: an LDS atomic per entry (a fifth of the instructions of the ballot match below, which
+            // the scatter phase cannot do without — the sorts share the chip with the step's bandwidth-bound kernels)
+            if (valid) atomicAdd(&cnt[w][d], 1);
         }
     }
     __syncthreads();

@@ -11,6 +11,8 @@
 #include "kernels.h"
 #include "device_utils.h"
 
+#include <cstdlib>
+
 namespace cunvsm {
 
 // =============================================================================================
@@ -143,20 +145,22 @@ __device__ __forceinline__ void accumulate_segment(const RowPassArgs& a, const i
     }
 }
 
-// ordered sum of `count` partial vectors starting at partial[first]
-template <int V, bool VEC>
+// ordered sum of `count` partial vectors starting at partial[first]: U loads in flight, added in index order (the sum is
+// the same sequence of additions whatever U is). U = 16 for the level-2 pass, whose few thread groups (a dozen very hot
+// rows) each walk 64 partials and are pure latency: 16 dependent round trips of 4 loads took 19-25 us in the step.
+template <int V, bool VEC, int U>
 __device__ __forceinline__ void sum_partials(const float* __restrict__ partial, const float* __restrict__ partial_q,
                                              int first, int count, int dim, int col, float (&g)[V], float& q) {
     int ch = 0;
-    for (; ch + 4 <= count; ch += 4) {
-        float x[4][V], pq[4];
+    for (; ch + U <= count; ch += U) {
+        float x[U][V], pq[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (VEC) ldv<V>(partial + static_cast<size_t>(first + ch + u) * dim + col, x[u]);
             pq[u] = partial_q[first + ch + u];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (VEC) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) g[i] += x[u][i];
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void chunk2_pass_kernel(Csr c, int dim, int G,
 #pragma unroll
             for (int i = 0; i < V; ++i) g[i] = 0.f;
             float q = 0.f;
-            sum_partials<V, VEC>(c.partial, c.partial_q, first, last - first, dim, col, g, q);
+            sum_partials<V, VEC, 16>(c.partial, c.partial_q, first, last - first, dim, col, g, q);
             if (VEC) stv<V>(c.partial2 + static_cast<size_t>(ci) * dim + col, g);
             if (cv == 0) c.partial2_q[ci] = q;
         }
@@ -329,8 +333,8 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
             float q = 0.f;
             if (cnt > kChunk) {            // long row: ordered sum of its chunk partials
                 const int nch = (cnt + kChunk - 1) / kChunk;
-                if (nch > kFan) sum_partials<V, VEC>(c.partial2, c.partial2_q, c.chunk2_base[row], (nch + kFan - 1) / kFan, dim, col, g, q);
-                else sum_partials<V, VEC>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
+                if (nch > kFan) sum_partials<V, VEC, 4>(c.partial2, c.partial2_q, c.chunk2_base[row], (nch + kFan - 1) / kFan, dim, col, g, q);
+                else sum_partials<V, VEC, 4>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
             } else if (cnt > 0) {
                 accumulate_segment<V, TABLE, VEC>(a, c.sorted_entry, begin, end, col, g, q);
             }
@@ -388,8 +392,11 @@ static void group_geometry(int dim, int& V, int& nvec, int& G) {
 template <int V, int TABLE>
 static void chunk_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nvec, hipStream_t s) {
     const int gpb = 256 / G;
-    const int grid = (c.max_chunks + gpb - 1) / gpb;
-    const int grid2 = (c.max_chunks2 + gpb - 1) / gpb;
+    int grid = (c.max_chunks + gpb - 1) / gpb;
+    int grid2 = (c.max_chunks2 + gpb - 1) / gpb;
+    // (the kernels grid-stride over the chunks actually in use) NVSM_CHUNK_GRID_CAP: experiments
+    static const int cap = [] { const char* e = std::getenv("NVSM_CHUNK_GRID_CAP"); return e ? std::atoi(e) : 0; }();
+    if (cap > 0 && TABLE == 1) { grid = grid < cap ? grid : cap; grid2 = grid2 < cap ? grid2 : cap; }
     if (a.kind == ROW_SCALAR_ACC) {
         hipLaunchKernelGGL((chunk_pass_kernel<V, TABLE, false>), dim3(grid), dim3(256), 0, s, c, a, G, nvec);
         hipLaunchKernelGGL((chunk2_pass_kernel<V, false>), dim3(grid2), dim3(256), 0, s, c, a.dim, G, nvec);

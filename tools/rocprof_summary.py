@@ -36,10 +36,13 @@ def stats(path):
     print("%-92s %8d %12.1f" % ("TOTAL", sum(a[0] for a in agg.values()), total / 1e3))
 
 
-def mfma(path, json_path=None, cu_num=256):
+def mfma(path, json_path=None, cu_num=256, xcds=8):
     """Counter-based MFMA utilisation per kernel: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
-    GRBM_GUI_ACTIVE. MfmaUtil = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * CU_NUM * 4) (derived_counters.xml, the gfx94x
-    formula the gfx950 tool falls back to); flops = SQ_INSTS_VALU_MFMA_MOPS_F32 * 512."""
+    GRBM_GUI_ACTIVE. MfmaUtil = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * CU_NUM * 4) is derived_counters.xml's
+    (gfx94x) formula; on gfx950 rocprofv3 reports GRBM_GUI_ACTIVE SUMMED over the 8 XCDs (1 998 687 "cycles" for a 103.75 us
+    kernel = 8 x 2.4 GHz x 103.75 us), so the per-device busy window is GRBM_GUI_ACTIVE / 8:
+    MfmaUtil = 100 * BUSY / ((GUI_ACTIVE / 8) * 256 CUs * 4 SIMDs). Cross-check: SQ_VALU_MFMA_BUSY_CYCLES is exactly
+    (number of v_mfma_f32_32x32x2 instructions) x 64 cycles, and flops = SQ_INSTS_VALU_MFMA_MOPS_F32 * 512."""
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
     ncol = next((c for c in ("counter_name", "name") if c in cols), None)
@@ -55,7 +58,8 @@ def mfma(path, json_path=None, cu_num=256):
         busy, mops, gui = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), e.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0), e.get("GRBM_GUI_ACTIVE", 0.0)
         if mops <= 0:
             continue
-        e["mfma_util_pct"] = 100.0 * busy / (gui * cu_num * 4) if gui else None
+        e["mfma_util_pct"] = 100.0 * busy / ((gui / xcds) * cu_num * 4) if gui else None
+        e["mfma_util_pct_uncorrected_formula"] = 100.0 * busy / (gui * cu_num * 4) if gui else None
         e["mfma_flops"] = mops * 512
         e["TFLOPs_under_pmc"] = mops * 512 / (e["avg_us"] * 1e-6) / 1e12 if e["avg_us"] else None
         rows.append((k, e))
@@ -67,7 +71,8 @@ def mfma(path, json_path=None, cu_num=256):
         import json
         with open(json_path, "w") as f:
             json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE; "
-                               "MfmaUtil = 100*BUSY/(GUI_ACTIVE*256 CUs*4); the fp32 MFMA peak is 157.3 TF/s",
+                               "MfmaUtil = 100*BUSY/((GUI_ACTIVE/8 XCDs)*256 CUs*4 SIMDs) — GRBM_GUI_ACTIVE is reported summed over the 8 XCDs; "
+                               "the fp32 MFMA peak is 157.3 TF/s",
                        "kernels": {k: e for k, e in rows}}, f, indent=1, sort_keys=True)
 
 

@@ -157,7 +157,34 @@ struct RowPassArgs {
     int max_blocks;            // 0 = one thread group per row; > 0 = cap the grid (rows are grid-strided) so that a kernel
                                //   running concurrently on another stream finds free registers on every CU
     int touched_only;          // set by launch_row_pass: visit the rows of Csr::touched only (see row_pass_split)
+    int lazy;                  // lazy dense decay (below): rows without entries are NOT visited, their decay stays pending
+    int* stamp;                // lazy, last pass of the table's update: stamp[row] = stamp_value for every row visited
+    int stamp_value;
 };
+// ---- lazy dense decay, for tables much larger than the batch ------------------------------------------------------------
+// The reference rewrites EVERY row of a table on every update (θ·(1 − λ·lr), Adam m·β₁, v·β₂: cpp/storage.cu:65-67,
+// cpp/updates_adam.cu:196-252): at |D| = 2 M that is 8 of the 10 GB a step moves. A row without entries only ever gets
+// multiplied by those per-update constants, so the multiplications can wait until somebody looks at the row: every row
+// carries the number of updates applied to it (stamp); before a step reads or updates a row — the rows of the batch, i.e.
+// the touched list of the CSR — launch_lazy_refresh applies the pending updates' factors ONE BY ONE, in fp32, in update
+// order (the factors of the last kLazyHistory updates travel in the kernel arguments), which is exactly the sequence of
+// roundings the dense pass would have produced: parameters and optimiser state stay bit-identical to the eager path
+// (tests/test_gpu_lazy.py compares them). Every kLazyHistory updates, and before anything else looks at a whole table
+// (get_param, set_param, replica averaging), all rows are brought up to date.
+constexpr int kLazyHistory = 128;
+struct LazyRefreshArgs {
+    float* P; float* m;                 // table rows, first moments (null: none)
+    float* sc;                          // per-row scalar state (Adam v / Adagrad accumulator; null: none)
+    float* sc_snapshot;                 // copy of the refreshed scalar the row pass reads while it writes `sc` (null: none)
+    int* stamp;                         // [rows] updates applied to the row
+    const int* list; const int* list_count;      // rows to refresh (Csr::touched); null = all `rows`
+    int64_t rows; int dim;
+    int now;                            // updates applied to the table so far
+    float s_m, s_v;                     // per-update factors of m and of the scalar (1 = none)
+    float decay[kLazyHistory];          // factor of update u on P at [(u - 1) % kLazyHistory]
+};
+void launch_lazy_refresh(const LazyRefreshArgs& a, int64_t max_rows, hipStream_t s);
+
 void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
 void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
 

@@ -237,6 +237,16 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
     t.chunk2_desc.alloc(static_cast<size_t>(t.max_chunks2) * 2, true);
     t.partial2.alloc(static_cast<size_t>(t.max_chunks2) * dim);
     t.partial2_q.alloc(t.max_chunks2, true);
+    {
+        const char* lazy_env = std::getenv("NVSM_LAZY_DECAY");        // read per handle: tests build an eager twin
+        const bool lazy_enabled = !(lazy_env && lazy_env[0] == '0');
+        const bool sparse_adam = method == NVSM_ADAM && mode <= NVSM_ADAM_SPARSE;
+        const bool decays = sparse_adam || (method != NVSM_ADAM && cfg_.regularization_lambda > 0.f);
+        t.lazy = lazy_enabled && decays && rows >= max_entries;
+        t.lazy_scalar = sparse_adam || (method == NVSM_ADAGRAD && &t == &ents_);
+        if (t.lazy) t.stamp.alloc(rows, true);
+        for (float& d : t.decay_hist) d = 1.f;
+    }
     t.sort_bits = bits_for(rows);
     t.sort_temp_bytes = sort_pairs_temp_bytes(max_entries, t.sort_bits);
     t.sort_temp.alloc(t.sort_temp_bytes, true);      // zero once: the arrival counter only ever grows
@@ -409,6 +419,7 @@ void Model::initialize(uint64_t seed) {
 void Model::initialize_from_rng_state() {
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
     synchronize();
+    lazy_flush_all();          // (fresh parameters carry no pending decay: every row is current as of updates_done)
     if (device_seed_ == 0) device_seed_ = 1;
     auto glorot = [&](DevBuf<float>& dst, size_t rows, size_t cols) {
         std::vector<float> h(rows * cols);
@@ -448,6 +459,7 @@ void Model::average_tables() {
     if (cfg_.world_size <= 1) return;
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
     synchronize();
+    lazy_flush_all();
     const float inv = 1.0f / static_cast<float>(cfg_.world_size);
     for (TableState* t : {&words_, &ents_}) {
         const int64_t n = static_cast<int64_t>(t->P.n);
@@ -646,22 +658,33 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // Which side stream builds which table's CSR. Side stream 1 still carries the PREVIOUS step's documents update when this
     // step begins (it runs ~150 us into it), so a sort queued there starts late and lands on the loss kernel; side stream 2
     // (dT GEMM + projection update of the previous step) is free by then. NVSM_SORT_LAYOUT: 0 = documents on side stream 1,
-    // words on 2 (round 1); 1 = both on 2, words first (default); 2 = both on 2, documents first; 3 = documents on 2, words
-    // on 1. Measured at the bench shape (two interleaved rounds, M windows/s | loss-kernel fraction of 8 TB/s):
-    // 0: 45.10 | 0.73   1: 45.55 | 0.75   2: 45.24 | 0.80   3: 45.18 | 0.81; started only after the word gather
-    // (NVSM_CSR_AFTER=1) layout 1 gives 44.9 | 0.76 with the word gather back at its stand-alone 67 us.
-    static const int sort_layout = [] { const char* e = std::getenv("NVSM_SORT_LAYOUT"); return e ? std::atoi(e) : 1; }();
+    // words on 2 (default); 1 = both on 2, words first; 2 = both on 2, documents first; 3 = documents on 2, words on 1.
+    // The documents CSR arrays are still being read by the previous step's documents update, so a build on another stream
+    // has to wait for it (ev_E_done_) all the same — on side stream 1 that order comes for free. Measured at the bench shape
+    // WITHOUT that wait (i.e. racing; M windows/s | loss-kernel fraction of 8 TB/s): 0: 45.10 | 0.73, 1: 45.55 | 0.75,
+    // 2: 45.24 | 0.80, 3: 45.18 | 0.81 — nothing a second set of CSR arrays would be worth.
+    static const int sort_layout = [] { const char* e = std::getenv("NVSM_SORT_LAYOUT"); return e ? std::atoi(e) : 0; }();
     auto launch_csr_builds = [&](hipEvent_t after) {
         hipStream_t se = (sort_layout == 0) ? aux_stream_ : aux2_stream_;
         hipStream_t sw = (sort_layout == 3) ? aux_stream_ : aux2_stream_;
         NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, after, 0));
         NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, after, 0));
+        if (se != aux_stream_ && E_pending_) NVSM_HIP_CHECK(hipStreamWaitEvent(se, ev_E_done_, 0));
         auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, ids_.p, N, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
         auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, widx_.p, B * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
         if (sort_layout == 1) { wrds(); ents(); } else { ents(); wrds(); }
         if (se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
     };
-    if (csr_after == 0) launch_csr_builds(ev_inputs_);
+    const bool any_lazy = words_.lazy || ents_.lazy;
+    if (csr_after == 0 || any_lazy) launch_csr_builds(ev_inputs_);
+    if (words_.lazy) {
+        // lazy dense decay: the rows this batch is about to gather (= the touched list of the words CSR) first get the
+        // decay of the updates they sat out — the sort is on the critical path here, a small price next to the dense
+        // passes it replaces (tables much larger than the batch only)
+        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
+        Csr cw = csr_of(words_, B * w);
+        lazy_refresh(words_, &cw, stream_);
+    }
 
     // F3: phrase representations (objective.cu:126-130). The previous step's dT GEMM may still be reading its phrase
     // matrix on the side stream: write the other one.
@@ -673,7 +696,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         // optional phrase normaliser (objective.cu:136-142): the raw means stay cached for its backward pass
         if (l2p) launch_l2_rows_forward(phrase_raw_.p, B, dw, phrase_p_, phrase_norms_.p, stream_);
     }
-    if (csr_after == 1) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
+    if (csr_after == 1 && !any_lazy) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     debug_check(phrase_p_, B * dw, 0);                  // CHECK_MATRIX(*result->phrase_reprs_), objective.cu:134,141
 
     // F5: projection GEMM  pre[B][de] = phrase[B][dw] · Tt[dw][de] (+ b when no BN)   (params.cu:417-421)
@@ -688,7 +711,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
     const double bn_n = (cfg_.world_size > 1 && cfg_.sync_batch_norm) ? B_global : static_cast<double>(B);
-    if (csr_after == 2) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
+    if (csr_after == 2 && !any_lazy) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     debug_check(pre_.p, B * de, 1);                     // CHECK_MATRIX(*result->word_projections_), objective.cu:152
     // F6: batch statistics (cudnn_utils.cu:107-124), ε = 1e-4 (objective.cu:114)
     if (cfg_.batch_normalization && cfg_.world_size > 1 && cfg_.sync_batch_norm) {
@@ -699,6 +722,11 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
 
     // F7–F16 + B1–B4: fused loss
     join_E();        // the previous step's documents update: reads proj / coef, writes E
+    if (ents_.lazy) {                                    // as for the words: the documents the loss is about to gather
+        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
+        Csr ce = csr_of(ents_, N);
+        lazy_refresh(ents_, &ce, stream_);
+    }
     {
         PROF("loss_fused");
         LossArgs a;
@@ -723,10 +751,11 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         a.inv_de = static_cast<float>(std::exp(-std::log(static_cast<double>(de))));
         launch_loss(a, stream_);
     }
-    if (csr_after == 3) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
+    if (csr_after == 3 && !any_lazy) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     NVSM_HIP_CHECK(hipGetLastError());      // a failed launch of any kernel above surfaces here, not at the next sync
     have_forward_ = true;
     if (debug_) {
+        if (any_lazy) { NVSM_HIP_CHECK(hipStreamSynchronize(stream_)); lazy_flush_all(); }
         debug_check(proj_.p, B * de, 2); debug_check(probs_.p, N, 3); debug_check(dy_.p, B * de, 4);
         debug_check(words_.P.p, static_cast<int64_t>(words_.P.n), 7); debug_check(ents_.P.p, static_cast<int64_t>(ents_.P.n), 8);
         debug_check(T_.p, static_cast<int64_t>(T_.n), 9);
@@ -875,6 +904,49 @@ void Model::build_csr(TableState& t, const int* keys, int64_t n, hipStream_t s) 
     launch_csr_build(csr_of(t, n), s);
 }
 
+static void fill_adam_consts(RowPassArgs& a, float bc, float sl);
+
+// ---- lazy dense decay (kernels.h) ---------------------------------------------------------------------------------
+void Model::lazy_refresh(TableState& t, const Csr* touched, hipStream_t s) {
+    if (!t.lazy) return;
+    LazyRefreshArgs r{};
+    r.P = t.P.p; r.m = t.m.p;
+    r.sc = t.lazy_scalar ? t.sc[0].p : nullptr;
+    r.sc_snapshot = t.lazy_scalar ? t.sc[1].p : nullptr;
+    r.stamp = t.stamp.p; r.rows = t.rows; r.dim = t.dim; r.now = t.updates_done;
+    r.s_m = 1.f; r.s_v = 1.f;
+    if (cfg_.update_method == NVSM_ADAM) { RowPassArgs c{}; fill_adam_consts(c, 1.f, 0.f); r.s_m = c.s_m; r.s_v = c.s_v; }
+    std::memcpy(r.decay, t.decay_hist, sizeof(r.decay));
+    int64_t max_rows = t.rows;
+    if (touched) { r.list = touched->touched; r.list_count = touched->num_touched; max_rows = std::min<int64_t>(touched->n, t.rows); }
+    PROF_ON(&t == &words_ ? "lazy_refresh_words" : "lazy_refresh_entities", s);
+    launch_lazy_refresh(r, max_rows, s);
+}
+
+void Model::lazy_flush_all() {
+    if (!words_.lazy && !ents_.lazy) return;
+    synchronize();
+    lazy_refresh(words_, nullptr, stream_);
+    lazy_refresh(ents_, nullptr, stream_);
+    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// the passes of one update of a lazy table: rows without entries are skipped (their decay stays pending); the per-row
+// scalar is read from the snapshot the refresh left in sc[1] and written to sc[0] (no ping-pong flip: rows that are not
+// visited must keep their value where it is)
+void Model::lazy_begin_update(TableState& t, RowPassArgs& a, bool scalar_pingpong) {
+    if (!t.lazy) return;
+    a.lazy = 1;
+    if (scalar_pingpong) { a.sc_in = t.sc[1].p; a.sc_out = t.sc[0].p; }
+    t.decay_hist[t.updates_done % kLazyHistory] = a.decay;           // factor of update number updates_done + 1 on P
+}
+void Model::lazy_end_update(TableState& t, hipStream_t s) {
+    if (!t.lazy) return;
+    t.updates_done += 1;
+    // the kernel arguments carry the factors of the last kLazyHistory updates: nobody may fall further behind
+    if (t.updates_done % kLazyHistory == 0) lazy_refresh(t, nullptr, s);
+}
+
 static void fill_adam_consts(RowPassArgs& a, float bc, float sl) {
     const double b1 = static_cast<double>(0.9f), b2 = static_cast<double>(0.999f);
     a.one_m_b1 = static_cast<float>(1.0 - b1);
@@ -920,11 +992,17 @@ void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row
     }
     // (Capping this grid so that GEMM workgroups of the other stream find free registers on every CU was measured in
     // the fused step: 1.30 -> 1.31-1.33 ms, no gain; RowPassArgs::max_blocks stays 0.)
+    if (t.lazy) {
+        lazy_begin_update(t, a, swap_sc);
+        swap_sc = false;
+        a.stamp = t.stamp.p; a.stamp_value = t.updates_done + 1;
+    }
     { PROF_ON("chunk_pass_entities", strm); launch_chunk_pass(c, a, strm); }
     // the (usually empty) chunk passes only need the loss kernel's outputs; the row pass may be held back further
     if (row_pass_after) NVSM_HIP_CHECK(hipStreamWaitEvent(strm, row_pass_after, 0));
     { PROF_ON("row_pass_entities", strm); launch_row_pass(c, a, strm); }
     if (swap_sc) t.sc_cur ^= 1;
+    lazy_end_update(t, strm);
 }
 
 void Model::update_words(float lr, float sl) {
@@ -942,8 +1020,11 @@ void Model::update_words(float lr, float sl) {
 
     if (method == NVSM_SGD) {
         a.kind = ROW_SGD; a.dense = sl > 0.f;
+        lazy_begin_update(t, a, false);
+        if (t.lazy) { a.stamp = t.stamp.p; a.stamp_value = t.updates_done + 1; }
         { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
         { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
+        lazy_end_update(t, stream_);
         return;
     }
     if (method == NVSM_ADAGRAD) {
@@ -955,8 +1036,11 @@ void Model::update_words(float lr, float sl) {
         { PROF("adagrad_acc_words"); launch_chunk_pass(c, s, stream_); launch_row_pass(c, s, stream_); }
         { PROF("adagrad_scale_words"); launch_adagrad_scale(t.sc[t.sc_cur].p, widx_.p, w, B_, 1e-6f, scale_w_.p, stream_); }
         a.kind = ROW_SGD; a.src_scale = scale_w_.p; a.dense = sl > 0.f;
+        lazy_begin_update(t, a, false);
+        if (t.lazy) { a.stamp = t.stamp.p; a.stamp_value = t.updates_done + 1; }
         { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
         { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
+        lazy_end_update(t, stream_);
         return;
     }
     // Adam
@@ -979,14 +1063,17 @@ void Model::update_words(float lr, float sl) {
     }
     // SPARSE: moments, then the window-averaged direction, then the scatter (updates_adam.cu:332-384)
     a.kind = ROW_ADAM_MV;
+    lazy_begin_update(t, a, true);
     { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
     { PROF("row_pass_words_mv"); launch_row_pass(c, a, stream_); }
-    t.sc_cur ^= 1;
+    if (!t.lazy) t.sc_cur ^= 1;
     { PROF("adam_u_words"); launch_adam_u(t.m.p, t.sc[t.sc_cur].p, dw, widx_.p, w, B_, a.bc, a.eps, U_.p, stream_); }
     RowPassArgs r = a;
     r.kind = ROW_SGD; r.X = U_.p; r.sq_src = nullptr; r.dense = sl > 0.f;
+    if (t.lazy) { r.stamp = t.stamp.p; r.stamp_value = t.updates_done + 1; }
     { PROF("chunk_pass_words_u"); launch_chunk_pass(c, r, stream_); }
     { PROF("row_pass_words_u"); launch_row_pass(c, r, stream_); }
+    lazy_end_update(t, stream_);
 }
 
 void Model::update_transform(float lr, float sl, hipStream_t strm) {
@@ -1145,6 +1232,7 @@ void Model::get_param(const std::string& name, float* dst, int64_t count) {
     if (!r.p) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown parameter: " + name);
     if (count != r.n) throw Error(NVSM_ERR_INVALID_ARGUMENT, "size mismatch for " + name);
     synchronize();
+    lazy_flush_all();
     NVSM_HIP_CHECK(hipMemcpy(dst, r.p, count * sizeof(float), hipMemcpyDeviceToHost));
 }
 void Model::set_param(const std::string& name, const float* src, int64_t count) {
@@ -1152,6 +1240,7 @@ void Model::set_param(const std::string& name, const float* src, int64_t count) 
     if (!r.p) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown parameter: " + name);
     if (count != r.n) throw Error(NVSM_ERR_INVALID_ARGUMENT, "size mismatch for " + name);
     synchronize();
+    lazy_flush_all();
     NVSM_HIP_CHECK(hipMemcpy(r.p, src, count * sizeof(float), hipMemcpyHostToDevice));
 }
 
@@ -1160,6 +1249,7 @@ void Model::increment_param(const std::string& name, int64_t index, float delta)
     if (!r.p) throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown parameter: " + name);
     if (index < 0 || index >= r.n) throw Error(NVSM_ERR_INVALID_ARGUMENT, "parameter index out of range for " + name);
     synchronize();
+    lazy_flush_all();
     float v = 0.f;
     NVSM_HIP_CHECK(hipMemcpy(&v, r.p + index, sizeof(float), hipMemcpyDeviceToHost));
     v += delta;

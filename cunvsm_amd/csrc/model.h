@@ -90,6 +90,12 @@ struct TableState {           // one embedding table + its optimiser state + its
     int sort_bits = 1;
     int max_chunks = 0, max_chunks2 = 0;
     int64_t max_entries = 0;
+    // lazy dense decay (kernels.h): for tables with at least as many rows as a batch has entries
+    bool lazy = false;
+    bool lazy_scalar = false;     // the per-row scalar state takes part (Adam v, document Adagrad accumulator)
+    DevBuf<int> stamp;            // [rows] updates applied to the row
+    int updates_done = 0;
+    float decay_hist[kLazyHistory];
 };
 
 class Model {
@@ -147,6 +153,10 @@ class Model {
     void update_transform(float lr, float sl, hipStream_t s);
     void allreduce_f64(double* dev, int64_t n);
     void allreduce_f32(float* dev, int64_t n, hipStream_t s);
+    void lazy_refresh(TableState& t, const Csr* touched, hipStream_t s);     // null = every row of the table
+    void lazy_flush_all();                 // before anything reads or writes whole tables (get / set_param, averaging)
+    void lazy_begin_update(TableState& t, RowPassArgs& a, bool scalar_pingpong);
+    void lazy_end_update(TableState& t, hipStream_t s);
     void raise_device_error();             // throws when a kernel has flagged bad ids / non-finite values since the last check
     void debug_check(const float* x, int64_t n, int which);
     void alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entries);

@@ -100,9 +100,12 @@ void launch_csr_build(const Csr& c, hipStream_t s) {
 // two). Out-of-range slots of the last batch re-read the segment's last entry with coefficient 0 (branch-free).
 // src = entry / div by multiply-shift: exact for entry < 2^26, div <= 2048 (checked by the host).
 // =============================================================================================
-constexpr int kSegUnroll = 8;
+constexpr int kSegUnrollDeep = 8;
+// rows of a table much larger than the batch hold one or two entries: two slots in flight per lane leave registers for
+// 2-3x as many rows in flight per CU, which is what bounds that regime (a dependent chain of four loads per row)
+constexpr int kSegUnrollShallow = 2;
 
-template <int V, int TABLE, bool VEC>
+template <int V, int TABLE, bool VEC, int kSegUnroll = kSegUnrollDeep>
 __device__ __forceinline__ void accumulate_segment(const RowPassArgs& a, const int* __restrict__ sorted_entry,
                                                    int begin, int end, int col, float (&g)[V], float& q) {
     const bool need_q = (a.sq_src != nullptr);
@@ -302,7 +305,7 @@ __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t 
     }
 }
 
-template <int V, int TABLE, int KIND>
+template <int V, int TABLE, int KIND, int UNROLL>
 __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int G, int nvec) {
     constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
     const int rpb = blockDim.x / G;
@@ -336,10 +339,11 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
                 if (nch > kFan) sum_partials<V, VEC, 4>(c.partial2, c.partial2_q, c.chunk2_base[row], (nch + kFan - 1) / kFan, dim, col, g, q);
                 else sum_partials<V, VEC, 4>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
             } else if (cnt > 0) {
-                accumulate_segment<V, TABLE, VEC>(a, c.sorted_entry, begin, end, col, g, q);
+                accumulate_segment<V, TABLE, VEC, UNROLL>(a, c.sorted_entry, begin, end, col, g, q);
             }
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, touch_p, g, q, p, m, v);
         }
+        if (a.stamp && lig == 0) a.stamp[row] = a.stamp_value;      // lazy decay: this row now carries this update
     }
 }
 
@@ -378,6 +382,55 @@ __global__ __launch_bounds__(256) void untouched_rows_kernel(Csr c, RowPassArgs 
                                        g, 0.f, p[u], m[u], v[u]);
         }
     }
+}
+
+// One wave per row (every lane reads the row's stamp before lane 0 rewrites it): P, m of the row and its scalar state get
+// the factors of the updates (stamp, now] applied one at a time — the roundings of the dense pass, see kernels.h.
+template <int V>
+__global__ __launch_bounds__(256) void lazy_refresh_kernel(LazyRefreshArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+    const int64_t limit = a.list ? static_cast<int64_t>(*a.list_count) : a.rows;
+    for (int64_t it = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; it < limit; it += waves) {
+        const int64_t row = a.list ? static_cast<int64_t>(a.list[it]) : it;
+        const int from = a.stamp[row];
+        if (from != a.now) {
+            for (int c = lane * V; c < a.dim; c += 64 * V) {
+                const size_t off = static_cast<size_t>(row) * a.dim + c;
+                float p[V], m[V];
+                ldv<V>(a.P + off, p);
+                if (a.m) ldv<V>(a.m + off, m);
+                for (int u = from; u < a.now; ++u) {
+                    const float d = a.decay[u % kLazyHistory];
+#pragma unroll
+                    for (int i = 0; i < V; ++i) p[i] *= d;
+                    if (a.m) {
+#pragma unroll
+                        for (int i = 0; i < V; ++i) m[i] *= a.s_m;
+                    }
+                }
+                stv<V>(a.P + off, p);
+                if (a.m) stv<V>(a.m + off, m);
+            }
+        }
+        if (lane == 0) {
+            if (a.sc) {
+                float v = a.sc[row];
+                if (a.s_v != 1.f) for (int u = from; u < a.now; ++u) v *= a.s_v;
+                if (from != a.now) a.sc[row] = v;
+                if (a.sc_snapshot) a.sc_snapshot[row] = v;
+            }
+            a.stamp[row] = a.now;
+        }
+    }
+}
+
+void launch_lazy_refresh(const LazyRefreshArgs& a, int64_t max_rows, hipStream_t s) {
+    if (max_rows <= 0) return;
+    int64_t blocks = (max_rows + 3) / 4;                       // 4 waves per workgroup, one row per wave
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (a.dim % 4 == 0) hipLaunchKernelGGL(lazy_refresh_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lazy_refresh_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
 }
 
 bool row_pass_split(const Csr& c) { return c.rows >= c.n && c.n > 0; }
@@ -422,7 +475,10 @@ static void row_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nve
     // a.max_blocks > 0: persistent grid-stride launch that leaves room on every CU for a concurrent kernel
     if (a.max_blocks > 0 && blocks > a.max_blocks) blocks = a.max_blocks;
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
-#define NVSM_ROW_CASE(K) case K: hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K>), grid, block, 0, s, c, a, G, nvec); break;
+#define NVSM_ROW_CASE(K) case K: \
+        if (a.touched_only) hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec); \
+        else hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K, kSegUnrollDeep>), grid, block, 0, s, c, a, G, nvec); \
+        break;
     switch (a.kind) {
         NVSM_ROW_CASE(ROW_SGD)
         NVSM_ROW_CASE(ROW_ADAGRAD_ENT)
@@ -466,7 +522,7 @@ void launch_row_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
     // Table much larger than the batch (at most one entry per row on average): the rows with entries go through the
     // row pass by list, all the others — if the pass is dense — through the streaming pass.
     if (row_pass_split(c) && kind_is_row_local_when_untouched(a.kind)) {
-        if (a.dense) { if (V == 4) untouched_dispatch<4>(c, a, nvec, s); else untouched_dispatch<1>(c, a, nvec, s); }
+        if (a.dense && !a.lazy) { if (V == 4) untouched_dispatch<4>(c, a, nvec, s); else untouched_dispatch<1>(c, a, nvec, s); }
         a.touched_only = 1;
         cc.rows = c.n < c.rows ? c.n : c.rows;      // upper bound of the list length: sizes the grid
     }

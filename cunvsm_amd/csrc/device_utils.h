@@ -27,6 +27,30 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const float (&x)[V]) 
     }
 }
 
+// streaming variants (nt): data that is touched once per step and should not displace the gather sources in the caches
+template <int V>
+__device__ __forceinline__ void ldv_nt(const float* __restrict__ p, float (&x)[V]) {
+    if constexpr (V == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+        x[0] = t[0]; x[1] = t[1]; x[2] = t[2]; x[3] = t[3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) x[i] = __builtin_nontemporal_load(p + i);
+    }
+}
+template <int V>
+__device__ __forceinline__ void stv_nt(float* __restrict__ p, const float (&x)[V]) {
+    if constexpr (V == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 t; t[0] = x[0]; t[1] = x[1]; t[2] = x[2]; t[3] = x[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p));
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) __builtin_nontemporal_store(x[i], p + i);
+    }
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));

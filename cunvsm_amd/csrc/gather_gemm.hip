@@ -362,7 +362,8 @@ bool launch_gemm_panel(int a_layout, int b_layout, const float* A, const float* 
 static bool g_gemm_panel_enabled = true;
 void gemm_set_panel_enabled(bool on) { g_gemm_panel_enabled = on; }
 
-int gemm_rowsq_parts(int N) { return (N + BN - 1) / BN; }
+static int tiled_rowsq_parts(int N) { return (N + BN - 1) / BN; }
+int gemm_rowsq_parts(int N) { return (N + 15) / 16; }
 
 __global__ void sum_parts_kernel(const float* __restrict__ parts, int nparts, int64_t stride, float* __restrict__ out, int64_t n) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
@@ -385,8 +386,13 @@ int gemm_split_k_slabs(int K, int want) {
 
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
-                 hipStream_t s, double* colstats, float* rowsq, float rowsq_scale) {
+                 hipStream_t s, double* colstats, float* rowsq, float rowsq_scale, int* rowsq_parts) {
     if (M <= 0 || N <= 0) return;
+    if (rowsq_parts) *rowsq_parts = rowsq ? tiled_rowsq_parts(N) : 0;
+    // batch-sized products against the projection matrix: the matrix stationary in LDS (gemm_tstat.hip)
+    if (split_k <= 1 && launch_gemm_tstat(a_layout, b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, s, colstats, rowsq,
+                                          rowsq_scale, rowsq_parts))
+        return;
     GemmArgs g;
     g.colstats = (split_k > 1) ? nullptr : colstats;
     g.rowsq = nullptr; g.rowsq_scale = rowsq_scale;
@@ -434,7 +440,7 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
 #undef NVSM_GEMM_CASE
     if (rowsq && split_k <= 1) {      // shapes the SWAP kernel does not cover: a separate pass, all of it in part 0
         launch_row_meansq(C, M, N, rowsq_scale, rowsq, s);
-        const int parts = gemm_rowsq_parts(N);
+        const int parts = tiled_rowsq_parts(N);
         if (parts > 1) (void)hipMemsetAsync(rowsq + M, 0, sizeof(float) * static_cast<size_t>(parts - 1) * M, s);
     }
 }

@@ -20,11 +20,17 @@ void launch_gather_mean(const float* table, int dim, const int* idx, const float
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
                  hipStream_t s, double* colstats = nullptr,     // colstats [2][N] (no split-K): += Σ_rows C, Σ_rows C²
-                 float* rowsq = nullptr, float rowsq_scale = 0.f);
-// rowsq [gemm_rowsq_parts(N)][M]: rowsq_scale · Σ_cols C² per row, split by 128-column tile; launch_sum_parts adds the
-// parts in order (a runtime-length loop over the parts inside the row passes' unrolled gather was measured: it halves
-// their speed, so the parts are combined once up front)
-int gemm_rowsq_parts(int N);
+                 float* rowsq = nullptr, float rowsq_scale = 0.f, int* rowsq_parts = nullptr);
+// rowsq [gemm_rowsq_parts(N)][M]: rowsq_scale · Σ_cols C² per row, split by column tile (128 columns in the tiled kernel,
+// 16 in the LDS-stationary one): *rowsq_parts = the number of parts this launch wrote; launch_sum_parts adds them in
+// order (a runtime-length loop over the parts inside the row passes' unrolled gather was measured: it halves their
+// speed, so the parts are combined once up front)
+int gemm_rowsq_parts(int N);             // upper bound of *rowsq_parts: sizes the buffer
+// LDS-stationary kernel for the batch-sized projection products (gemm_tstat.hip); false = shape not covered
+bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
+                       int lda, int ldb, int ldc, float alpha, const float* bias_n, hipStream_t s, double* colstats,
+                       float* rowsq, float rowsq_scale, int* rowsq_parts);
+void gemm_set_tstat_enabled(bool on);    // experiments / tests: force the tiled kernel
 void launch_sum_parts(const float* parts, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
 void gemm_set_panel_enabled(bool on);    // experiments / tests: force the tiled kernel
 int gemm_split_k_slabs(int K, int want);   // actual number of slabs launch_gemm will use for `want`
@@ -117,6 +123,8 @@ struct Csr {
     float* partial_q;     // [max_chunks]
     float* partial2;      // [max_chunks2][dim]
     float* partial2_q;    // [max_chunks2]
+    int* arrive_row;      // [rows]        arrival counters of table_pass_kernel, zero between launches
+    int* arrive2;         // [max_chunks2]
     int64_t n;            // entries
     int64_t rows;
     int max_chunks, max_chunks2;
@@ -125,7 +133,8 @@ constexpr int kChunk = 64;    // entries per level-1 chunk of a long row
 constexpr int kFan = 64;      // level-1 partials per level-2 chunk
 
 void launch_csr_build(const Csr& c, hipStream_t s);   // bounds + long-row chunk list, from sorted_key
-bool row_pass_split(const Csr& c);                    // rows >= entries: touched-row list + streaming pass over the rest
+bool row_pass_split(const Csr& c);                    // rows · ratio >= entries: touched-row list + streaming pass over the rest
+double table_split_ratio();                           // that ratio (2 unless NVSM_SPLIT_RATIO says otherwise)
 
 // ---- row passes: gather Σ coef·X[src] per table row, then the optimiser's row-local formula --------
 enum RowKind {
@@ -157,6 +166,9 @@ struct RowPassArgs {
     int max_blocks;            // 0 = one thread group per row; > 0 = cap the grid (rows are grid-strided) so that a kernel
                                //   running concurrently on another stream finds free registers on every CU
     int touched_only;          // set by launch_row_pass: visit the rows of Csr::touched only (see row_pass_split)
+    int nt_p;                  // the table rows themselves likewise (experiments)
+    int nt_m;                  // first moments with streaming (nt) loads / stores: nobody gathers them (documents table)
+    int shallow;               // set by launch_row_pass: two entries in flight per lane instead of eight (rows >= entries)
     int lazy;                  // lazy dense decay (below): rows without entries are NOT visited, their decay stays pending
     int* stamp;                // lazy, last pass of the table's update: stamp[row] = stamp_value for every row visited
     int stamp_value;
@@ -187,6 +199,7 @@ void launch_lazy_refresh(const LazyRefreshArgs& a, int64_t max_rows, hipStream_t
 
 void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
 void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
+void launch_table_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);      // both, in one launch (update.hip)
 
 // words, window > 1 (cpp/updates_adagrad.cu:83-97, cpp/updates_adam.cu:132-151)
 void launch_adagrad_scale(const float* acc, const int* idx, int window, int64_t B, float eps, float* scale, hipStream_t s);

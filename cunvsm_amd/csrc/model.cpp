@@ -237,12 +237,20 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
     t.chunk2_desc.alloc(static_cast<size_t>(t.max_chunks2) * 2, true);
     t.partial2.alloc(static_cast<size_t>(t.max_chunks2) * dim);
     t.partial2_q.alloc(t.max_chunks2, true);
+    t.arrive_row.alloc(rows, true); t.arrive2.alloc(t.max_chunks2, true);      // zero once: the last arriver resets its counter
     {
         const char* lazy_env = std::getenv("NVSM_LAZY_DECAY");        // read per handle: tests build an eager twin
         const bool lazy_enabled = !(lazy_env && lazy_env[0] == '0');
         const bool sparse_adam = method == NVSM_ADAM && mode <= NVSM_ADAM_SPARSE;
         const bool decays = sparse_adam || (method != NVSM_ADAM && cfg_.regularization_lambda > 0.f);
-        t.lazy = lazy_enabled && decays && rows >= max_entries;
+        // Lazy decay puts the batch's sort in front of the first gather (the rows to bring up to date are the CSR's touched
+        // list): ≈0.1 ms of latency. It pays when the dense passes it saves cost more than that, i.e. for tables of
+        // hundreds of MB (configs[4]); at the LSE shape (a 100 MB table, batch 4096) it made the step 0.28 → 0.34 ms.
+        const char* min_env = std::getenv("NVSM_LAZY_MIN_MB");          // (per handle, as NVSM_LAZY_DECAY: the tests use small tables)
+        const double lazy_min_mb = min_env ? std::atof(min_env) : 384.0;
+        const double state_mb = static_cast<double>(rows) * dim * sizeof(float) * (method == NVSM_ADAM ? 2.0 : 1.0) / 1048576.0;
+        t.lazy = lazy_enabled && decays && state_mb >= lazy_min_mb &&
+                 static_cast<double>(rows) * table_split_ratio() >= static_cast<double>(max_entries);
         t.lazy_scalar = sparse_adam || (method == NVSM_ADAGRAD && &t == &ents_);
         if (t.lazy) t.stamp.alloc(rows, true);
         for (float& d : t.decay_hist) d = 1.f;
@@ -817,12 +825,13 @@ void Model::backward_dx() {
         const float inv_dw = static_cast<float>(std::exp(-std::log(static_cast<double>(dw))));
         // (A/B, interleaved: 1.235 ms per step with the epilogue fusion vs 1.262 ms with a separate row-mean-of-squares pass)
         const bool l2p = cfg_.l2_normalize_phrase_reprs != 0;
+        int msq_parts = 0;
         launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, l2p ? 1.f : inv_w, nullptr, 1, 0, stream_,
-                    nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw);
+                    nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw, &msq_parts);
         if (l2p)        // Normalizer::backward, then the division by the window (objective.cu:461-476); mean of squares of the result
             launch_l2_rows_backward(gphrase_.p, phrase_raw_.p, phrase_norms_.p, B, dw, inv_w, gphrase_.p,
                                     need_msq ? msq_w_.p : nullptr, stream_);
-        else if (need_msq) launch_sum_parts(msq_parts_.p, gemm_rowsq_parts(dw), B, msq_w_.p, B, stream_);
+        else if (need_msq) launch_sum_parts(msq_parts_.p, msq_parts, B, msq_w_.p, B, stream_);
         NVSM_HIP_CHECK(hipEventRecord(ev_bwdx_, stream_));      // last reader of T before its update
     }
     if (dp) loss_reduced_ = true;
@@ -895,6 +904,7 @@ Csr Model::csr_of(TableState& t, int64_t n) {
     c.partial = t.partial.p; c.partial_q = t.partial_q.p;
     c.chunk2_base = t.chunk2_base.p; c.chunk2_desc = t.chunk2_desc.p;
     c.partial2 = t.partial2.p; c.partial2_q = t.partial2_q.p;
+    c.arrive_row = t.arrive_row.p; c.arrive2 = t.arrive2.p;
     c.n = n; c.rows = t.rows; c.max_chunks = t.max_chunks; c.max_chunks2 = t.max_chunks2;
     return c;
 }
@@ -905,6 +915,13 @@ void Model::build_csr(TableState& t, const int* keys, int64_t n, hipStream_t s) 
 }
 
 static void fill_adam_consts(RowPassArgs& a, float bc, float sl);
+// Streaming (nt) loads / stores for state the row passes touch once per step, so that it does not displace the gradient
+// rows they gather (each read 10-17 times) from the caches: 1 = documents moments, 2 = documents rows, 4 = word moments,
+// 8 = word rows. Interleaved A/B at the bench shape: 0: 1.134, 1: 1.128, 3: 1.125, 5: 1.136, 9: 1.134, 15: 1.144 ms.
+static int nt_mask() {
+    static const int m = [] { const char* e = std::getenv("NVSM_NT"); return e ? std::atoi(e) : 3; }();
+    return m;
+}
 
 // ---- lazy dense decay (kernels.h) ---------------------------------------------------------------------------------
 void Model::lazy_refresh(TableState& t, const Csr* touched, hipStream_t s) {
@@ -997,10 +1014,9 @@ void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row
         swap_sc = false;
         a.stamp = t.stamp.p; a.stamp_value = t.updates_done + 1;
     }
-    { PROF_ON("chunk_pass_entities", strm); launch_chunk_pass(c, a, strm); }
-    // the (usually empty) chunk passes only need the loss kernel's outputs; the row pass may be held back further
+    a.nt_m = nt_mask() & 1; a.nt_p = (nt_mask() >> 1) & 1;
     if (row_pass_after) NVSM_HIP_CHECK(hipStreamWaitEvent(strm, row_pass_after, 0));
-    { PROF_ON("row_pass_entities", strm); launch_row_pass(c, a, strm); }
+    { PROF_ON("row_pass_entities", strm); launch_table_pass(c, a, strm); }
     if (swap_sc) t.sc_cur ^= 1;
     lazy_end_update(t, strm);
 }
@@ -1022,8 +1038,7 @@ void Model::update_words(float lr, float sl) {
         a.kind = ROW_SGD; a.dense = sl > 0.f;
         lazy_begin_update(t, a, false);
         if (t.lazy) { a.stamp = t.stamp.p; a.stamp_value = t.updates_done + 1; }
-        { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
-        { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
+        { PROF("row_pass_words"); launch_table_pass(c, a, stream_); }
         lazy_end_update(t, stream_);
         return;
     }
@@ -1033,13 +1048,12 @@ void Model::update_words(float lr, float sl) {
         // it is updated in place: rows without entries keep their value without being visited at all
         s.kind = ROW_SCALAR_ACC; s.sq_src = msq_w_.p; s.dense = 0;
         s.sc_in = t.sc[t.sc_cur].p; s.sc_out = t.sc[t.sc_cur].p;
-        { PROF("adagrad_acc_words"); launch_chunk_pass(c, s, stream_); launch_row_pass(c, s, stream_); }
+        { PROF("adagrad_acc_words"); launch_table_pass(c, s, stream_); }
         { PROF("adagrad_scale_words"); launch_adagrad_scale(t.sc[t.sc_cur].p, widx_.p, w, B_, 1e-6f, scale_w_.p, stream_); }
         a.kind = ROW_SGD; a.src_scale = scale_w_.p; a.dense = sl > 0.f;
         lazy_begin_update(t, a, false);
         if (t.lazy) { a.stamp = t.stamp.p; a.stamp_value = t.updates_done + 1; }
-        { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
-        { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
+        { PROF("row_pass_words"); launch_table_pass(c, a, stream_); }
         lazy_end_update(t, stream_);
         return;
     }
@@ -1048,31 +1062,29 @@ void Model::update_words(float lr, float sl) {
     t.t += 1;
     if (mode == NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE) {
         a.kind = ROW_ADAM_FULL; a.dense = 1; a.decay = 1.f;
-        { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
-        { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
+        { PROF("row_pass_words"); launch_table_pass(c, a, stream_); }
         return;
     }
     a.sq_src = msq_w_.p; a.dense = 1;     // from the dx GEMM's epilogue
     a.sc_in = t.sc[t.sc_cur].p; a.sc_out = t.sc[t.sc_cur ^ 1].p;
     if (mode == NVSM_ADAM_DENSE_UPDATE) {
         a.kind = ROW_ADAM_DENSE;
-        { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
-        { PROF("row_pass_words"); launch_row_pass(c, a, stream_); }
+        { PROF("row_pass_words"); launch_table_pass(c, a, stream_); }
         t.sc_cur ^= 1;
         return;
     }
     // SPARSE: moments, then the window-averaged direction, then the scatter (updates_adam.cu:332-384)
     a.kind = ROW_ADAM_MV;
+    a.nt_m = (nt_mask() >> 2) & 1;
     lazy_begin_update(t, a, true);
-    { PROF("chunk_pass_words"); launch_chunk_pass(c, a, stream_); }
-    { PROF("row_pass_words_mv"); launch_row_pass(c, a, stream_); }
+    { PROF("row_pass_words_mv"); launch_table_pass(c, a, stream_); }
     if (!t.lazy) t.sc_cur ^= 1;
     { PROF("adam_u_words"); launch_adam_u(t.m.p, t.sc[t.sc_cur].p, dw, widx_.p, w, B_, a.bc, a.eps, U_.p, stream_); }
     RowPassArgs r = a;
     r.kind = ROW_SGD; r.X = U_.p; r.sq_src = nullptr; r.dense = sl > 0.f;
+    r.nt_m = 0; r.nt_p = (nt_mask() >> 3) & 1;
     if (t.lazy) { r.stamp = t.stamp.p; r.stamp_value = t.updates_done + 1; }
-    { PROF("chunk_pass_words_u"); launch_chunk_pass(c, r, stream_); }
-    { PROF("row_pass_words_u"); launch_row_pass(c, r, stream_); }
+    { PROF("row_pass_words_u"); launch_table_pass(c, r, stream_); }
     lazy_end_update(t, stream_);
 }
 

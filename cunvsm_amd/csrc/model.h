@@ -82,6 +82,7 @@ struct TableState {           // one embedding table + its optimiser state + its
     // CSR workspace
     DevBuf<int> sorted_key, sorted_entry, chunk_base, chunk_desc, chunk2_base, chunk2_desc;
     DevBuf<int> touched;      // rows with entries (Csr::touched)
+    DevBuf<int> arrive_row, arrive2;      // arrival counters of the one-launch table pass (Csr)
     DevBuf<int> csr_zeroed;   // [row_begin (rows) | row_end (rows) | num_chunks (2) | num_touched]: one memset per step clears them all
     DevBuf<float> partial, partial_q, partial2, partial2_q;
     DevBuf<char> sort_temp;

@@ -182,6 +182,79 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ partial, 
     }
 }
 
+
+// ---- hand-over of partial sums between thread groups of ONE launch (table_pass_kernel) -----------------------------------
+// The XCDs' L2s are not coherent with each other inside a kernel. A partial that another workgroup will read travels as
+// agent-scope atomic stores / loads (write-through, cache-bypassing: the form the radix sort's grid-wide meeting point
+// uses, sort.hip) — no release / acquire fence, which would write back and invalidate whole caches under the step's
+// bandwidth-bound kernels.
+template <int V>
+__device__ __forceinline__ void st_agent(float* p, const float (&x)[V]) {
+    if constexpr (V == 4) {
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+        const unsigned long long lo = static_cast<unsigned long long>(__float_as_uint(x[0])) | (static_cast<unsigned long long>(__float_as_uint(x[1])) << 32);
+        const unsigned long long hi = static_cast<unsigned long long>(__float_as_uint(x[2])) | (static_cast<unsigned long long>(__float_as_uint(x[3])) << 32);
+        __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(p) + i, __float_as_uint(x[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int V>
+__device__ __forceinline__ void ld_agent(const float* p, float (&x)[V]) {
+    if constexpr (V == 4) {
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<float*>(p));
+        const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x[0] = __uint_as_float(static_cast<unsigned int>(lo)); x[1] = __uint_as_float(static_cast<unsigned int>(lo >> 32));
+        x[2] = __uint_as_float(static_cast<unsigned int>(hi)); x[3] = __uint_as_float(static_cast<unsigned int>(hi >> 32));
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            x[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(const_cast<float*>(p)) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+}
+__device__ __forceinline__ void st_agent1(float* p, float x) {
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent1(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// sum_partials over partials written by other workgroups of the same launch: the same additions in the same order
+template <int V, bool VEC, int U>
+__device__ __forceinline__ void sum_partials_agent(const float* partial, const float* partial_q, int first, int count, int dim,
+                                                   int col, float (&g)[V], float& q) {
+    int ch = 0;
+    for (; ch + U <= count; ch += U) {
+        float x[U][V], pq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (VEC) ld_agent<V>(partial + static_cast<size_t>(first + ch + u) * dim + col, x[u]);
+            pq[u] = ld_agent1(partial_q + first + ch + u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (VEC) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) g[i] += x[u][i];
+            }
+            q += pq[u];
+        }
+    }
+    for (; ch < count; ++ch) {
+        if (VEC) {
+            float x[V];
+            ld_agent<V>(partial + static_cast<size_t>(first + ch) * dim + col, x);
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] += x[i];
+        }
+        q += ld_agent1(partial_q + first + ch);
+    }
+}
+
 // level 1: one thread group (nvec threads, one 16 B column each) per chunk of a long row
 template <int V, int TABLE, bool VEC>
 __global__ __launch_bounds__(256) void chunk_pass_kernel(Csr c, RowPassArgs a, int G, int nvec) {
@@ -240,11 +313,10 @@ __device__ __forceinline__ void load_row_state(const RowPassArgs& a, size_t off,
                                                float (&p)[V], float (&m)[V], float (&v)[V]) {
 #pragma unroll
     for (int i = 0; i < V; ++i) { p[i] = 0.f; m[i] = 0.f; v[i] = 0.f; }
-    if (RowKindTraits<V, KIND>::kUsesM) ldv<V>(a.m + off, m);
+    if (RowKindTraits<V, KIND>::kUsesM) { if (a.nt_m) ldv_nt<V>(a.m + off, m); else ldv<V>(a.m + off, m); }
     if (KIND == ROW_ADAM_FULL) ldv<V>(a.v + off, v);
     if (RowKindTraits<V, KIND>::kUsesP) {
-        if (p_always) ldv<V>(a.P + off, p);
-        else if (cnt != 0) ldv<V>(a.P + off, p);
+        if (p_always || cnt != 0) { if (a.nt_p) ldv_nt<V>(a.P + off, p); else ldv<V>(a.P + off, p); }
     }
 }
 
@@ -256,7 +328,7 @@ __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t 
         if (!touch_p) return;
 #pragma unroll
         for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * g[i];
-        stv<V>(a.P + off, p);
+        if (a.nt_p) stv_nt<V>(a.P + off, p); else stv<V>(a.P + off, p);
     } else if (KIND == ROW_ADAGRAD_ENT) {
         const float acc = a.sc_in[row] + q;
         if (first_col) a.sc_out[row] = acc;
@@ -264,7 +336,7 @@ __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t 
         const float sc = 1.f / sqrtf(acc + a.eps);
 #pragma unroll
         for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * (g[i] * sc);
-        stv<V>(a.P + off, p);
+        if (a.nt_p) stv_nt<V>(a.P + off, p); else stv<V>(a.P + off, p);
     } else if (KIND == ROW_SCALAR_ACC) {
         if (first_col) a.sc_out[row] = a.sc_in[row] + q;
     } else if (KIND == ROW_ADAM_FULL) {
@@ -279,14 +351,14 @@ __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t 
             v[i] = vn;
             p[i] = p[i] + ((mn / (sqrtf(vn) + a.eps)) * a.bc) * a.lr;   // :312-328 (λ = 0)
         }
-        stv<V>(a.m + off, m);
+        if (a.nt_m) stv_nt<V>(a.m + off, m); else stv<V>(a.m + off, m);
         stv<V>(a.v + off, v);
-        stv<V>(a.P + off, p);
+        if (a.nt_p) stv_nt<V>(a.P + off, p); else stv<V>(a.P + off, p);
     } else {
         // ROW_ADAM_MV / ROW_ADAM_SPARSE_ENT / ROW_ADAM_DENSE: v is one scalar per row (updates_adam.cu:126).
 #pragma unroll
         for (int i = 0; i < V; ++i) m[i] = m[i] * a.s_m + a.one_m_b1 * g[i];
-        stv<V>(a.m + off, m);
+        if (a.nt_m) stv_nt<V>(a.m + off, m); else stv<V>(a.m + off, m);
         const float vn = a.sc_in[row] * a.s_v + a.one_m_b2 * q;
         if (first_col) a.sc_out[row] = vn;
         if (KIND == ROW_ADAM_SPARSE_ENT) {
@@ -295,12 +367,12 @@ __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t 
             const float fc = static_cast<float>(cnt);
 #pragma unroll
             for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + (a.lr * fc) * ((a.bc * m[i]) / denom);
-            stv<V>(a.P + off, p);
+            if (a.nt_p) stv_nt<V>(a.P + off, p); else stv<V>(a.P + off, p);
         } else if (KIND == ROW_ADAM_DENSE) {
             const float denom = sqrtf(vn) + a.eps;
 #pragma unroll
             for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + ((m[i] / denom) * a.bc) * a.lr;
-            stv<V>(a.P + off, p);
+            if (a.nt_p) stv_nt<V>(a.P + off, p); else stv<V>(a.P + off, p);
         }
     }
 }
@@ -344,6 +416,149 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, touch_p, g, q, p, m, v);
         }
         if (a.stamp && lig == 0) a.stamp[row] = a.stamp_value;      // lazy decay: this row now carries this update
+    }
+}
+
+// One launch per pass of a table (chunk_pass_kernel + chunk2_pass_kernel + row_pass_kernel in one grid). The first
+// `chunk_blocks` workgroups take the level-1 chunks of the long rows, one per thread group; a group that finishes a
+// chunk bumps an arrival counter, and whoever arrives LAST — nobody ever waits — carries on: the last chunk of a level-2
+// range sums that range's partials, the last contribution of a row sums the row's partials and applies the optimiser's
+// row formula. Which group that is varies from run to run; what it computes does not (the sums run over the partials in
+// index order), so results are bit-identical to the three-launch form. The remaining workgroups are the row pass over
+// the rows of at most kChunk entries, which depend on nothing: they overlap the chunk work instead of queueing behind
+// two kernel boundaries. Counters return to zero (reset by the last arriver) for the next pass.
+constexpr int kMaxGroupsPerBlock = 256;      // one-column rows: a thread group is a single thread
+template <int V, int TABLE, int KIND, int UNROLL>
+__global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
+    constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
+    const int gpb = blockDim.x / G;
+    const int group = threadIdx.x / G, lig = threadIdx.x - group * G;
+    const int dim = a.dim;
+    if (static_cast<int>(blockIdx.x) < chunk_blocks) {
+        __shared__ int todo[kMaxGroupsPerBlock];
+        const int nchunks = min(c.num_chunks[0], c.max_chunks);
+        if (static_cast<int>(blockIdx.x) * gpb >= nchunks) return;              // the whole workgroup
+        const int ci = blockIdx.x * gpb + group;
+        const bool active = group < gpb && ci < nchunks;
+        int row = 0, nch = 0, c_in_row = 0;
+        if (active) {
+            row = c.chunk_desc[ci * 3 + 0];
+            const int begin = c.chunk_desc[ci * 3 + 1], end = c.chunk_desc[ci * 3 + 2];
+            nch = (c.row_end[row] - c.row_begin[row] + kChunk - 1) / kChunk;
+            c_in_row = ci - c.chunk_base[row];
+            for (int cv = lig; cv < nvec; cv += G) {
+                const int col = cv * V;
+                float g[V];
+#pragma unroll
+                for (int i = 0; i < V; ++i) g[i] = 0.f;
+                float q = 0.f;
+                accumulate_segment<V, TABLE, VEC>(a, c.sorted_entry, begin, end, col, g, q);
+                if (VEC) st_agent<V>(c.partial + static_cast<size_t>(ci) * dim + col, g);
+                if (cv == 0) st_agent1(c.partial_q + ci, q);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the partial has reached memory before anybody is told
+        __syncthreads();
+        const bool two_level = nch > kFan;
+        if (active && lig == 0) {
+            int what = 0;
+            if (two_level) {
+                const int c2 = c_in_row / kFan;
+                const int members = min(kFan, nch - c2 * kFan);
+                int* ctr = c.arrive2 + c.chunk2_base[row] + c2;
+                if (c.chunk2_base[row] + c2 < c.max_chunks2 &&
+                    __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                    __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    what = 1;
+                }
+            } else {
+                int* ctr = c.arrive_row + row;
+                if (__hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nch - 1) {
+                    __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    what = 2;
+                }
+            }
+            todo[group] = what;
+        } else if (lig == 0) {
+            todo[group] = 0;
+        }
+        __syncthreads();
+        int what = (group < gpb) ? todo[group] : 0;
+        __syncthreads();
+        // level 2: ordered sum of this range's (up to kFan) level-1 partials
+        if (what == 1) {
+            const int c2 = c_in_row / kFan;
+            const int first = c.chunk_base[row] + c2 * kFan, count = min(kFan, nch - c2 * kFan);
+            const int slot = c.chunk2_base[row] + c2;
+            for (int cv = lig; cv < nvec; cv += G) {
+                const int col = cv * V;
+                float g[V];
+#pragma unroll
+                for (int i = 0; i < V; ++i) g[i] = 0.f;
+                float q = 0.f;
+                sum_partials_agent<V, VEC, 16>(c.partial, c.partial_q, first, count, dim, col, g, q);
+                if (VEC) st_agent<V>(c.partial2 + static_cast<size_t>(slot) * dim + col, g);
+                if (cv == 0) st_agent1(c.partial2_q + slot, q);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (what == 1 && lig == 0) {
+            const int n2 = (nch + kFan - 1) / kFan;
+            int* ctr = c.arrive_row + row;
+            int next = 0;
+            if (__hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n2 - 1) {
+                __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                next = 2;
+            }
+            todo[group] = next;
+        }
+        __syncthreads();
+        what = (group < gpb) ? todo[group] : 0;
+        if (what != 2) return;
+        // the row: ordered sum of its partials, then the row formula (row_pass_kernel's long-row branch)
+        const int cnt = c.row_end[row] - c.row_begin[row];
+        const bool p_always = (a.decay != 1.f) || KIND == ROW_ADAM_FULL || KIND == ROW_ADAM_DENSE;
+        for (int cv = lig; cv < nvec; cv += G) {
+            const int col = cv * V;
+            const size_t off = static_cast<size_t>(row) * dim + col;
+            float p[V], m[V], v[V];
+            load_row_state<V, KIND>(a, off, cnt, p_always, p, m, v);
+            float g[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] = 0.f;
+            float q = 0.f;
+            if (two_level) sum_partials_agent<V, VEC, 4>(c.partial2, c.partial2_q, c.chunk2_base[row], (nch + kFan - 1) / kFan, dim, col, g, q);
+            else sum_partials_agent<V, VEC, 4>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
+            apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, true, g, q, p, m, v);
+        }
+        if (a.stamp && lig == 0) a.stamp[row] = a.stamp_value;
+        return;
+    }
+    // ---- rows of at most kChunk entries ----
+    if (group >= gpb) return;
+    const int64_t limit = a.touched_only ? static_cast<int64_t>(*c.num_touched) : c.rows;
+    const int64_t nblocks = static_cast<int64_t>(gridDim.x) - chunk_blocks;
+    for (int64_t r = (static_cast<int64_t>(blockIdx.x) - chunk_blocks) * gpb + group; r < limit; r += nblocks * gpb) {
+        const int64_t row = a.touched_only ? static_cast<int64_t>(c.touched[r]) : r;
+        const int begin = c.row_begin[row], end = c.row_end[row];
+        const int cnt = end - begin;
+        if (cnt > kChunk || (cnt == 0 && !a.dense)) continue;
+        const bool p_always = (a.decay != 1.f) || KIND == ROW_ADAM_FULL || KIND == ROW_ADAM_DENSE;
+        const bool touch_p = p_always || cnt != 0;
+        for (int cv = lig; cv < nvec; cv += G) {
+            const int col = cv * V;
+            const size_t off = static_cast<size_t>(row) * dim + col;
+            float p[V], m[V], v[V];
+            load_row_state<V, KIND>(a, off, cnt, p_always, p, m, v);
+            float g[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] = 0.f;
+            float q = 0.f;
+            if (cnt > 0) accumulate_segment<V, TABLE, VEC, UNROLL>(a, c.sorted_entry, begin, end, col, g, q);
+            apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, touch_p, g, q, p, m, v);
+        }
+        if (a.stamp && lig == 0) a.stamp[row] = a.stamp_value;
     }
 }
 
@@ -433,7 +648,14 @@ void launch_lazy_refresh(const LazyRefreshArgs& a, int64_t max_rows, hipStream_t
     else hipLaunchKernelGGL(lazy_refresh_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
 }
 
-bool row_pass_split(const Csr& c) { return c.rows >= c.n && c.n > 0; }
+// Touched-row list + streaming pass over the rest when the table has at least half as many rows as the batch has entries
+// (then at least 14 % of the rows are without entries for uniform ids, most of them for Zipf ids).
+// NVSM_SPLIT_RATIO overrides the factor (experiments); the lazy decay of model.cpp uses the same rule.
+double table_split_ratio() {
+    static const double r = [] { const char* e = std::getenv("NVSM_SPLIT_RATIO"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 2.0; }();
+    return r;
+}
+bool row_pass_split(const Csr& c) { return c.n > 0 && static_cast<double>(c.rows) * table_split_ratio() >= static_cast<double>(c.n); }
 static bool kind_is_row_local_when_untouched(int kind) { return kind != ROW_ADAM_DENSE && kind != ROW_ADAM_FULL; }
 
 static void group_geometry(int dim, int& V, int& nvec, int& G) {
@@ -476,7 +698,7 @@ static void row_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nve
     if (a.max_blocks > 0 && blocks > a.max_blocks) blocks = a.max_blocks;
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 #define NVSM_ROW_CASE(K) case K: \
-        if (a.touched_only) hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec); \
+        if (a.shallow) hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec); \
         else hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K, kSegUnrollDeep>), grid, block, 0, s, c, a, G, nvec); \
         break;
     switch (a.kind) {
@@ -517,17 +739,69 @@ void launch_row_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
     int V, nvec, G;
     group_geometry(a_in.dim, V, nvec, G);
     RowPassArgs a = a_in;
-    a.touched_only = 0;
+    a.touched_only = 0; a.shallow = 0;
     Csr cc = c;
     // Table much larger than the batch (at most one entry per row on average): the rows with entries go through the
     // row pass by list, all the others — if the pass is dense — through the streaming pass.
     if (row_pass_split(c) && kind_is_row_local_when_untouched(a.kind)) {
         if (a.dense && !a.lazy) { if (V == 4) untouched_dispatch<4>(c, a, nvec, s); else untouched_dispatch<1>(c, a, nvec, s); }
         a.touched_only = 1;
+        a.shallow = c.rows >= c.n;      // at most one entry per row on average
         cc.rows = c.n < c.rows ? c.n : c.rows;      // upper bound of the list length: sizes the grid
     }
     if (V == 4) { if (a.table == 0) row_pass_dispatch<4, 0>(cc, a, G, nvec, s); else row_pass_dispatch<4, 1>(cc, a, G, nvec, s); }
     else        { if (a.table == 0) row_pass_dispatch<1, 0>(cc, a, G, nvec, s); else row_pass_dispatch<1, 1>(cc, a, G, nvec, s); }
+}
+
+// NVSM_MERGED_PASS=0 (A/B runs, tests): the three-launch form
+static bool merged_pass_enabled() {
+    static const bool on = [] { const char* e = std::getenv("NVSM_MERGED_PASS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+template <int V, int TABLE>
+static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nvec, int64_t row_items, hipStream_t s) {
+    const int gpb = 256 / G;
+    const int chunk_blocks = (c.n > 0 && c.max_chunks > 0) ? (c.max_chunks + gpb - 1) / gpb : 0;
+    int64_t row_blocks = (row_items + gpb - 1) / gpb;
+    if (row_blocks > 256 * 64) row_blocks = 256 * 64;
+    if (a.max_blocks > 0 && row_blocks > a.max_blocks) row_blocks = a.max_blocks;
+    if (row_blocks < 1) row_blocks = 1;
+    const dim3 grid(static_cast<unsigned>(chunk_blocks + row_blocks)), block(256);
+#define NVSM_TABLE_CASE(K) case K: \
+        if (a.shallow) hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+        else hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, kSegUnrollDeep>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+        break;
+    switch (a.kind) {
+        NVSM_TABLE_CASE(ROW_SGD)
+        NVSM_TABLE_CASE(ROW_ADAGRAD_ENT)
+        NVSM_TABLE_CASE(ROW_ADAM_MV)
+        NVSM_TABLE_CASE(ROW_ADAM_SPARSE_ENT)
+        NVSM_TABLE_CASE(ROW_ADAM_DENSE)
+        NVSM_TABLE_CASE(ROW_ADAM_FULL)
+        NVSM_TABLE_CASE(ROW_SCALAR_ACC)
+        default: break;
+    }
+#undef NVSM_TABLE_CASE
+}
+
+// one pass over a table: chunk tree of the long rows + row formula, in one launch (table_pass_kernel)
+void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
+    if (!merged_pass_enabled()) { launch_chunk_pass(c, a_in, s); launch_row_pass(c, a_in, s); return; }
+    if (c.rows <= 0) return;
+    int V, nvec, G;
+    group_geometry(a_in.dim, V, nvec, G);
+    RowPassArgs a = a_in;
+    a.touched_only = 0; a.shallow = 0;
+    int64_t row_items = c.rows;
+    if (row_pass_split(c) && kind_is_row_local_when_untouched(a.kind)) {      // as launch_row_pass
+        if (a.dense && !a.lazy) { if (V == 4) untouched_dispatch<4>(c, a, nvec, s); else untouched_dispatch<1>(c, a, nvec, s); }
+        a.touched_only = 1;
+        a.shallow = c.rows >= c.n;
+        row_items = c.n < c.rows ? c.n : c.rows;
+    }
+    if (V == 4) { if (a.table == 0) table_pass_dispatch<4, 0>(c, a, G, nvec, row_items, s); else table_pass_dispatch<4, 1>(c, a, G, nvec, row_items, s); }
+    else        { if (a.table == 0) table_pass_dispatch<1, 0>(c, a, G, nvec, row_items, s); else table_pass_dispatch<1, 1>(c, a, G, nvec, row_items, s); }
 }
 
 // =============================================================================================

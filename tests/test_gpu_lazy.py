@@ -26,6 +26,7 @@ def twins(spec, B, monkeypatch):
     monkeypatch.setenv("NVSM_LAZY_DECAY", "0")
     eager = gpu_model(spec, B, sampler=ca.SAMPLER_DEVICE)
     monkeypatch.setenv("NVSM_LAZY_DECAY", "1")
+    monkeypatch.setenv("NVSM_LAZY_MIN_MB", "0")          # by default only tables of hundreds of MB decay lazily
     lazy = gpu_model(spec, B, sampler=ca.SAMPLER_DEVICE)
     return eager, lazy
 

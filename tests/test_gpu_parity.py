@@ -21,7 +21,10 @@ FWD_TOL, GRAD_TOL, UPD_TOL = 2e-5, 2e-4, 2e-4
 # ---------------------------------------------------------------------------------------------
 # unit kernels
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (130, 70, 45), (64, 256, 300), (300, 256, 1000), (5, 3, 2), (257, 300, 256)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (130, 70, 45), (64, 256, 300), (300, 256, 1000), (5, 3, 2), (257, 300, 256),
+                                   # batch-sized products against a projection matrix: the LDS-stationary kernel
+                                   # (gemm_tstat.hip; layouts 0 and 1), ragged row counts, both projection shapes
+                                   (1031, 256, 300), (4099, 300, 256), (2048, 256, 128), (1500, 128, 256)])
 @pytest.mark.parametrize("layout", [0, 1, 2, 3])
 def test_gemm_layouts(M, N, K, layout):
     """fp32 MFMA GEMM incl. an asymmetric operand (transposed-output bugs show up, cdna guide G9)."""

@@ -104,9 +104,10 @@ void launch_materialize_grad_entity_l2(const float* coef, const float* proj, con
 // Stable radix sort of (key, value) pairs by the low `bits` bits of the key (sort.hip). `temp` must be zero-filled ONCE when
 // allocated; *epoch (host, starts at 0, one per workspace) is the value its arrival counter has reached. vals_in may be
 // null (= 0, 1, 2, …). err_flag: the engine's error word (a grid-wide wait that never completes stores NVSM_SORT_TIMEOUT).
+// zero_buf (optional, 16 B aligned, zero_count % 4 == 0): ints the first pass clears on the way (the CSR's per-step counters).
 size_t sort_pairs_temp_bytes(int64_t n, int bits);
 void sort_pairs(void* temp, size_t temp_bytes, uint64_t* epoch, const int* keys_in, int* keys_out, const int* vals_in,
-                int* vals_out, int64_t n, int bits, int* err_flag, hipStream_t s);
+                int* vals_out, int64_t n, int bits, int* err_flag, hipStream_t s, int* zero_buf = nullptr, int64_t zero_count = 0);
 struct Csr {
     int* sorted_key;      // [n]
     int* sorted_entry;    // [n]  entry ids ordered by row (stable)
@@ -132,7 +133,10 @@ struct Csr {
 constexpr int kChunk = 64;    // entries per level-1 chunk of a long row
 constexpr int kFan = 64;      // level-1 partials per level-2 chunk
 
-void launch_csr_build(const Csr& c, hipStream_t s);   // bounds + long-row chunk list, from sorted_key
+// bounds + long-row chunk list, from sorted_key; counters_cleared: row_begin | row_end | num_chunks | num_touched (one
+// allocation of csr_counter_ints(rows) ints) are already zero (sort_pairs cleared them), otherwise a memset does it
+void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared = false);
+inline int64_t csr_counter_ints(int64_t rows) { return (2 * rows + 3 + 63) / 64 * 64; }
 bool row_pass_split(const Csr& c);                    // rows · ratio >= entries: touched-row list + streaming pass over the rest
 double table_split_ratio();                           // that ratio (2 unless NVSM_SPLIT_RATIO says otherwise)
 

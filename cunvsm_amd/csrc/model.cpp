@@ -225,16 +225,19 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
         if (mode == NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE) t.vfull.alloc(rows * dim, true);
         else { t.sc[0].alloc(rows, true); t.sc[1].alloc(rows, true); }
     }
-    t.sorted_key.alloc(max_entries); t.sorted_entry.alloc(max_entries);
-    t.csr_zeroed.alloc(2 * rows + 3, true); t.chunk_base.alloc(rows, true);
-    t.touched.alloc(std::min<int64_t>(rows, max_entries));
     t.max_chunks = static_cast<int>(2 * max_entries / kChunk + 2);
-    t.chunk_desc.alloc(static_cast<size_t>(t.max_chunks) * 3, true);
+    t.max_chunks2 = static_cast<int>(2 * max_entries / (static_cast<int64_t>(kChunk) * kFan) + 2);
+    for (int k = 0; k < t.idx_sets; ++k) {
+        TableState::CsrIndex& x = t.idx[k];
+        x.sorted_key.alloc(max_entries); x.sorted_entry.alloc(max_entries);
+        x.csr_zeroed.alloc(csr_counter_ints(rows), true); x.chunk_base.alloc(rows, true);
+        x.touched.alloc(std::min<int64_t>(rows, max_entries));
+        x.chunk_desc.alloc(static_cast<size_t>(t.max_chunks) * 3, true);
+        x.chunk2_base.alloc(rows, true);
+        x.chunk2_desc.alloc(static_cast<size_t>(t.max_chunks2) * 2, true);
+    }
     t.partial.alloc(static_cast<size_t>(t.max_chunks) * dim);
     t.partial_q.alloc(t.max_chunks, true);
-    t.chunk2_base.alloc(rows, true);
-    t.max_chunks2 = static_cast<int>(2 * max_entries / (static_cast<int64_t>(kChunk) * kFan) + 2);
-    t.chunk2_desc.alloc(static_cast<size_t>(t.max_chunks2) * 2, true);
     t.partial2.alloc(static_cast<size_t>(t.max_chunks2) * dim);
     t.partial2_q.alloc(t.max_chunks2, true);
     t.arrive_row.alloc(rows, true); t.arrive2.alloc(t.max_chunks2, true);      // zero once: the last arriver resets its counter
@@ -296,6 +299,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         own_stream_ = true;
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, lo));
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux2_stream_, hipStreamNonBlocking, lo));
+        NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux3_stream_, hipStreamNonBlocking, lo));
         NVSM_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     }
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, hipEventDisableTiming));
@@ -311,6 +315,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     const int dw = cfg.word_repr_size, de = cfg.entity_repr_size, w = cfg.window_size;
     const int64_t N = B * R_;
     alloc_table(words_, cfg.num_words, dw, B * w);
+    ents_.idx_sets = 2;
     alloc_table(ents_, cfg.num_entities, de, N);
     T_.alloc(static_cast<size_t>(de) * dw, true); b_.alloc(de, true);
     if (cfg.update_method != NVSM_SGD) { s0T_.alloc(static_cast<size_t>(de) * dw, true); s0b_.alloc(de, true); }
@@ -340,6 +345,7 @@ Model::~Model() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
     if (aux2_stream_) { (void)hipStreamSynchronize(aux2_stream_); (void)hipStreamDestroy(aux2_stream_); }
+    if (aux3_stream_) { (void)hipStreamSynchronize(aux3_stream_); (void)hipStreamDestroy(aux3_stream_); }
     if (ev_csr_ents_) (void)hipEventDestroy(ev_csr_ents_);
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
@@ -370,6 +376,7 @@ void Model::synchronize() {
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(aux_stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(aux2_stream_));
+    if (aux3_stream_) NVSM_HIP_CHECK(hipStreamSynchronize(aux3_stream_));
     NVSM_HIP_CHECK(hipStreamSynchronize(copy_stream_));
     E_pending_ = T_pending_ = false;
     raise_device_error();
@@ -668,19 +675,20 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // (dT GEMM + projection update of the previous step) is free by then. NVSM_SORT_LAYOUT: 0 = documents on side stream 1,
     // words on 2 (default); 1 = both on 2, words first; 2 = both on 2, documents first; 3 = documents on 2, words on 1.
     // The documents CSR arrays are still being read by the previous step's documents update, so a build on another stream
-    // has to wait for it (ev_E_done_) all the same — on side stream 1 that order comes for free. Measured at the bench shape
-    // WITHOUT that wait (i.e. racing; M windows/s | loss-kernel fraction of 8 TB/s): 0: 45.10 | 0.73, 1: 45.55 | 0.75,
-    // 2: 45.24 | 0.80, 3: 45.18 | 0.81 — nothing a second set of CSR arrays would be worth.
-    static const int sort_layout = [] { const char* e = std::getenv("NVSM_SORT_LAYOUT"); return e ? std::atoi(e) : 0; }();
+    // would have to wait for it (ev_E_done_) all the same; hence the second set of CSR arrays (TableState::CsrIndex).
+    // 4 = documents on side stream 3, words on 2: neither queues behind the previous step's tails (default).
+    static const int sort_layout = [] { const char* e = std::getenv("NVSM_SORT_LAYOUT"); return e ? std::atoi(e) : 4; }();
     auto launch_csr_builds = [&](hipEvent_t after) {
-        hipStream_t se = (sort_layout == 0) ? aux_stream_ : aux2_stream_;
-        hipStream_t sw = (sort_layout == 3) ? aux_stream_ : aux2_stream_;
-        NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, after, 0));
-        NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, after, 0));
-        if (se != aux_stream_ && E_pending_) NVSM_HIP_CHECK(hipStreamWaitEvent(se, ev_E_done_, 0));
+        const int layout = aux3_stream_ ? sort_layout : (sort_layout == 4 ? 0 : sort_layout);
+        hipStream_t se = (layout == 0) ? aux_stream_ : (layout == 4 ? aux3_stream_ : aux2_stream_);
+        hipStream_t sw = (layout == 3) ? aux_stream_ : aux2_stream_;
+        NVSM_HIP_CHECK(hipStreamWaitEvent(se, after, 0));
+        NVSM_HIP_CHECK(hipStreamWaitEvent(sw, after, 0));
+        // (the documents table has two sets of CSR arrays: its build does not wait for the previous documents update)
+        if (se != aux_stream_ && E_pending_ && ents_.idx_sets < 2) NVSM_HIP_CHECK(hipStreamWaitEvent(se, ev_E_done_, 0));
         auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, ids_.p, N, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
         auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, widx_.p, B * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
-        if (sort_layout == 1) { wrds(); ents(); } else { ents(); wrds(); }
+        if (layout == 1) { wrds(); ents(); } else { ents(); wrds(); }
         if (se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
     };
     const bool any_lazy = words_.lazy || ents_.lazy;
@@ -897,12 +905,13 @@ float Model::adam_bc(uint64_t t) const {
 
 Csr Model::csr_of(TableState& t, int64_t n) {
     Csr c;
-    c.sorted_key = t.sorted_key.p; c.sorted_entry = t.sorted_entry.p;
-    c.row_begin = t.csr_zeroed.p; c.row_end = t.csr_zeroed.p + t.rows; c.chunk_base = t.chunk_base.p;
-    c.chunk_desc = t.chunk_desc.p; c.num_chunks = t.csr_zeroed.p + 2 * t.rows;
-    c.num_touched = c.num_chunks + 2; c.touched = t.touched.p;
+    TableState::CsrIndex& x = t.idx[t.idx_cur];
+    c.sorted_key = x.sorted_key.p; c.sorted_entry = x.sorted_entry.p;
+    c.row_begin = x.csr_zeroed.p; c.row_end = x.csr_zeroed.p + t.rows; c.chunk_base = x.chunk_base.p;
+    c.chunk_desc = x.chunk_desc.p; c.num_chunks = x.csr_zeroed.p + 2 * t.rows;
+    c.num_touched = c.num_chunks + 2; c.touched = x.touched.p;
     c.partial = t.partial.p; c.partial_q = t.partial_q.p;
-    c.chunk2_base = t.chunk2_base.p; c.chunk2_desc = t.chunk2_desc.p;
+    c.chunk2_base = x.chunk2_base.p; c.chunk2_desc = x.chunk2_desc.p;
     c.partial2 = t.partial2.p; c.partial2_q = t.partial2_q.p;
     c.arrive_row = t.arrive_row.p; c.arrive2 = t.arrive2.p;
     c.n = n; c.rows = t.rows; c.max_chunks = t.max_chunks; c.max_chunks2 = t.max_chunks2;
@@ -910,8 +919,12 @@ Csr Model::csr_of(TableState& t, int64_t n) {
 }
 
 void Model::build_csr(TableState& t, const int* keys, int64_t n, hipStream_t s) {
-    sort_pairs(t.sort_temp.p, t.sort_temp_bytes, &t.sort_epoch, keys, t.sorted_key.p, nullptr, t.sorted_entry.p, n, t.sort_bits, err_host_, s);
-    launch_csr_build(csr_of(t, n), s);
+    if (t.idx_sets > 1) t.idx_cur ^= 1;      // the other set may still be read by the previous step's update
+    TableState::CsrIndex& x = t.idx[t.idx_cur];
+    // (the sort's first launch also clears the CSR's per-step counters: no memset launch)
+    sort_pairs(t.sort_temp.p, t.sort_temp_bytes, &t.sort_epoch, keys, x.sorted_key.p, nullptr, x.sorted_entry.p, n, t.sort_bits, err_host_, s,
+               x.csr_zeroed.p, csr_counter_ints(t.rows));
+    launch_csr_build(csr_of(t, n), s, n > 0);
 }
 
 static void fill_adam_consts(RowPassArgs& a, float bc, float sl);

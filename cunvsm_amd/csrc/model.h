@@ -79,15 +79,21 @@ struct TableState {           // one embedding table + its optimiser state + its
     DevBuf<float> P, m, vfull, sc[2];
     int sc_cur = 0;
     uint64_t t = 1;           // Adam step counter (cpp/updates_adam.cu:130)
-    // CSR workspace
-    DevBuf<int> sorted_key, sorted_entry, chunk_base, chunk_desc, chunk2_base, chunk2_desc;
-    DevBuf<int> touched;      // rows with entries (Csr::touched)
+    // CSR workspace. What the build writes and the update reads comes in two sets for the documents table: the build
+    // of step k+1 (side stream, at the start of the step) then does not have to wait for the documents update of step k,
+    // which trails into step k+1 and still reads the arrays of step k.
+    struct CsrIndex {
+        DevBuf<int> sorted_key, sorted_entry, chunk_base, chunk_desc, chunk2_base, chunk2_desc;
+        DevBuf<int> touched;      // rows with entries (Csr::touched)
+        DevBuf<int> csr_zeroed;   // [row_begin (rows) | row_end (rows) | num_chunks (2) | num_touched | pad]: cleared by the sort's first launch
+    };
+    CsrIndex idx[2];
+    int idx_sets = 1, idx_cur = 0;
     DevBuf<int> arrive_row, arrive2;      // arrival counters of the one-launch table pass (Csr)
-    DevBuf<int> csr_zeroed;   // [row_begin (rows) | row_end (rows) | num_chunks (2) | num_touched]: one memset per step clears them all
     DevBuf<float> partial, partial_q, partial2, partial2_q;
     DevBuf<char> sort_temp;
     size_t sort_temp_bytes = 0;
-    uint64_t sort_epoch = 0;      // value the workspace's grid-barrier arrival counter has reached (sort.hip)
+    uint64_t sort_epoch = 0;      // (unused by the two-launch sort)
     int sort_bits = 1;
     int max_chunks = 0, max_chunks2 = 0;
     int64_t max_entries = 0;
@@ -171,6 +177,7 @@ class Model {
     // forward / backward kernels and are joined right before the row passes.
     hipStream_t aux_stream_ = nullptr;
     hipStream_t aux2_stream_ = nullptr;   // the words CSR build: next to the documents CSR build instead of behind it
+    hipStream_t aux3_stream_ = nullptr;   // the documents CSR build (NVSM_SORT_LAYOUT 4)
     hipEvent_t ev_csr_ents_ = nullptr;
     hipEvent_t ev_inputs_ = nullptr, ev_csr_ = nullptr;
     // fused step(): the documents update (HBM bound) and the dT GEMM (MFMA bound) run on the side stream next to the

@@ -2,20 +2,23 @@
 // Plumbing, not arithmetic: it only permutes entry ids so that update.hip's row passes can own rows; stability is what
 // makes every row's gradient sum run in ascending entry order, i.e. run-to-run deterministic.
 //
-// Keys are table rows: 16-17 bits at the NVSM shape, at most 31. One launch per digit (≤ 9 bits: two launches up to
-// 2^18 rows, three up to 2^27), no workspace memsets:
-//   * at most 128 workgroups of 8 waves, all co-resident (256 CUs); wave gw owns the contiguous entries
-//     [gw·per_wave, (gw+1)·per_wave), so "workgroup, wave, round, lane" order IS ascending entry order;
-//   * phase 1 — count: one LDS atomic per entry into the wave's private per-digit counters (order does not matter here);
-//   * the workgroup publishes its per-digit totals, all workgroups meet at a grid-wide arrival counter (agent-scope
-//     release / acquire; the counter only ever grows — the host passes the value to wait for — so nothing is zeroed
-//     between launches), then every workgroup turns the published totals into its own scatter bases: digit base
-//     (exclusive scan over digits) + the entries of the same digit in earlier workgroups + in earlier waves;
-//   * phase 2 — scatter: per round of 64 entries the lanes holding the same digit find each other with one ballot per digit
-//     bit (no atomics: the rank of an entry among its equals must be its lane order, which makes the sort stable); the
-//     lowest lane of each group advances the wave's counter by the group size.
-// (rocPRIM's Onesweep, which this replaces, took 9 launches + 17 workspace memsets per step for the two tables and was
-//  the reason the documents update could not start when the loss kernel finished.)
+// Keys are table rows: 16-17 bits at the NVSM shape, at most 31. One pass per digit (≤ 9 bits: two passes up to 2^18
+// rows, three up to 2^27), two launches per pass, no workspace memsets:
+//   * at most 128 workgroups of 8 waves; wave gw owns the contiguous entries [gw·per_wave, (gw+1)·per_wave), so
+//     "workgroup, wave, round, lane" order IS ascending entry order;
+//   * launch 1 — count: one LDS atomic per entry into the wave's private per-digit counters (order does not matter
+//     here), the workgroup publishes its per-digit totals;
+//   * launch 2 — scatter: every workgroup recounts its entries (the keys come from L2), turns the published totals into
+//     its own scatter bases — digit base (exclusive scan over digits) + the entries of the same digit in earlier
+//     workgroups + in earlier waves — and then, per round of 64 entries, the lanes holding the same digit find each other
+//     with one ballot per digit bit (no atomics: the rank of an entry among its equals must be its lane order, which makes
+//     the sort stable); the lowest lane of each group advances the wave's counter by the group size.
+// An earlier form did a pass in ONE launch with a grid-wide meeting point between the two phases. Alone it sorted the
+// documents' 870 k pairs in 51 us, but inside a step — on the lowest-priority streams, next to the gather / GEMM / loss
+// kernels — a pass took 100-150 us: the meeting point needs all 128 workgroups resident at once, and those that had
+// arrived held 8 waves and their LDS each while they waited for the others to be scheduled (a fifth of the loss
+// kernel's wave slots). Workgroups of the two-launch form come, work and go.
+// (rocPRIM's Onesweep, which this replaces, took 9 launches + 17 workspace memsets per step for the two tables.)
 #include "kernels.h"
 #include "device_utils.h"
 
@@ -32,7 +35,6 @@ constexpr int kSortMaxBuckets = 1 << kSortMaxDigitBits;
 constexpr int kSortMaxBlocks = 128;
 constexpr int kSortUnroll = 4;
 constexpr int64_t kSortMinTile = 4096;          // entries per workgroup before a second workgroup is worth its barrier
-constexpr long long kSpinLimit = 1ll << 22;     // ≈ seconds: a barrier that never completes is reported, not hung on
 
 // lanes of this wave (among `active`) whose digit equals mine
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, int D, uint64_t active) {
@@ -45,10 +47,59 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, int D, uint64_t acti
     return peers;
 }
 
-__global__ __launch_bounds__(kSortThreads) void radix_pass_kernel(
+// phase 1 of a pass — count: one LDS atomic per entry into the wave's private per-digit counters (order does not matter
+// here: a fifth of the instructions of the ballot match the scatter phase cannot do without)
+__device__ __forceinline__ void count_digits(const int* __restrict__ keys_in, uint32_t begin, uint32_t end, int shift, uint32_t mask,
+                                             int lane, int (&cnt)[kSortMaxBuckets]) {
+    for (uint32_t r0 = begin; r0 < end; r0 += 64 * kSortUnroll) {
+        int key[kSortUnroll];
+#pragma unroll
+        for (int u = 0; u < kSortUnroll; ++u) {
+            const uint32_t i = r0 + u * 64 + lane;
+            key[u] = (i < end) ? keys_in[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kSortUnroll; ++u) {
+            const bool valid = (r0 + u * 64 + lane) < end;
+            const uint32_t d = (static_cast<uint32_t>(key[u]) >> shift) & mask;
+            if (valid) atomicAdd(&cnt[d], 1);
+        }
+    }
+}
+
+// Kernel 1 of a pass: per-workgroup digit totals → counts[block][digit]. (Also clears the caller's per-step counters —
+// the CSR's row bounds — instead of a memset launch of their own.)
+__global__ __launch_bounds__(kSortThreads) void radix_count_kernel(
+        const int* __restrict__ keys_in, uint32_t n, int shift, int D, uint32_t per_wave, int* __restrict__ counts,
+        int4* __restrict__ zero_buf, uint32_t zero_n4) {
+    __shared__ int cnt[kSortWaves][kSortMaxBuckets];
+    for (uint32_t i = blockIdx.x * kSortThreads + threadIdx.x; i < zero_n4; i += gridDim.x * kSortThreads)
+        zero_buf[i] = make_int4(0, 0, 0, 0);
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int NB = 1 << D;
+    const uint32_t mask = static_cast<uint32_t>(NB - 1);
+    const uint32_t gw = blockIdx.x * kSortWaves + w;
+    const uint64_t b64 = static_cast<uint64_t>(gw) * per_wave;
+    const uint32_t begin = b64 < n ? static_cast<uint32_t>(b64) : n;
+    const uint32_t end = (b64 + per_wave < n) ? static_cast<uint32_t>(b64 + per_wave) : n;
+    for (int i = tid; i < kSortWaves * kSortMaxBuckets; i += kSortThreads) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    count_digits(keys_in, begin, end, shift, mask, lane, cnt[w]);
+    __syncthreads();
+    if (tid < NB) {
+        int run = 0;
+#pragma unroll
+        for (int ww = 0; ww < kSortWaves; ++ww) run += cnt[ww][tid];
+        counts[blockIdx.x * kSortMaxBuckets + tid] = run;
+    }
+}
+
+// Kernel 2 of a pass: recount (the keys come from L2), turn the published totals into this workgroup's scatter bases —
+// digit base (exclusive scan over digits) + the entries of the same digit in earlier workgroups + in earlier waves —
+// then rank and scatter.
+__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         const int* __restrict__ keys_in, const int* __restrict__ vals_in, int* __restrict__ keys_out, int* __restrict__ vals_out,
-        uint32_t n, int shift, int D, uint32_t per_wave, int* __restrict__ counts, unsigned long long* sync_counter,
-        unsigned long long sync_target, int* __restrict__ err_flag) {
+        uint32_t n, int shift, int D, uint32_t per_wave, const int* __restrict__ counts) {
     __shared__ int cnt[kSortWaves][kSortMaxBuckets];
     __shared__ int wave_tot[kSortWaves];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -62,51 +113,14 @@ __global__ __launch_bounds__(kSortThreads) void radix_pass_kernel(
 
     for (int i = tid; i < kSortWaves * kSortMaxBuckets; i += kSortThreads) (&cnt[0][0])[i] = 0;
     __syncthreads();
-
-    // ---- phase 1: count ----
-    for (uint32_t r0 = begin; r0 < end; r0 += 64 * kSortUnroll) {
-        int key[kSortUnroll];
-#pragma unroll
-        for (int u = 0; u < kSortUnroll; ++u) {
-            const uint32_t i = r0 + u * 64 + lane;
-            key[u] = (i < end) ? keys_in[i] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < kSortUnroll; ++u) {
-            const bool valid = (r0 + u * 64 + lane) < end;
-            const uint32_t d = (static_cast<uint32_t>(key[u]) >> shift) & mask;
-            // counting needs no order: an LDS atomic per entry (a fifth of the instructions of the ballot match below, which
-            // the scatter phase cannot do without — the sorts share the chip with the step's bandwidth-bound kernels)
-            if (valid) atomicAdd(&cnt[w][d], 1);
-        }
-    }
+    count_digits(keys_in, begin, end, shift, mask, lane, cnt[w]);
     __syncthreads();
-    // per-digit totals of this workgroup; the wave counters become exclusive prefixes over the waves
+    // the wave counters become exclusive prefixes over the waves
     if (tid < NB) {
         int run = 0;
 #pragma unroll
         for (int ww = 0; ww < kSortWaves; ++ww) { const int c = cnt[ww][tid]; cnt[ww][tid] = run; run += c; }
-        // published write-through (agent-scope atomic store = sc1): readable by the other XCDs without any cache-wide
-        // write-back / invalidate
-        __hip_atomic_store(&counts[blockIdx.x * kSortMaxBuckets + tid], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-
-    // ---- grid-wide meeting point (cdna_hip_programming.md §6 G16, the write-through-payload form) ----
-    // The payload travels as agent-scope atomics (stores above, loads below), drained before the arrival counter is
-    // bumped; the spin is a relaxed load. No acquire / release FENCE anywhere: an agent-scope acquire per spin iteration
-    // invalidates the CU's vector cache and the XCD's L2 lines each time — measured: the word gather-mean running next
-    // to the sorts went from 67 to 153 us and the projection GEMM from 106 to 161 us.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(sync_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        long long spins = 0;
-        while (__hip_atomic_load(sync_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sync_target) {
-            __builtin_amdgcn_s_sleep(32);
-            if (++spins > kSpinLimit) { *err_flag = NVSM_SORT_TIMEOUT; break; }
-        }
-    }
-    __syncthreads();
 
     // ---- scatter bases ----
     int pre = 0, tot = 0;
@@ -116,12 +130,12 @@ __global__ __launch_bounds__(kSortThreads) void radix_pass_kernel(
         for (; t + 16 <= G; t += 16) {
             int c[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) c[u] = __hip_atomic_load(&counts[(t + u) * kSortMaxBuckets + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < 16; ++u) c[u] = counts[(t + u) * kSortMaxBuckets + tid];
 #pragma unroll
             for (int u = 0; u < 16; ++u) { tot += c[u]; pre += (t + u < me) ? c[u] : 0; }
         }
         for (; t < G; ++t) {
-            const int c = __hip_atomic_load(&counts[t * kSortMaxBuckets + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int c = counts[t * kSortMaxBuckets + tid];
             tot += c; pre += (t < me) ? c : 0;
         }
     }
@@ -144,7 +158,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_pass_kernel(
     }
     __syncthreads();
 
-    // ---- phase 2: rank + scatter ----
+    // ---- rank + scatter: per round of 64 entries the lanes holding the same digit find each other with one ballot per
+    // digit bit (no atomics: the rank of an entry among its equals must be its lane order, which makes the sort stable) ----
     for (uint32_t r0 = begin; r0 < end; r0 += 64 * kSortUnroll) {
         int key[kSortUnroll], val[kSortUnroll];
 #pragma unroll
@@ -193,19 +208,19 @@ SortPlan make_plan(int64_t n, int bits) {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 }  // namespace
 
-// workspace layout: [arrival counter (u64, padded to 256 B) | counts [128][512] int | scratch keys [n] | scratch entries [n]]
-// The counter must be zero when the workspace is first used (the caller zero-fills the allocation once) and only grows.
+// workspace layout: [256 B unused | counts [128][512] int | scratch keys [n] | scratch entries [n]]
 size_t sort_pairs_temp_bytes(int64_t n, int /*bits*/) {
     return 256 + sizeof(int) * kSortMaxBlocks * kSortMaxBuckets + 2 * align_up(static_cast<size_t>(n > 0 ? n : 1) * sizeof(int), 256);
 }
 
 void sort_pairs(void* temp, size_t temp_bytes, uint64_t* epoch, const int* keys_in, int* keys_out, const int* vals_in,
-                int* vals_out, int64_t n, int bits, int* err_flag, hipStream_t s) {
+                int* vals_out, int64_t n, int bits, int* err_flag, hipStream_t s, int* zero_buf, int64_t zero_count) {
     if (n <= 0) return;
+    if (zero_count % 4 || reinterpret_cast<uintptr_t>(zero_buf) % 16) throw std::runtime_error("sort_pairs: zero_buf must be 16 B aligned, a multiple of 4 ints");
     if (n >= (int64_t(1) << 31)) throw std::runtime_error("sort_pairs: more than 2^31 entries");
     if (temp_bytes < sort_pairs_temp_bytes(n, bits)) throw std::runtime_error("sort_pairs: workspace too small");
     char* base = static_cast<char*>(temp);
-    unsigned long long* counter = reinterpret_cast<unsigned long long*>(base);
+    (void)epoch; (void)err_flag;      // (the one-launch form's arrival counter and time-out report)
     int* counts = reinterpret_cast<int*>(base + 256);
     const size_t arr = align_up(static_cast<size_t>(n) * sizeof(int), 256);
     int* tmp_k = reinterpret_cast<int*>(base + 256 + sizeof(int) * kSortMaxBlocks * kSortMaxBuckets);
@@ -218,10 +233,11 @@ void sort_pairs(void* temp, size_t temp_bytes, uint64_t* epoch, const int* keys_
         const bool to_out = ((p.passes - 1 - i) % 2) == 0;
         int* dst_k = to_out ? keys_out : tmp_k;
         int* dst_v = to_out ? vals_out : tmp_v;
-        *epoch += static_cast<uint64_t>(p.blocks);
-        hipLaunchKernelGGL(radix_pass_kernel, dim3(p.blocks), dim3(kSortThreads), 0, s, src_k, src_v, dst_k, dst_v,
-                           static_cast<uint32_t>(n), shift, p.digit_bits[i], p.per_wave, counts, counter,
-                           static_cast<unsigned long long>(*epoch), err_flag);
+        hipLaunchKernelGGL(radix_count_kernel, dim3(p.blocks), dim3(kSortThreads), 0, s, src_k, static_cast<uint32_t>(n), shift,
+                           p.digit_bits[i], p.per_wave, counts, reinterpret_cast<int4*>(i == 0 ? zero_buf : nullptr),
+                           static_cast<uint32_t>(i == 0 && zero_buf ? zero_count / 4 : 0));
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(p.blocks), dim3(kSortThreads), 0, s, src_k, src_v, dst_k, dst_v,
+                           static_cast<uint32_t>(n), shift, p.digit_bits[i], p.per_wave, counts);
         shift += p.digit_bits[i];
         src_k = dst_k; src_v = dst_v;
     }

@@ -80,9 +80,9 @@ __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, co
     }
 }
 
-void launch_csr_build(const Csr& c, hipStream_t s) {
-    // row_begin | row_end | num_chunks | num_touched are one allocation (model.cpp): a single memset clears them all
-    (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * (2 * c.rows + 3), s);
+void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared) {
+    // row_begin | row_end | num_chunks | num_touched are one allocation (model.cpp), padded so that one fill kernel does it
+    if (!counters_cleared) (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * csr_counter_ints(c.rows), s);
     if (c.n > 0)
         hipLaunchKernelGGL(csr_bounds_kernel, dim3(stream_grid(c.n, 256)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end,
                            row_pass_split(c) ? c.touched : nullptr, c.num_touched);

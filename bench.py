@@ -92,8 +92,8 @@ def algorithmic_bytes(kernel, wl, method):
 
 
 # kernel group (engine profiler name) -> rocprofv3 kernel name prefix, for the PMC traffic figures kept under profiles/
-PMC_KERNEL = {"loss_fused": "loss_rows_kernel", "row_pass_entities": "row_pass_kernel<4, 1, 3>",
-              "row_pass_words_mv": "row_pass_kernel<4, 0, 2>", "row_pass_words_u": "row_pass_kernel<4, 0, 0>",
+PMC_KERNEL = {"loss_fused": "loss_rows_kernel", "row_pass_entities": "table_pass_kernel<4, 1, 3",
+              "row_pass_words_mv": "table_pass_kernel<4, 0, 2", "row_pass_words_u": "table_pass_kernel<4, 0, 0",
               "gather_mean_words": "gather_mean_kernel", "adam_u_words": "adam_u_kernel"}
 
 
@@ -431,7 +431,7 @@ def main():
         # largest kernel of the step that runs with nothing else next to it but the (tiny) side-stream sorts. In the fused
         # step the documents update / dT GEMM overlap the dx GEMM / words update on a second stream; their event-timed
         # durations (marked "overlapped") include the time they share the chip and are not per-kernel roofline figures.
-        for k in (() if args.sequential else ("update_entities", "chunk_pass_entities", "row_pass_entities", "gemm_bwd_T", "transform_update", "csr_entities", "csr_words")):
+        for k in (() if args.sequential else ("update_entities", "row_pass_entities", "gemm_bwd_T", "transform_update", "csr_entities", "csr_words")):
             if k in breakdown:
                 breakdown[k]["overlapped"] = True
         have = lambda k: prof_timed.get(k, (0, 0))[1] > 0

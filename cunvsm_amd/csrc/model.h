@@ -177,7 +177,7 @@ class Model {
     // forward / backward kernels and are joined right before the row passes.
     hipStream_t aux_stream_ = nullptr;
     hipStream_t aux2_stream_ = nullptr;   // the words CSR build: next to the documents CSR build instead of behind it
-    hipStream_t aux3_stream_ = nullptr;   // the documents CSR build (NVSM_SORT_LAYOUT 4)
+    hipStream_t aux3_stream_ = nullptr;   // host-batch copies, then the documents CSR build (NVSM_SORT_LAYOUT 4)
     hipEvent_t ev_csr_ents_ = nullptr;
     hipEvent_t ev_inputs_ = nullptr, ev_csr_ = nullptr;
     // fused step(): the documents update (HBM bound) and the dT GEMM (MFMA bound) run on the side stream next to the
@@ -195,7 +195,7 @@ class Model {
     DevBuf<int64_t> in_words_[2], in_labels_[2], in_ids64_;      // host batches: two staging sets (see compute_cost)
     DevBuf<float> in_wwts_[2], in_instw_[2];
     int in_parity_ = 0;
-    hipStream_t copy_stream_ = nullptr;
+    hipStream_t copy_stream_ = nullptr;   // alias of aux3_stream_
     hipEvent_t ev_copied_ = nullptr, ev_step_begin_[2] = {nullptr, nullptr};
     bool copied_recorded_ = false, last_batch_on_host_ = false;
     DevBuf<int> widx_, ids_;

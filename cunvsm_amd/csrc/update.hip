@@ -428,8 +428,13 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
 // the rows of at most kChunk entries, which depend on nothing: they overlap the chunk work instead of queueing behind
 // two kernel boundaries. Counters return to zero (reset by the last arriver) for the next pass.
 constexpr int kMaxGroupsPerBlock = 256;      // one-column rows: a thread group is a single thread
+#ifdef NVSM_TABLE_PASS_WAVES
+#define NVSM_TABLE_PASS_ATTR __attribute__((amdgpu_waves_per_eu(NVSM_TABLE_PASS_WAVES)))
+#else
+#define NVSM_TABLE_PASS_ATTR
+#endif
 template <int V, int TABLE, int KIND, int UNROLL>
-__global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
+__global__ __launch_bounds__(256) NVSM_TABLE_PASS_ATTR void table_pass_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
     constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
     const int gpb = blockDim.x / G;
     const int group = threadIdx.x / G, lig = threadIdx.x - group * G;

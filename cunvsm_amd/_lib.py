@@ -112,6 +112,7 @@ def lib():
         "nvsm_range_push": (None, [cp]), "nvsm_range_pop": (None, []),
         "nvsm_profile_enable": (C.c_int, [vp, C.c_int]), "nvsm_profile_reset": (C.c_int, [vp]),
         "nvsm_profile_names": (C.c_int, [vp, vp, i64]), "nvsm_profile_select": (C.c_int, [vp, cp]), "nvsm_debug_delay": (C.c_int, [vp, C.c_int]),
+        "nvsm_debug_set_table_pass_form": (C.c_int, [C.c_int]),
         "nvsm_profile_get": (C.c_int, [vp, cp, P(C.c_double), P(i64)]),
         "nvsm_debug_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
         "nvsm_debug_sort": (C.c_int, [i64, C.c_int, vp, vp, vp, C.c_int, P(C.c_float)]),

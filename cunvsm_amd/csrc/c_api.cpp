@@ -158,6 +158,7 @@ int nvsm_set_allreduce_callback(nvsm_model* m, nvsm_allreduce_fn fn, void* user)
     return guarded([&] { m->impl.set_allreduce_callback(fn, user); });
 }
 
+int nvsm_debug_set_table_pass_form(int one_launch) { cunvsm::set_table_pass_one_launch(one_launch != 0); return NVSM_OK; }
 int nvsm_debug_delay(nvsm_model* m, int microseconds) { NVSM_REQUIRE(m); return guarded([&] { m->impl.debug_delay(microseconds); }); }
 int nvsm_profile_enable(nvsm_model* m, int enable) { NVSM_REQUIRE(m); return guarded([&] { m->impl.synchronize(); m->impl.prof.enabled = enable != 0; }); }
 int nvsm_profile_select(nvsm_model* m, const char* kernel) {

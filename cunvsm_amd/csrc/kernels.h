@@ -204,6 +204,7 @@ void launch_lazy_refresh(const LazyRefreshArgs& a, int64_t max_rows, hipStream_t
 void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
 void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
 void launch_table_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);      // both, in one launch (update.hip)
+void set_table_pass_one_launch(bool on);      // tests / A-B runs: false = the three-launch form (also NVSM_MERGED_PASS=0)
 
 // words, window > 1 (cpp/updates_adagrad.cu:83-97, cpp/updates_adam.cu:132-151)
 void launch_adagrad_scale(const float* acc, const int* idx, int window, int64_t B, float eps, float* scale, hipStream_t s);

@@ -108,6 +108,10 @@ constexpr int kSegUnrollShallow = 2;
 template <int V, int TABLE, bool VEC, int kSegUnroll = kSegUnrollDeep>
 __device__ __forceinline__ void accumulate_segment(const RowPassArgs& a, const int* __restrict__ sorted_entry,
                                                    int begin, int end, int col, float (&g)[V], float& q) {
+    // Which products the compiler fuses with the following add may differ from one kernel this is inlined into to the
+    // next; the three-launch and the one-launch form of a pass (and the dense / streaming halves of a split pass) must
+    // round alike, so the contraction is spelled out: fused here, never in apply_row_formula.
+#pragma clang fp contract(off)
     const bool need_q = (a.sq_src != nullptr);
     const int last = end - 1;
     int en_next[kSegUnroll];
@@ -142,7 +146,7 @@ __device__ __forceinline__ void accumulate_segment(const RowPassArgs& a, const i
             if (need_q) q += sq[u];
             if (VEC) {
 #pragma unroll
-                for (int i = 0; i < V; ++i) g[i] += cf[u] * x[u][i];
+                for (int i = 0; i < V; ++i) g[i] = __builtin_fmaf(cf[u], x[u][i], g[i]);
             }
         }
     }
@@ -324,6 +328,7 @@ template <int V, int KIND>
 __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t row, bool first_col, size_t off, int cnt,
                                                   bool touch_p, const float (&g)[V], float q, float (&p)[V],
                                                   float (&m)[V], float (&v)[V]) {
+#pragma clang fp contract(off)      // every product rounded on its own, in whichever kernel this lands (see accumulate_segment)
     if (KIND == ROW_SGD) {
         if (!touch_p) return;
 #pragma unroll
@@ -428,13 +433,10 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
 // the rows of at most kChunk entries, which depend on nothing: they overlap the chunk work instead of queueing behind
 // two kernel boundaries. Counters return to zero (reset by the last arriver) for the next pass.
 constexpr int kMaxGroupsPerBlock = 256;      // one-column rows: a thread group is a single thread
-#ifdef NVSM_TABLE_PASS_WAVES
-#define NVSM_TABLE_PASS_ATTR __attribute__((amdgpu_waves_per_eu(NVSM_TABLE_PASS_WAVES)))
-#else
-#define NVSM_TABLE_PASS_ATTR
-#endif
+// (Forcing four waves per SIMD — the words passes need 133 registers, five too many — was measured with
+// amdgpu_waves_per_eu: the spills cost more than the occupancy gains, 1.123 against 1.105 ms per step.)
 template <int V, int TABLE, int KIND, int UNROLL>
-__global__ __launch_bounds__(256) NVSM_TABLE_PASS_ATTR void table_pass_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
+__global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
     constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
     const int gpb = blockDim.x / G;
     const int group = threadIdx.x / G, lig = threadIdx.x - group * G;
@@ -759,10 +761,12 @@ void launch_row_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
 }
 
 // NVSM_MERGED_PASS=0 (A/B runs, tests): the three-launch form
-static bool merged_pass_enabled() {
-    static const bool on = [] { const char* e = std::getenv("NVSM_MERGED_PASS"); return !(e && e[0] == '0'); }();
+static bool& merged_pass_flag() {
+    static bool on = [] { const char* e = std::getenv("NVSM_MERGED_PASS"); return !(e && e[0] == '0'); }();
     return on;
 }
+static bool merged_pass_enabled() { return merged_pass_flag(); }
+void set_table_pass_one_launch(bool on) { merged_pass_flag() = on; }
 
 template <int V, int TABLE>
 static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nvec, int64_t row_items, hipStream_t s) {

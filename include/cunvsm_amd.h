@@ -244,6 +244,9 @@ int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const 
 /* Queues a kernel on the handle's stream that spins for `microseconds` of GPU wall clock: profiling runs put it in
  * front of a step so that the host has queued the whole step before the GPU starts it (tools/rocprof_summary.py timeline). */
 int nvsm_debug_delay(nvsm_model* m, int microseconds);
+/* table passes of the update in one launch (1, the default) or as the three launches chunk / level-2 / rows (0): the two
+ * forms are bit-identical (tests/test_gpu_parity.py); process-wide */
+int nvsm_debug_set_table_pass_form(int one_launch);
 /* the stable (row, entry) radix sort alone: keys of `bits` significant bits in, sorted keys + their original positions out */
 int nvsm_debug_sort(int64_t n, int bits, const int32_t* keys, int32_t* keys_out, int32_t* vals_out, int repeats, float* avg_ms);
 int nvsm_debug_gather_mean(int64_t num_rows, int dim, const float* table, const int64_t* idx, const float* wts,

@@ -296,6 +296,43 @@ def test_hot_rows_are_chunked(method):
         assert err <= UPD_TOL * delta + 1e-7 * np.linalg.norm(o.get(p)), (p, err, delta)
 
 
+@pytest.mark.parametrize("method", ["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
+@pytest.mark.parametrize("dims", [(300, 256), (7, 5)])
+def test_one_launch_table_pass_equals_three_launches(method, dims):
+    """The update's table passes in one launch (chunk tree of the long rows handed over by last-arriver counters, update.hip
+    table_pass_kernel) against the chunk / level-2 / row launches: same additions in the same order, so every parameter
+    and optimiser state is bit-identical. 40 words under Zipf at batch 4096: the head rows hold > 4096 entries (both
+    levels of the tree), the tail a handful; three steps, so that counters left non-zero by a pass would show."""
+    spec = dict(num_words=40, num_entities=30, word_dim=dims[0], entity_dim=dims[1], window=10, num_random=4,
+                nonlinearity="hard_tanh", batch_norm=True, update_method=method)
+    spec["lambda"] = 0.01
+    B = 4096
+    rs = np.random.RandomState(11)
+    params = random_params(spec, rs)
+    batches = [random_batch(spec, rs, B, zipf=True) for _ in range(3)]
+    assert np.bincount(batches[0][0], minlength=40).max() > 4096
+    results = []
+    try:
+        for one_launch in (1, 0):
+            ca._lib.check(ca.lib().nvsm_debug_set_table_pass_form(one_launch))
+            g = gpu_model(spec, B)
+            load_params(g, params, True)
+            for words, ww, labels, iw, ids in batches:
+                g.compute_cost(ca.Batch(words, labels, ww, iw), ids); g.compute_gradients(); g.update(0.001)
+            state = {"adagrad": ["word_representations/a", "entity_representations/a"],
+                     "sparse_adam": ["word_representations/m", "word_representations/v", "entity_representations/m",
+                                     "entity_representations/v"],
+                     "dense_adam": ["word_representations/m", "word_representations/v", "entity_representations/m",
+                                    "entity_representations/v"],
+                     "full_adam": ["word_representations/m", "word_representations/v", "entity_representations/m",
+                                   "entity_representations/v"]}.get(method, [])
+            results.append({p: g.get_param(p) for p in list(PARAMS) + state})
+    finally:
+        ca._lib.check(ca.lib().nvsm_debug_set_table_pass_form(1))
+    for p in results[0]:
+        np.testing.assert_array_equal(results[0][p], results[1][p], err_msg=p)
+
+
 def test_edge_cases_ragged_and_minimal():
     """B not a multiple of anything, B = 1, k = 0 (no negatives), window = 1, NULL weights."""
     spec = dict(num_words=30, num_entities=20, word_dim=8, entity_dim=12, window=1, num_random=0,

@@ -708,6 +708,10 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // F3: phrase representations (objective.cu:126-130). The previous step's dT GEMM may still be reading its phrase
     // matrix on the side stream: write the other one.
     if (T_pending_) phrase_p_ = (phrase_p_ == phrase_.p) ? phrase_alt_.p : phrase_.p;
+    // NVSM_JOIN_E (experiments): where the main stream waits for the previous step's documents update — 0 = right before
+    // the loss kernel (its first reader), 1 = before the projection GEMM, 2 = before the word gather
+    static const int join_e_at = [] { const char* e = std::getenv("NVSM_JOIN_E"); return e ? std::atoi(e) : 0; }();
+    if (join_e_at == 2) join_E();
     {
         PROF("gather_mean_words");
         const bool l2p = cfg_.l2_normalize_phrase_reprs != 0;
@@ -721,6 +725,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // F5: projection GEMM  pre[B][de] = phrase[B][dw] · Tt[dw][de] (+ b when no BN)   (params.cu:417-421)
     // F6 (first half): with batch-norm the column sums Σx, Σx² of the projection ride in the GEMM epilogue
     join_T();        // the previous step's projection update (after its dT GEMM, the last reader of dy)
+    if (join_e_at == 1) join_E();
     {
         PROF("gemm_fwd");
         launch_gemm(0, 0, phrase_p_, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,

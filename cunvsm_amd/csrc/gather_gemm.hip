@@ -1,5 +1,6 @@
 // gfx950 kernels: embedding gather-mean, fp32 MFMA GEMM, split-K reduce, small utilities.
 #include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 #include "device_utils.h"
 
@@ -12,12 +13,14 @@ namespace cunvsm {
 // embedding row (a 300-float row = 75 chunks; a wave covers parts of at most two rows).
 // out[b][t] = (Σ_j wt[b,j]·table[idx[b,j]][t]) / window     — divides by window even when weighted.
 // =============================================================================================
-template <int V>
+// LAZY: the table decays lazily (kernels.h LazyView): a gathered row first gets the factors of the updates it sat out.
+struct NoLazyView { const int* stamp; int now; float decay[1]; };      // the eager kernel carries no 0.5 KB of factors
+template <int V, bool LAZY>
 __global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restrict__ table, int dim,
                                                           const int* __restrict__ idx,
                                                           const float* __restrict__ wts, int window,
-                                                          uint32_t total, uint32_t nvec,
-                                                          float* __restrict__ out) {
+                                                          uint32_t total, uint32_t nvec, float* __restrict__ out,
+                                                          typename std::conditional<LAZY, LazyView, NoLazyView>::type lazy) {
     const float fw = static_cast<float>(window);
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
         const uint32_t b = q / nvec;
@@ -32,8 +35,15 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restric
             const float wt = wp ? wp[j] : 1.f;
             float x[V];
             ldv<V>(table + row * dim + c, x);
+            if (LAZY) {
+                for (int u = lazy.stamp[row]; u < lazy.now; ++u) {
+                    const float d = lazy.decay[u % kLazyHistory];
 #pragma unroll
-            for (int i = 0; i < V; ++i) acc[i] += wt * x[i];
+                    for (int i = 0; i < V; ++i) x[i] *= d;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] = __builtin_fmaf(wt, x[i], acc[i]);      // (written out: the LAZY and eager forms must round alike)
         }
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[i] = acc[i] / fw;
@@ -42,18 +52,23 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restric
 }
 
 void launch_gather_mean(const float* table, int dim, const int* idx, const float* wts, int window,
-                        int64_t num_out, float* out, hipStream_t s) {
+                        int64_t num_out, float* out, hipStream_t s, const LazyView* lazy) {
     if (num_out <= 0) return;
+    const bool lz = lazy && lazy->stamp;
     if (dim % 4 == 0) {
         const uint32_t nvec = dim / 4;
         const uint32_t total = static_cast<uint32_t>(num_out * nvec);
-        hipLaunchKernelGGL(gather_mean_kernel<4>, dim3(stream_grid(total, 256)), dim3(256), 0, s,
-                           table, dim, idx, wts, window, total, nvec, out);
+        if (lz) hipLaunchKernelGGL((gather_mean_kernel<4, true>), dim3(stream_grid(total, 256)), dim3(256), 0, s,
+                                   table, dim, idx, wts, window, total, nvec, out, *lazy);
+        else hipLaunchKernelGGL((gather_mean_kernel<4, false>), dim3(stream_grid(total, 256)), dim3(256), 0, s,
+                                table, dim, idx, wts, window, total, nvec, out, NoLazyView{});
     } else {
         const uint32_t nvec = dim;
         const uint32_t total = static_cast<uint32_t>(num_out * nvec);
-        hipLaunchKernelGGL(gather_mean_kernel<1>, dim3(stream_grid(total, 256)), dim3(256), 0, s,
-                           table, dim, idx, wts, window, total, nvec, out);
+        if (lz) hipLaunchKernelGGL((gather_mean_kernel<1, true>), dim3(stream_grid(total, 256)), dim3(256), 0, s,
+                                   table, dim, idx, wts, window, total, nvec, out, *lazy);
+        else hipLaunchKernelGGL((gather_mean_kernel<1, false>), dim3(stream_grid(total, 256)), dim3(256), 0, s,
+                                table, dim, idx, wts, window, total, nvec, out, NoLazyView{});
     }
 }
 

@@ -8,9 +8,19 @@
 
 namespace cunvsm {
 
+// How a reader brings the rows of a lazily decayed table up to date while it gathers them (see "lazy dense decay" below):
+// row r has had `stamp[r]` updates applied, the table `now`; the factors of the updates in between are applied to the
+// loaded values one by one, in update order — the roundings of the dense passes — without writing anything back.
+constexpr int kLazyHistory = 128;
+struct LazyView {
+    const int* stamp;               // null: the table is current (no lazy decay)
+    int now;
+    float decay[kLazyHistory];      // factor of update u + 1 on the table rows at [u % kLazyHistory]
+};
+
 // ---- gather-mean (F3/F9; replaces average_repr_kernel, cpp/params.cu:75-95) ------------------
 void launch_gather_mean(const float* table, int dim, const int* idx, const float* wts, int window,
-                        int64_t num_out, float* out, hipStream_t s);
+                        int64_t num_out, float* out, hipStream_t s, const LazyView* lazy = nullptr);
 
 // ---- fp32 MFMA GEMM (F5, B6, B7; replaces the cuBLAS calls at cpp/params.cu:417,528, objective.cu:453)
 // C[M][N] = alpha * A·B (+ bias[n]).  a_layout 0: A is [M][K] (lda); 1: A is stored [K][M] (lda).
@@ -67,6 +77,7 @@ struct LossArgs {
     float* bn_inv_std;        // [de] (bn) OUT
     const float* bias;        // [de] (bn: β)
     const float* E;           // [nD][de]
+    LazyView lazyE;           // pending decay of E's rows, applied as they are gathered (stamp null: none)
     const int* ids;           // [B*R]
     const float* inst_w;      // [B] or null
     float* proj;              // [B][de]  act(BN(pre))
@@ -88,6 +99,8 @@ struct LossArgs {
     float inv_de;             // exp(−log(de))
 };
 void launch_loss(const LossArgs& a, hipStream_t s);
+// true: the kernel launch_loss picks for these shapes applies LossArgs::lazyE itself; false: the rows must be current
+bool loss_reads_lazily(const LossArgs& a);
 
 // per-row mean of squares: out[b] = Σ_t G[b][t]² · inv_dim  (cpp/updates_adam.cu:232-240)
 void launch_row_meansq(const float* G, int64_t rows, int dim, float inv_dim, float* out, hipStream_t s);
@@ -174,8 +187,8 @@ struct RowPassArgs {
     int nt_m;                  // first moments with streaming (nt) loads / stores: nobody gathers them (documents table)
     int shallow;               // set by launch_row_pass: two entries in flight per lane instead of eight (rows >= entries)
     int lazy;                  // lazy dense decay (below): rows without entries are NOT visited, their decay stays pending
-    int* stamp;                // lazy, last pass of the table's update: stamp[row] = stamp_value for every row visited
-    int stamp_value;
+    LazyView pending;          // lazy: the row's P (and m, by s_m) first get the factors of the updates (stamp[row], now] the
+                               //   row sat out, one by one (pending.stamp null: the rows are current)
 };
 // ---- lazy dense decay, for tables much larger than the batch ------------------------------------------------------------
 // The reference rewrites EVERY row of a table on every update (θ·(1 − λ·lr), Adam m·β₁, v·β₂: cpp/storage.cu:65-67,
@@ -187,11 +200,12 @@ struct RowPassArgs {
 // roundings the dense pass would have produced: parameters and optimiser state stay bit-identical to the eager path
 // (tests/test_gpu_lazy.py compares them). Every kLazyHistory updates, and before anything else looks at a whole table
 // (get_param, set_param, replica averaging), all rows are brought up to date.
-constexpr int kLazyHistory = 128;
 struct LazyRefreshArgs {
     float* P; float* m;                 // table rows, first moments (null: none)
     float* sc;                          // per-row scalar state (Adam v / Adagrad accumulator; null: none)
     float* sc_snapshot;                 // copy of the refreshed scalar the row pass reads while it writes `sc` (null: none)
+    int scalars_only;                   // P, m and the stamps are left alone (the row pass refreshes them itself): only the
+                                        //   scalar is brought up to date and snapshotted, one thread per row
     int* stamp;                         // [rows] updates applied to the row
     const int* list; const int* list_count;      // rows to refresh (Csr::touched); null = all `rows`
     int64_t rows; int dim;
@@ -199,6 +213,8 @@ struct LazyRefreshArgs {
     float s_m, s_v;                     // per-update factors of m and of the scalar (1 = none)
     float decay[kLazyHistory];          // factor of update u on P at [(u - 1) % kLazyHistory]
 };
+// stamp[row] = value for the rows of c.touched (after the last pass of a lazy table's update)
+void launch_stamp_rows(const Csr& c, int* stamp, int value, int64_t max_rows, hipStream_t s);
 void launch_lazy_refresh(const LazyRefreshArgs& a, int64_t max_rows, hipStream_t s);
 
 void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);

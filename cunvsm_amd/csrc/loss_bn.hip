@@ -16,6 +16,7 @@ namespace cunvsm {
 template <int V>
 __device__ __forceinline__ void bn_stats_from_sums(const double* __restrict__ sums, int dim, int c, double n, float eps,
                                                    float (&mean)[V], float (&inv_std)[V]) {
+#pragma clang fp contract(off)      // the same values in every kernel this is inlined into
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const double m = sums[c + i] / n;
@@ -305,8 +306,25 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 // the NVSM config: 151 us vs 234 us for the generic kernel below; a gather-only kernel with the same access
 // pattern (no arithmetic, no outputs) takes 132 us.
 // ---------------------------------------------------------------------------------------------
-template <int RB>
+// LAZY: E decays lazily (kernels.h LazyView): a gathered row gets the factors of the updates it sat out, one by one; the
+// row's stamp is wave-uniform (scalar loads), so the loop is too.
+template <int RB, bool LAZY>
+__device__ __forceinline__ void loss_refresh_row(const LossArgs& a, size_t id, float (&e)[4]) {
+    if (LAZY) {
+        for (int u = a.lazyE.stamp[id]; u < a.lazyE.now; ++u) {
+            const float d = a.lazyE.decay[u % kLazyHistory];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] *= d;
+        }
+    }
+}
+
+template <int RB, bool LAZY = false>
 __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_wave) {
+    // Which products get fused into the following sum is written out (fmaf in the dot products and the gradient / statistics
+    // sums, nothing else), not left to the compiler: the LAZY and the eager instantiation — different loop structures
+    // around the same arithmetic — were contracted differently (Σdy came out one ulp apart) and have to agree bit for bit.
+#pragma clang fp contract(off)
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int de = a.de, R = a.R;
@@ -364,7 +382,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
             y = (a.nonlinearity == 0) ? tanhf(y) : fminf(fmaxf(y, a.clip_min), a.clip_max);
             y = valid ? y : 0.f;
             out[i] = y;
-            ssq += y * y;
+            ssq = __builtin_fmaf(y, y, ssq);
         }
         if (valid) stv<4>(a.proj + b * de + c, out);
         ssq = wave_sum(ssq);
@@ -383,12 +401,19 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
                     ldv<4>(reinterpret_cast<const float*>(rowp + coff), e[u]);
                 }
             }
+            if (LAZY) {
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int r = min(r0 + u, R - 1);
+                    loss_refresh_row<RB, LAZY>(a, static_cast<size_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(myid, r))), e[u]);
+                }
+            }
             float dot[RB];
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 float d = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d += out[i] * e[u][i];
+                for (int i = 0; i < 4; ++i) d = __builtin_fmaf(out[i], e[u][i], d);
                 dot[u] = d;
             }
 #pragma unroll
@@ -422,7 +447,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
             const float dd = (a.nonlinearity == 0) ? (1.f - y * y) : ((y > a.clip_min && y < a.clip_max) ? 1.f : 0.f);
             g[i] = valid ? dd * gp[i] : 0.f;
             sdy[i] += g[i];
-            sdyx[i] += g[i] * xhat[i];
+            sdyx[i] = __builtin_fmaf(g[i], xhat[i], sdyx[i]);
         }
         if (valid) stv<4>(a.dy + b * de + c, g);
     }
@@ -460,8 +485,11 @@ static void launch_loss_rows(const LossArgs& a, hipStream_t s) {
     epw = epw < 1 ? 1 : (epw > 16 ? 16 : epw);
     const int grid = ceil_div(a.B, 4 * epw);
     const size_t shmem = (8 * static_cast<size_t>(a.de) + 4) * sizeof(float);
-    hipLaunchKernelGGL((loss_rows_kernel<RB>), dim3(grid), dim3(256), shmem, s, a, epw);
+    if (a.lazyE.stamp) hipLaunchKernelGGL((loss_rows_kernel<RB, true>), dim3(grid), dim3(256), shmem, s, a, epw);
+    else hipLaunchKernelGGL((loss_rows_kernel<RB, false>), dim3(grid), dim3(256), shmem, s, a, epw);
 }
+
+bool loss_reads_lazily(const LossArgs& a) { return a.de % 4 == 0 && a.de <= 256 && a.R <= 64 && !a.l2_entity; }
 
 void launch_loss(const LossArgs& a, hipStream_t s) {
     if (a.B <= 0) return;

@@ -696,14 +696,8 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     };
     const bool any_lazy = words_.lazy || ents_.lazy;
     if (csr_after == 0 || any_lazy) launch_csr_builds(ev_inputs_);
-    if (words_.lazy) {
-        // lazy dense decay: the rows this batch is about to gather (= the touched list of the words CSR) first get the
-        // decay of the updates they sat out — the sort is on the critical path here, a small price next to the dense
-        // passes it replaces (tables much larger than the batch only)
-        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
-        Csr cw = csr_of(words_, B * w);
-        lazy_refresh(words_, &cw, stream_);
-    }
+    // (lazy dense decay: the gathers below bring the rows they read up to date on the fly — LazyView — and the row passes of
+    //  the update do it for real; nothing waits for the sorts here)
 
     // F3: phrase representations (objective.cu:126-130). The previous step's dT GEMM may still be reading its phrase
     // matrix on the side stream: write the other one.
@@ -715,7 +709,8 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     {
         PROF("gather_mean_words");
         const bool l2p = cfg_.l2_normalize_phrase_reprs != 0;
-        launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, l2p ? phrase_raw_.p : phrase_p_, stream_);
+        const LazyView lv = lazy_view(words_);
+        launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, l2p ? phrase_raw_.p : phrase_p_, stream_, &lv);
         // optional phrase normaliser (objective.cu:136-142): the raw means stay cached for its backward pass
         if (l2p) launch_l2_rows_forward(phrase_raw_.p, B, dw, phrase_p_, phrase_norms_.p, stream_);
     }
@@ -746,14 +741,9 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
 
     // F7–F16 + B1–B4: fused loss
     join_E();        // the previous step's documents update: reads proj / coef, writes E
-    if (ents_.lazy) {                                    // as for the words: the documents the loss is about to gather
-        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
-        Csr ce = csr_of(ents_, N);
-        lazy_refresh(ents_, &ce, stream_);
-    }
     {
         PROF("loss_fused");
-        LossArgs a;
+        LossArgs a{};
         a.pre = pre_.p; a.bn_mean = bn_mean_.p; a.bn_inv_std = bn_inv_std_.p; a.bias = b_.p;
         a.bn_sums = stats_fwd_; a.bn_n = bn_n; a.bn_eps = 1e-4f;
         a.E = ents_.P.p; a.ids = ids_.p; a.inst_w = instw_;
@@ -773,6 +763,16 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         a.clip_min = std::nextafter(-1.0f, -1.0f - 1e-5f);                                      // cuda_utils.h:91-96
         a.clip_max = std::nextafter(1.0f, 1.0f + 1e-5f);
         a.inv_de = static_cast<float>(std::exp(-std::log(static_cast<double>(de))));
+        if (ents_.lazy) {
+            if (loss_reads_lazily(a)) a.lazyE = lazy_view(ents_);
+            else {
+                // the generic loss kernel (odd dimensions, entity normaliser) reads the rows as they are: the documents of
+                // this batch (the touched list of their CSR) are brought up to date first, behind the sort
+                NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
+                Csr ce = csr_of(ents_, N);
+                lazy_refresh(ents_, &ce, stream_);
+            }
+        }
         launch_loss(a, stream_);
     }
     if (csr_after == 3 && !any_lazy) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
@@ -961,6 +961,29 @@ void Model::lazy_refresh(TableState& t, const Csr* touched, hipStream_t s) {
     launch_lazy_refresh(r, max_rows, s);
 }
 
+LazyView Model::lazy_view(const TableState& t) const {
+    LazyView v{};
+    if (!t.lazy) return v;
+    v.stamp = t.stamp.p; v.now = t.updates_done;
+    std::memcpy(v.decay, t.decay_hist, sizeof(v.decay));
+    return v;
+}
+
+// before the passes of an update: the per-row scalar of the rows the batch touches, brought up to date into the
+// snapshot the row pass reads (a few KB; P and m are refreshed by the row passes themselves)
+void Model::lazy_scalar_snapshot(TableState& t, const Csr& c, hipStream_t s) {
+    if (!t.lazy || !t.lazy_scalar) return;
+    LazyRefreshArgs r{};
+    r.scalars_only = 1;
+    r.sc = t.sc[0].p; r.sc_snapshot = t.sc[1].p;
+    r.stamp = t.stamp.p; r.rows = t.rows; r.dim = t.dim; r.now = t.updates_done;
+    r.s_m = 1.f; r.s_v = 1.f;
+    if (cfg_.update_method == NVSM_ADAM) { RowPassArgs k{}; fill_adam_consts(k, 1.f, 0.f); r.s_v = k.s_v; }
+    r.list = c.touched; r.list_count = c.num_touched;
+    PROF_ON(&t == &words_ ? "lazy_scalars_words" : "lazy_scalars_entities", s);
+    launch_lazy_refresh(r, std::min<int64_t>(c.n, t.rows), s);
+}
+
 void Model::lazy_flush_all() {
     if (!words_.lazy && !ents_.lazy) return;
     synchronize();
@@ -976,11 +999,16 @@ void Model::lazy_begin_update(TableState& t, RowPassArgs& a, bool scalar_pingpon
     if (!t.lazy) return;
     a.lazy = 1;
     if (scalar_pingpong) { a.sc_in = t.sc[1].p; a.sc_out = t.sc[0].p; }
+    a.pending = lazy_view(t);                                        // what the rows this pass visits sat out
     t.decay_hist[t.updates_done % kLazyHistory] = a.decay;           // factor of update number updates_done + 1 on P
 }
-void Model::lazy_end_update(TableState& t, hipStream_t s) {
+void Model::lazy_end_update(TableState& t, const Csr& c, hipStream_t s) {
     if (!t.lazy) return;
     t.updates_done += 1;
+    {   // the touched rows carry this update
+        PROF_ON(&t == &words_ ? "lazy_stamp_words" : "lazy_stamp_entities", s);
+        launch_stamp_rows(c, t.stamp.p, t.updates_done, std::min<int64_t>(c.n, t.rows), s);
+    }
     // the kernel arguments carry the factors of the last kLazyHistory updates: nobody may fall further behind
     if (t.updates_done % kLazyHistory == 0) lazy_refresh(t, nullptr, s);
 }
@@ -1033,13 +1061,13 @@ void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row
     if (t.lazy) {
         lazy_begin_update(t, a, swap_sc);
         swap_sc = false;
-        a.stamp = t.stamp.p; a.stamp_value = t.updates_done + 1;
+        lazy_scalar_snapshot(t, c, strm);
     }
     a.nt_m = nt_mask() & 1; a.nt_p = (nt_mask() >> 1) & 1;
     if (row_pass_after) NVSM_HIP_CHECK(hipStreamWaitEvent(strm, row_pass_after, 0));
     { PROF_ON("row_pass_entities", strm); launch_table_pass(c, a, strm); }
     if (swap_sc) t.sc_cur ^= 1;
-    lazy_end_update(t, strm);
+    lazy_end_update(t, c, strm);
 }
 
 void Model::update_words(float lr, float sl) {
@@ -1058,9 +1086,8 @@ void Model::update_words(float lr, float sl) {
     if (method == NVSM_SGD) {
         a.kind = ROW_SGD; a.dense = sl > 0.f;
         lazy_begin_update(t, a, false);
-        if (t.lazy) { a.stamp = t.stamp.p; a.stamp_value = t.updates_done + 1; }
         { PROF("row_pass_words"); launch_table_pass(c, a, stream_); }
-        lazy_end_update(t, stream_);
+        lazy_end_update(t, c, stream_);
         return;
     }
     if (method == NVSM_ADAGRAD) {
@@ -1073,9 +1100,8 @@ void Model::update_words(float lr, float sl) {
         { PROF("adagrad_scale_words"); launch_adagrad_scale(t.sc[t.sc_cur].p, widx_.p, w, B_, 1e-6f, scale_w_.p, stream_); }
         a.kind = ROW_SGD; a.src_scale = scale_w_.p; a.dense = sl > 0.f;
         lazy_begin_update(t, a, false);
-        if (t.lazy) { a.stamp = t.stamp.p; a.stamp_value = t.updates_done + 1; }
         { PROF("row_pass_words"); launch_table_pass(c, a, stream_); }
-        lazy_end_update(t, stream_);
+        lazy_end_update(t, c, stream_);
         return;
     }
     // Adam
@@ -1098,15 +1124,15 @@ void Model::update_words(float lr, float sl) {
     a.kind = ROW_ADAM_MV;
     a.nt_m = (nt_mask() >> 2) & 1;
     lazy_begin_update(t, a, true);
+    lazy_scalar_snapshot(t, c, stream_);
     { PROF("row_pass_words_mv"); launch_table_pass(c, a, stream_); }
     if (!t.lazy) t.sc_cur ^= 1;
     { PROF("adam_u_words"); launch_adam_u(t.m.p, t.sc[t.sc_cur].p, dw, widx_.p, w, B_, a.bc, a.eps, U_.p, stream_); }
     RowPassArgs r = a;
     r.kind = ROW_SGD; r.X = U_.p; r.sq_src = nullptr; r.dense = sl > 0.f;
     r.nt_m = 0; r.nt_p = (nt_mask() >> 3) & 1;
-    if (t.lazy) { r.stamp = t.stamp.p; r.stamp_value = t.updates_done + 1; }
     { PROF("row_pass_words_u"); launch_table_pass(c, r, stream_); }
-    lazy_end_update(t, stream_);
+    lazy_end_update(t, c, stream_);
 }
 
 void Model::update_transform(float lr, float sl, hipStream_t strm) {

@@ -162,8 +162,10 @@ class Model {
     void allreduce_f32(float* dev, int64_t n, hipStream_t s);
     void lazy_refresh(TableState& t, const Csr* touched, hipStream_t s);     // null = every row of the table
     void lazy_flush_all();                 // before anything reads or writes whole tables (get / set_param, averaging)
+    LazyView lazy_view(const TableState& t) const;      // what a reader needs to bring the rows it gathers up to date on the fly
+    void lazy_scalar_snapshot(TableState& t, const Csr& c, hipStream_t s);   // the touched rows' scalar state, before an update's passes
     void lazy_begin_update(TableState& t, RowPassArgs& a, bool scalar_pingpong);
-    void lazy_end_update(TableState& t, hipStream_t s);
+    void lazy_end_update(TableState& t, const Csr& c, hipStream_t s);
     void raise_device_error();             // throws when a kernel has flagged bad ids / non-finite values since the last check
     void debug_check(const float* x, int64_t n, int which);
     void alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entries);

@@ -20,14 +20,28 @@ namespace cunvsm {
 // =============================================================================================
 __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* __restrict__ row_begin,
                                   int* __restrict__ row_end, int* __restrict__ touched, int* __restrict__ num_touched) {
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
-         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int k = key[i];
-        if (i == 0 || key[i - 1] != k) {
-            row_begin[k] = static_cast<int>(i);
-            if (touched) touched[atomicAdd(num_touched, 1)] = k;      // list order is irrelevant: rows are independent
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    // (whole waves iterate together: the touched-row list is appended to with ONE atomic per wave and turn — one per row
+    //  start serialised 700 k atomics on a single counter at |D| = 2 M: 158 us)
+    for (int64_t i0 = blockIdx.x * static_cast<int64_t>(blockDim.x) + (threadIdx.x - lane); i0 < n;
+         i0 += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t i = i0 + lane;
+        const bool in = i < n;
+        const int k = in ? key[i] : 0;
+        const bool head = in && (i == 0 || key[i - 1] != k);
+        if (head) row_begin[k] = static_cast<int>(i);
+        if (in && (i == n - 1 || key[i + 1] != k)) row_end[k] = static_cast<int>(i + 1);
+        if (touched) {                                                   // list order is irrelevant: rows are independent
+            const uint64_t heads = __ballot(head);
+            if (heads) {
+                const int leader = __ffsll(static_cast<long long>(heads)) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(num_touched, __popcll(heads));
+                base = __shfl(base, leader, 64);
+                if (head) touched[base + __popcll(heads & lt)] = k;
+            }
         }
-        if (i == n - 1 || key[i + 1] != k) row_end[k] = static_cast<int>(i + 1);
     }
 }
 
@@ -324,6 +338,25 @@ __device__ __forceinline__ void load_row_state(const RowPassArgs& a, size_t off,
     }
 }
 
+// lazy decay: the row's P and m first get the factors of the updates the row sat out, one at a time in update order — what
+// the dense passes would have done to it (kernels.h). The per-row scalar travels separately (launch_lazy_refresh's
+// scalars_only mode leaves an up-to-date snapshot in sc_in).
+template <int V, int KIND>
+__device__ __forceinline__ void refresh_row_state(const RowPassArgs& a, int64_t row, float (&p)[V], float (&m)[V]) {
+    if (!a.pending.stamp) return;
+    for (int u = a.pending.stamp[row]; u < a.pending.now; ++u) {
+        if (RowKindTraits<V, KIND>::kUsesP) {
+            const float d = a.pending.decay[u % kLazyHistory];
+#pragma unroll
+            for (int i = 0; i < V; ++i) p[i] *= d;
+        }
+        if (RowKindTraits<V, KIND>::kUsesM) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) m[i] *= a.s_m;
+        }
+    }
+}
+
 template <int V, int KIND>
 __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t row, bool first_col, size_t off, int cnt,
                                                   bool touch_p, const float (&g)[V], float q, float (&p)[V],
@@ -406,6 +439,7 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
             // the row's own state does not depend on the entries: fetch it first so it is in flight during the gather
             float p[V], m[V], v[V];
             load_row_state<V, KIND>(a, off, cnt, p_always, p, m, v);
+            refresh_row_state<V, KIND>(a, row, p, m);
 
             float g[V];
 #pragma unroll
@@ -420,7 +454,6 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
             }
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, touch_p, g, q, p, m, v);
         }
-        if (a.stamp && lig == 0) a.stamp[row] = a.stamp_value;      // lazy decay: this row now carries this update
     }
 }
 
@@ -531,6 +564,7 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
             const size_t off = static_cast<size_t>(row) * dim + col;
             float p[V], m[V], v[V];
             load_row_state<V, KIND>(a, off, cnt, p_always, p, m, v);
+            refresh_row_state<V, KIND>(a, row, p, m);
             float g[V];
 #pragma unroll
             for (int i = 0; i < V; ++i) g[i] = 0.f;
@@ -539,7 +573,6 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
             else sum_partials_agent<V, VEC, 4>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, true, g, q, p, m, v);
         }
-        if (a.stamp && lig == 0) a.stamp[row] = a.stamp_value;
         return;
     }
     // ---- rows of at most kChunk entries ----
@@ -558,6 +591,7 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
             const size_t off = static_cast<size_t>(row) * dim + col;
             float p[V], m[V], v[V];
             load_row_state<V, KIND>(a, off, cnt, p_always, p, m, v);
+            refresh_row_state<V, KIND>(a, row, p, m);
             float g[V];
 #pragma unroll
             for (int i = 0; i < V; ++i) g[i] = 0.f;
@@ -565,7 +599,6 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
             if (cnt > 0) accumulate_segment<V, TABLE, VEC, UNROLL>(a, c.sorted_entry, begin, end, col, g, q);
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, touch_p, g, q, p, m, v);
         }
-        if (a.stamp && lig == 0) a.stamp[row] = a.stamp_value;
     }
 }
 
@@ -647,8 +680,40 @@ __global__ __launch_bounds__(256) void lazy_refresh_kernel(LazyRefreshArgs a) {
     }
 }
 
+// scalars_only: one thread per listed row; the scalar is brought up to date in place and snapshotted, nothing else moves
+__global__ void lazy_scalar_snapshot_kernel(LazyRefreshArgs a) {
+    const int64_t limit = a.list ? static_cast<int64_t>(*a.list_count) : a.rows;
+    for (int64_t it = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; it < limit;
+         it += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t row = a.list ? static_cast<int64_t>(a.list[it]) : it;
+        const int from = a.stamp[row];
+        float v = a.sc[row];
+        if (a.s_v != 1.f) for (int u = from; u < a.now; ++u) v *= a.s_v;
+        // (the in-place value stays as it was: the row pass, which reads the snapshot, writes the new one over it and then
+        //  stamps the row; a row's pending count therefore still describes what is stored)
+        a.sc_snapshot[row] = v;
+    }
+}
+
+// After the last pass of a lazy table's update: the rows the batch touched now carry this update. A launch of its own,
+// not a store at the end of the row pass: a row's thread group may straddle two waves (G = 75 lanes for 300 columns, 3
+// for 12), and the second wave must still find the old stamp when it reads what the row sat out.
+__global__ void stamp_rows_kernel(const int* __restrict__ list, const int* __restrict__ count, int* __restrict__ stamp, int value) {
+    const int64_t limit = *count;
+    for (int64_t it = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; it < limit;
+         it += static_cast<int64_t>(gridDim.x) * blockDim.x) stamp[list[it]] = value;
+}
+void launch_stamp_rows(const Csr& c, int* stamp, int value, int64_t max_rows, hipStream_t s) {
+    if (max_rows <= 0) return;
+    hipLaunchKernelGGL(stamp_rows_kernel, dim3(stream_grid(max_rows, 256)), dim3(256), 0, s, c.touched, c.num_touched, stamp, value);
+}
+
 void launch_lazy_refresh(const LazyRefreshArgs& a, int64_t max_rows, hipStream_t s) {
     if (max_rows <= 0) return;
+    if (a.scalars_only) {
+        if (a.sc && a.sc_snapshot) hipLaunchKernelGGL(lazy_scalar_snapshot_kernel, dim3(stream_grid(max_rows, 256)), dim3(256), 0, s, a);
+        return;
+    }
     int64_t blocks = (max_rows + 3) / 4;                       // 4 waves per workgroup, one row per wave
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (a.dim % 4 == 0) hipLaunchKernelGGL(lazy_refresh_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);

@@ -75,8 +75,8 @@ def test_lazy_decay_is_bit_identical_to_the_dense_passes(method, lam, bn, dims, 
     for m in (eager, lazy):
         m.profile_enable(True)
         m.step(ca.Batch(words, labels, ww, iw), 1e-3, entity_ids=ids)
-    assert {"lazy_refresh_words", "lazy_refresh_entities"} <= set(lazy.profile())
-    assert not any(k.startswith("lazy_refresh") for k in eager.profile())
+    assert {"lazy_stamp_words", "lazy_stamp_entities"} <= set(lazy.profile())
+    assert not any(k.startswith("lazy_") for k in eager.profile())
 
 
 def test_lazy_decay_with_the_device_sampler_and_set_param(monkeypatch):
@@ -111,4 +111,4 @@ def test_tables_smaller_than_the_batch_stay_eager():
     m.step(ca.Batch(words, labels, ww, iw), 1e-3, entity_ids=ids)
     m.profile_enable(True)
     m.step(ca.Batch(words, labels, ww, iw), 1e-3, entity_ids=ids)
-    assert not any(k.startswith("lazy_refresh") for k in m.profile())
+    assert not any(k.startswith("lazy_") for k in m.profile())

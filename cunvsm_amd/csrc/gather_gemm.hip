@@ -22,6 +22,11 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restric
                                                           uint32_t total, uint32_t nvec, float* __restrict__ out,
                                                           typename std::conditional<LAZY, LazyView, NoLazyView>::type lazy) {
     const float fw = static_cast<float>(window);
+    __shared__ float hist[LAZY ? kLazyHistory : 1];      // the factor history, out of the kernel arguments (per-lane index)
+    if (LAZY) {
+        for (int i = threadIdx.x; i < kLazyHistory; i += blockDim.x) hist[i] = lazy.decay[i];
+        __syncthreads();
+    }
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
         const uint32_t b = q / nvec;
         const uint32_t c = (q - b * nvec) * V;
@@ -37,7 +42,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restric
             ldv<V>(table + row * dim + c, x);
             if (LAZY) {
                 for (int u = lazy.stamp[row]; u < lazy.now; ++u) {
-                    const float d = lazy.decay[u % kLazyHistory];
+                    const float d = hist[u % kLazyHistory];
 #pragma unroll
                     for (int i = 0; i < V; ++i) x[i] *= d;
                 }

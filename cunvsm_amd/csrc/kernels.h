@@ -100,7 +100,7 @@ struct LossArgs {
 };
 void launch_loss(const LossArgs& a, hipStream_t s);
 // true: the kernel launch_loss picks for these shapes applies LossArgs::lazyE itself; false: the rows must be current
-bool loss_reads_lazily(const LossArgs& a);
+bool loss_reads_lazily(int de, int R, bool l2_entity);
 
 // per-row mean of squares: out[b] = Σ_t G[b][t]² · inv_dim  (cpp/updates_adam.cu:232-240)
 void launch_row_meansq(const float* G, int64_t rows, int dim, float inv_dim, float* out, hipStream_t s);
@@ -187,6 +187,7 @@ struct RowPassArgs {
     int nt_m;                  // first moments with streaming (nt) loads / stores: nobody gathers them (documents table)
     int shallow;               // set by launch_row_pass: two entries in flight per lane instead of eight (rows >= entries)
     int lazy;                  // lazy dense decay (below): rows without entries are NOT visited, their decay stays pending
+    int rows_elsewhere;        // set by launch_table_pass: the rows of at most a chunk's entries are done by entry_walk_kernel
     LazyView pending;          // lazy: the row's P (and m, by s_m) first get the factors of the updates (stamp[row], now] the
                                //   row sat out, one by one (pending.stamp null: the rows are current)
 };

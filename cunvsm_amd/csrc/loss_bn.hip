@@ -306,13 +306,16 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 // the NVSM config: 151 us vs 234 us for the generic kernel below; a gather-only kernel with the same access
 // pattern (no arithmetic, no outputs) takes 132 us.
 // ---------------------------------------------------------------------------------------------
-// LAZY: E decays lazily (kernels.h LazyView): a gathered row gets the factors of the updates it sat out, one by one; the
-// row's stamp is wave-uniform (scalar loads), so the loop is too.
-template <int RB, bool LAZY>
-__device__ __forceinline__ void loss_refresh_row(const LossArgs& a, size_t id, float (&e)[4]) {
+// LAZY: E decays lazily (kernels.h LazyView): a gathered row gets the factors of the updates it sat out, one by one. The
+// stamps of the example's rows are fetched by the lanes that hold their ids (one vector load, in front of the row loads);
+// the factor history lives in two registers (lane l: factors l and l + 64) and is read with v_readlane — the update
+// counter is wave-uniform, so the loop costs a handful of scalar / VALU cycles per pending update and no memory access.
+template <bool LAZY>
+__device__ __forceinline__ void loss_refresh_row(int from, int now, float dlo, float dhi, float (&e)[4]) {
     if (LAZY) {
-        for (int u = a.lazyE.stamp[id]; u < a.lazyE.now; ++u) {
-            const float d = a.lazyE.decay[u % kLazyHistory];
+        for (int u = from; u < now; ++u) {
+            const int src = __builtin_bit_cast(int, (u & 64) ? dhi : dlo);
+            const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(src, u & 63));
 #pragma unroll
             for (int i = 0; i < 4; ++i) e[i] *= d;
         }
@@ -343,6 +346,8 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
     }
     float lane_loss = 0.f;
     const int lane_r = lane < R ? lane : R - 1;
+    float dlo = 1.f, dhi = 1.f;
+    if (LAZY) { dlo = a.lazyE.decay[lane]; dhi = a.lazyE.decay[lane + 64]; }
 
     float xn[4] = {0, 0, 0, 0};
     int idn = 0;
@@ -358,6 +363,8 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
         for (int i = 0; i < 4; ++i) x[i] = xn[i];
         const int myid = idn;
         float w = wn;
+        int mystamp = 0;
+        if (LAZY) mystamp = a.lazyE.stamp[static_cast<uint32_t>(myid)];
 
         float e[RB][4];
 #pragma unroll
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
                     const int r = min(r0 + u, R - 1);
-                    loss_refresh_row<RB, LAZY>(a, static_cast<size_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(myid, r))), e[u]);
+                    loss_refresh_row<LAZY>(__builtin_amdgcn_readlane(mystamp, r), a.lazyE.now, dlo, dhi, e[u]);
                 }
             }
             float dot[RB];
@@ -489,7 +496,7 @@ static void launch_loss_rows(const LossArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((loss_rows_kernel<RB, false>), dim3(grid), dim3(256), shmem, s, a, epw);
 }
 
-bool loss_reads_lazily(const LossArgs& a) { return a.de % 4 == 0 && a.de <= 256 && a.R <= 64 && !a.l2_entity; }
+bool loss_reads_lazily(int de, int R, bool l2_entity) { return de % 4 == 0 && de <= 256 && R <= 64 && !l2_entity; }
 
 void launch_loss(const LossArgs& a, hipStream_t s) {
     if (a.B <= 0) return;

@@ -695,7 +695,9 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         if (se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
     };
     const bool any_lazy = words_.lazy || ents_.lazy;
-    if (csr_after == 0 || any_lazy) launch_csr_builds(ev_inputs_);
+    // (a lazily decayed documents table read by the generic loss kernel is refreshed by list first: that needs the CSR now)
+    const bool csr_first = csr_after == 0 || (ents_.lazy && !loss_reads_lazily(de, static_cast<int>(R_), cfg_.l2_normalize_entity_reprs != 0));
+    if (csr_first) launch_csr_builds(ev_inputs_);
     // (lazy dense decay: the gathers below bring the rows they read up to date on the fly — LazyView — and the row passes of
     //  the update do it for real; nothing waits for the sorts here)
 
@@ -714,7 +716,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         // optional phrase normaliser (objective.cu:136-142): the raw means stay cached for its backward pass
         if (l2p) launch_l2_rows_forward(phrase_raw_.p, B, dw, phrase_p_, phrase_norms_.p, stream_);
     }
-    if (csr_after == 1 && !any_lazy) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
+    if (csr_after == 1 && !csr_first) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     debug_check(phrase_p_, B * dw, 0);                  // CHECK_MATRIX(*result->phrase_reprs_), objective.cu:134,141
 
     // F5: projection GEMM  pre[B][de] = phrase[B][dw] · Tt[dw][de] (+ b when no BN)   (params.cu:417-421)
@@ -730,7 +732,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
     const double bn_n = (cfg_.world_size > 1 && cfg_.sync_batch_norm) ? B_global : static_cast<double>(B);
-    if (csr_after == 2 && !any_lazy) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
+    if (csr_after == 2 && !csr_first) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     debug_check(pre_.p, B * de, 1);                     // CHECK_MATRIX(*result->word_projections_), objective.cu:152
     // F6: batch statistics (cudnn_utils.cu:107-124), ε = 1e-4 (objective.cu:114)
     if (cfg_.batch_normalization && cfg_.world_size > 1 && cfg_.sync_batch_norm) {
@@ -764,7 +766,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         a.clip_max = std::nextafter(1.0f, 1.0f + 1e-5f);
         a.inv_de = static_cast<float>(std::exp(-std::log(static_cast<double>(de))));
         if (ents_.lazy) {
-            if (loss_reads_lazily(a)) a.lazyE = lazy_view(ents_);
+            if (loss_reads_lazily(a.de, a.R, a.l2_entity != 0)) a.lazyE = lazy_view(ents_);
             else {
                 // the generic loss kernel (odd dimensions, entity normaliser) reads the rows as they are: the documents of
                 // this batch (the touched list of their CSR) are brought up to date first, behind the sort
@@ -775,7 +777,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         }
         launch_loss(a, stream_);
     }
-    if (csr_after == 3 && !any_lazy) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
+    if (csr_after == 3 && !csr_first) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     NVSM_HIP_CHECK(hipGetLastError());      // a failed launch of any kernel above surfaces here, not at the next sync
     have_forward_ = true;
     if (debug_) {

@@ -342,11 +342,11 @@ __device__ __forceinline__ void load_row_state(const RowPassArgs& a, size_t off,
 // the dense passes would have done to it (kernels.h). The per-row scalar travels separately (launch_lazy_refresh's
 // scalars_only mode leaves an up-to-date snapshot in sc_in).
 template <int V, int KIND>
-__device__ __forceinline__ void refresh_row_state(const RowPassArgs& a, int64_t row, float (&p)[V], float (&m)[V]) {
+__device__ __forceinline__ void refresh_row_state(const RowPassArgs& a, const float* hist, int64_t row, float (&p)[V], float (&m)[V]) {
     if (!a.pending.stamp) return;
     for (int u = a.pending.stamp[row]; u < a.pending.now; ++u) {
         if (RowKindTraits<V, KIND>::kUsesP) {
-            const float d = a.pending.decay[u % kLazyHistory];
+            const float d = hist[u % kLazyHistory];
 #pragma unroll
             for (int i = 0; i < V; ++i) p[i] *= d;
         }
@@ -357,10 +357,11 @@ __device__ __forceinline__ void refresh_row_state(const RowPassArgs& a, int64_t 
     }
 }
 
+// sc_old: the row's scalar state going in, for the kinds that have one
 template <int V, int KIND>
-__device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t row, bool first_col, size_t off, int cnt,
-                                                  bool touch_p, const float (&g)[V], float q, float (&p)[V],
-                                                  float (&m)[V], float (&v)[V]) {
+__device__ __forceinline__ void apply_row_formula_sc(const RowPassArgs& a, int64_t row, bool first_col, size_t off, int cnt,
+                                                     bool touch_p, const float (&g)[V], float q, float (&p)[V],
+                                                     float (&m)[V], float (&v)[V], float sc_old) {
 #pragma clang fp contract(off)      // every product rounded on its own, in whichever kernel this lands (see accumulate_segment)
     if (KIND == ROW_SGD) {
         if (!touch_p) return;
@@ -368,7 +369,7 @@ __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t 
         for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * g[i];
         if (a.nt_p) stv_nt<V>(a.P + off, p); else stv<V>(a.P + off, p);
     } else if (KIND == ROW_ADAGRAD_ENT) {
-        const float acc = a.sc_in[row] + q;
+        const float acc = sc_old + q;
         if (first_col) a.sc_out[row] = acc;
         if (!touch_p) return;
         const float sc = 1.f / sqrtf(acc + a.eps);
@@ -376,7 +377,7 @@ __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t 
         for (int i = 0; i < V; ++i) p[i] = p[i] * a.decay + a.lr * (g[i] * sc);
         if (a.nt_p) stv_nt<V>(a.P + off, p); else stv<V>(a.P + off, p);
     } else if (KIND == ROW_SCALAR_ACC) {
-        if (first_col) a.sc_out[row] = a.sc_in[row] + q;
+        if (first_col) a.sc_out[row] = sc_old + q;
     } else if (KIND == ROW_ADAM_FULL) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -397,7 +398,7 @@ __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t 
 #pragma unroll
         for (int i = 0; i < V; ++i) m[i] = m[i] * a.s_m + a.one_m_b1 * g[i];
         if (a.nt_m) stv_nt<V>(a.m + off, m); else stv<V>(a.m + off, m);
-        const float vn = a.sc_in[row] * a.s_v + a.one_m_b2 * q;
+        const float vn = sc_old * a.s_v + a.one_m_b2 * q;
         if (first_col) a.sc_out[row] = vn;
         if (KIND == ROW_ADAM_SPARSE_ENT) {
             if (!touch_p) return;
@@ -415,9 +416,26 @@ __device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t 
     }
 }
 
+template <int KIND>
+struct RowKindScalar { static constexpr bool value = (KIND == ROW_ADAGRAD_ENT || KIND == ROW_SCALAR_ACC || KIND == ROW_ADAM_MV ||
+                                                      KIND == ROW_ADAM_SPARSE_ENT || KIND == ROW_ADAM_DENSE); };
+template <int V, int KIND>
+__device__ __forceinline__ void apply_row_formula(const RowPassArgs& a, int64_t row, bool first_col, size_t off, int cnt,
+                                                  bool touch_p, const float (&g)[V], float q, float (&p)[V],
+                                                  float (&m)[V], float (&v)[V]) {
+    float sc_old = 0.f;
+    if (RowKindScalar<KIND>::value) sc_old = a.sc_in[row];
+    apply_row_formula_sc<V, KIND>(a, row, first_col, off, cnt, touch_p, g, q, p, m, v, sc_old);
+}
+
 template <int V, int TABLE, int KIND, int UNROLL>
 __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int G, int nvec) {
     constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
+    __shared__ float hist[kLazyHistory];      // lazy decay: the factor history, out of the kernel arguments (per-lane index)
+    if (a.pending.stamp) {
+        for (int i = threadIdx.x; i < kLazyHistory; i += blockDim.x) hist[i] = a.pending.decay[i];
+        __syncthreads();
+    }
     const int rpb = blockDim.x / G;
     const int group = threadIdx.x / G, lig = threadIdx.x - group * G;
     if (group >= rpb) return;
@@ -439,7 +457,7 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
             // the row's own state does not depend on the entries: fetch it first so it is in flight during the gather
             float p[V], m[V], v[V];
             load_row_state<V, KIND>(a, off, cnt, p_always, p, m, v);
-            refresh_row_state<V, KIND>(a, row, p, m);
+            refresh_row_state<V, KIND>(a, hist, row, p, m);
 
             float g[V];
 #pragma unroll
@@ -471,14 +489,21 @@ constexpr int kMaxGroupsPerBlock = 256;      // one-column rows: a thread group 
 template <int V, int TABLE, int KIND, int UNROLL>
 __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
     constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
+    __shared__ float hist[kLazyHistory];      // lazy decay: the factor history, out of the kernel arguments (per-lane index)
+    if (a.pending.stamp) {
+        for (int i = threadIdx.x; i < kLazyHistory; i += blockDim.x) hist[i] = a.pending.decay[i];
+        __syncthreads();
+    }
     const int gpb = blockDim.x / G;
     const int group = threadIdx.x / G, lig = threadIdx.x - group * G;
     const int dim = a.dim;
     if (static_cast<int>(blockIdx.x) < chunk_blocks) {
         __shared__ int todo[kMaxGroupsPerBlock];
         const int nchunks = min(c.num_chunks[0], c.max_chunks);
-        if (static_cast<int>(blockIdx.x) * gpb >= nchunks) return;              // the whole workgroup
-        const int ci = blockIdx.x * gpb + group;
+        // (one turn when the launch has a workgroup per gpb chunks, as the one-launch pass does; the chunk-only launch next to
+        //  entry_walk_kernel has a bounded grid and strides)
+        for (int cb = blockIdx.x; cb * gpb < nchunks; cb += chunk_blocks) {
+        const int ci = cb * gpb + group;
         const bool active = group < gpb && ci < nchunks;
         int row = 0, nch = 0, c_in_row = 0;
         if (active) {
@@ -555,7 +580,7 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
         }
         __syncthreads();
         what = (group < gpb) ? todo[group] : 0;
-        if (what != 2) return;
+        if (what != 2) continue;
         // the row: ordered sum of its partials, then the row formula (row_pass_kernel's long-row branch)
         const int cnt = c.row_end[row] - c.row_begin[row];
         const bool p_always = (a.decay != 1.f) || KIND == ROW_ADAM_FULL || KIND == ROW_ADAM_DENSE;
@@ -564,7 +589,7 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
             const size_t off = static_cast<size_t>(row) * dim + col;
             float p[V], m[V], v[V];
             load_row_state<V, KIND>(a, off, cnt, p_always, p, m, v);
-            refresh_row_state<V, KIND>(a, row, p, m);
+            refresh_row_state<V, KIND>(a, hist, row, p, m);
             float g[V];
 #pragma unroll
             for (int i = 0; i < V; ++i) g[i] = 0.f;
@@ -573,10 +598,11 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
             else sum_partials_agent<V, VEC, 4>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, true, g, q, p, m, v);
         }
+        }
         return;
     }
     // ---- rows of at most kChunk entries ----
-    if (group >= gpb) return;
+    if (a.rows_elsewhere || group >= gpb) return;
     const int64_t limit = a.touched_only ? static_cast<int64_t>(*c.num_touched) : c.rows;
     const int64_t nblocks = static_cast<int64_t>(gridDim.x) - chunk_blocks;
     for (int64_t r = (static_cast<int64_t>(blockIdx.x) - chunk_blocks) * gpb + group; r < limit; r += nblocks * gpb) {
@@ -591,13 +617,136 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
             const size_t off = static_cast<size_t>(row) * dim + col;
             float p[V], m[V], v[V];
             load_row_state<V, KIND>(a, off, cnt, p_always, p, m, v);
-            refresh_row_state<V, KIND>(a, row, p, m);
+            refresh_row_state<V, KIND>(a, hist, row, p, m);
             float g[V];
 #pragma unroll
             for (int i = 0; i < V; ++i) g[i] = 0.f;
             float q = 0.f;
             if (cnt > 0) accumulate_segment<V, TABLE, VEC, UNROLL>(a, c.sorted_entry, begin, end, col, g, q);
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, touch_p, g, q, p, m, v);
+        }
+    }
+}
+
+// ---- rows of a table much larger than the batch: walk the sorted ENTRIES, not a list of rows --------------------------------
+// With about one entry per touched row the list walk above is a chain of four dependent random reads per row (list -> row
+// bounds -> entry -> coefficient / source row) with a wave's worth of registers parked on it: 0.8-0.9 ms for the 705 k
+// document rows a batch touches at |D| = 2 M, where the bytes moved (3.8 GB) would take 0.6. Here a wave takes 64
+// consecutive positions of the sorted (row, entry) arrays — two coalesced loads —, every lane fetches the coefficient / scalar
+// terms of its own entry and, if its position opens a row, the row's scalar state; then the wave goes through the rows that
+// open in its range one after the other, with everything a row needs (table row, moments, its entries' source rows — ids
+// and coefficients come out of the lanes by v_readlane) issued in ONE round of loads. A row whose entries run past the
+// wave's 64 positions is finished from the following positions (rare); rows of more than kChunk entries are left to the
+// chunk tree (table_pass_kernel finishes those). The sums run over a row's entries in sorted order with
+// accumulate_segment's arithmetic: results are bit-identical to the list walk.
+template <int TABLE>
+__device__ __forceinline__ void entry_terms(const RowPassArgs& a, uint32_t en, bool ok, uint32_t& src, float& cf, float& sq) {
+#pragma clang fp contract(off)
+    src = static_cast<uint32_t>((static_cast<uint64_t>(en) * a.div_magic) >> 37);
+    float c;
+    if (TABLE == 0) c = a.wts ? a.wts[en] : 1.f;
+    else c = a.coefs ? a.coefs[en] : 1.f;
+    const float s = a.sq_src ? a.sq_src[src] : 0.f;
+    const float scl = (TABLE == 0 && a.src_scale) ? a.src_scale[src] : 1.f;
+    c = ok ? c : 0.f;
+    sq = (TABLE == 0) ? c * s : (c * c) * s;
+    cf = (TABLE == 0 && a.src_scale) ? c * scl : c;
+}
+
+constexpr int kWalkUnroll = 4;
+// g, q += the entries held by lanes [first, first + count) of (src, cf, sq), in lane order
+template <int V>
+__device__ __forceinline__ void walk_entries(const RowPassArgs& a, uint32_t src, float cf, float sq, int first, int count, int col,
+                                             bool valid, float (&g)[V], float& q) {
+#pragma clang fp contract(off)
+    const bool need_q = (a.sq_src != nullptr);
+    for (int j = 0; j < count; j += kWalkUnroll) {
+        float x[kWalkUnroll][V], cu[kWalkUnroll], su[kWalkUnroll];
+#pragma unroll
+        for (int u = 0; u < kWalkUnroll; ++u) {
+            const bool ok = (j + u) < count;
+            const int l = first + (ok ? j + u : count - 1);
+            const uint32_t s = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src), l));
+            const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cf), l));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), l));
+            cu[u] = ok ? c1 : 0.f;
+            su[u] = ok ? s1 : 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) x[u][i] = 0.f;
+            if (valid) ldv<V>(a.X + static_cast<size_t>(s) * a.dim + col, x[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kWalkUnroll; ++u) {
+            if (need_q) q += su[u];
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] = __builtin_fmaf(cu[u], x[u][i], g[i]);
+        }
+    }
+}
+
+template <int V, int TABLE, int KIND>
+__global__ __launch_bounds__(256) void entry_walk_kernel(Csr c, RowPassArgs a, int nvec) {
+    __shared__ float hist[kLazyHistory];
+    if (a.pending.stamp) {
+        for (int i = threadIdx.x; i < kLazyHistory; i += blockDim.x) hist[i] = a.pending.decay[i];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int dim = a.dim;
+    const int64_t n = c.n;
+    const int64_t nblocks = (n + 63) >> 6;
+    const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t blk = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; blk < nblocks; blk += nwaves) {
+        const int64_t base = blk << 6;
+        const int64_t i = base + lane;
+        const bool in = i < n;
+        const int key = in ? c.sorted_key[i] : -1;
+        const int prev = (in && i > 0) ? c.sorted_key[i - 1] : -1;
+        const uint32_t en = in ? static_cast<uint32_t>(c.sorted_entry[i]) : 0u;
+        const int next_key = (base + 64 < n) ? c.sorted_key[base + 64] : -1;            // wave-uniform
+        uint32_t src; float cf, sq;
+        entry_terms<TABLE>(a, en, in, src, cf, sq);
+        const bool head = in && key != prev;
+        float sc_mine = 0.f;
+        if (RowKindScalar<KIND>::value && head) sc_mine = a.sc_in[key];
+        uint64_t heads = __ballot(head);
+        while (heads) {
+            const int h = __ffsll(static_cast<long long>(heads)) - 1;
+            heads &= heads - 1;
+            const int row = __builtin_amdgcn_readlane(key, h);
+            const int cnt1 = __popcll(__ballot(key == row));                           // lanes h .. h + cnt1 - 1 (sorted)
+            int cnt2 = 0;
+            uint32_t src2 = 0; float cf2 = 0.f, sq2 = 0.f;
+            if (h + cnt1 == 64 && next_key == row) {                                    // the row runs on past this wave's range
+                const int64_t i2 = base + 64 + lane;
+                const bool in2 = i2 < n;
+                const int key2 = in2 ? c.sorted_key[i2] : -1;
+                const uint32_t en2 = in2 ? static_cast<uint32_t>(c.sorted_entry[i2]) : 0u;
+                entry_terms<TABLE>(a, en2, in2, src2, cf2, sq2);
+                cnt2 = __popcll(__ballot(key2 == row));
+            }
+            const int cnt = cnt1 + cnt2;
+            if (cnt > kChunk) continue;                                                  // chunk tree (table_pass_kernel)
+            const float sc_old = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_mine), h));
+            for (int cv = lane; cv - lane < nvec; cv += 64) {                           // (whole waves: the lanes hand entries around)
+                const bool valid = cv < nvec;
+                const int col = (valid ? cv : 0) * V;
+                const size_t off = static_cast<size_t>(row) * dim + col;
+                float p[V], m[V], v[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) { p[k] = 0.f; m[k] = 0.f; v[k] = 0.f; }
+                if (valid) {
+                    load_row_state<V, KIND>(a, off, cnt, true, p, m, v);
+                    refresh_row_state<V, KIND>(a, hist, row, p, m);
+                }
+                float g[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) g[k] = 0.f;
+                float q = 0.f;
+                walk_entries<V>(a, src, cf, sq, h, cnt1, col, valid, g, q);
+                if (cnt2) walk_entries<V>(a, src2, cf2, sq2, 0, cnt2, col, valid, g, q);
+                if (valid) apply_row_formula_sc<V, KIND>(a, row, cv == 0, off, cnt, true, g, q, p, m, v, sc_old);
+            }
         }
     }
 }
@@ -836,11 +985,14 @@ void set_table_pass_one_launch(bool on) { merged_pass_flag() = on; }
 template <int V, int TABLE>
 static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nvec, int64_t row_items, hipStream_t s) {
     const int gpb = 256 / G;
-    const int chunk_blocks = (c.n > 0 && c.max_chunks > 0) ? (c.max_chunks + gpb - 1) / gpb : 0;
+    int chunk_blocks = (c.n > 0 && c.max_chunks > 0) ? (c.max_chunks + gpb - 1) / gpb : 0;
+    if (a.rows_elsewhere && chunk_blocks > 256) chunk_blocks = 256;      // normally there is no chunk at all: a launch that costs nothing
     int64_t row_blocks = (row_items + gpb - 1) / gpb;
     if (row_blocks > 256 * 64) row_blocks = 256 * 64;
     if (a.max_blocks > 0 && row_blocks > a.max_blocks) row_blocks = a.max_blocks;
     if (row_blocks < 1) row_blocks = 1;
+    if (a.rows_elsewhere) row_blocks = 0;
+    if (chunk_blocks + row_blocks < 1) return;
     const dim3 grid(static_cast<unsigned>(chunk_blocks + row_blocks)), block(256);
 #define NVSM_TABLE_CASE(K) case K: \
         if (a.shallow) hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
@@ -859,6 +1011,30 @@ static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
 #undef NVSM_TABLE_CASE
 }
 
+// NVSM_ENTRY_WALK=0 (A/B runs, tests): the list walk for the rows of tables much larger than the batch
+static bool entry_walk_enabled() {
+    static const bool on = [] { const char* e = std::getenv("NVSM_ENTRY_WALK"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static bool entry_walk_kind(int kind) { return kind == ROW_SGD || kind == ROW_ADAGRAD_ENT || kind == ROW_ADAM_MV || kind == ROW_ADAM_SPARSE_ENT; }
+
+template <int V, int TABLE>
+static void entry_walk_dispatch(const Csr& c, const RowPassArgs& a, int nvec, hipStream_t s) {
+    if (c.n <= 0) return;
+    int64_t blocks = ((c.n + 63) / 64 + 3) / 4;          // a wave per 64 sorted positions
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+#define NVSM_WALK_CASE(K) case K: hipLaunchKernelGGL((entry_walk_kernel<V, TABLE, K>), grid, block, 0, s, c, a, nvec); break;
+    switch (a.kind) {
+        NVSM_WALK_CASE(ROW_SGD)
+        NVSM_WALK_CASE(ROW_ADAGRAD_ENT)
+        NVSM_WALK_CASE(ROW_ADAM_MV)
+        NVSM_WALK_CASE(ROW_ADAM_SPARSE_ENT)
+        default: break;
+    }
+#undef NVSM_WALK_CASE
+}
+
 // one pass over a table: chunk tree of the long rows + row formula, in one launch (table_pass_kernel)
 void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
     if (!merged_pass_enabled()) { launch_chunk_pass(c, a_in, s); launch_row_pass(c, a_in, s); return; }
@@ -873,6 +1049,18 @@ void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
         a.touched_only = 1;
         a.shallow = c.rows >= c.n;
         row_items = c.n < c.rows ? c.n : c.rows;
+    }
+    if (a.touched_only && nvec <= 64 && entry_walk_enabled() && entry_walk_kind(a.kind)) {      // (rows of one wave's width)
+        // the rows with entries, by walking the sorted entries; the chunk tree (if the batch can have rows that long) in a
+        // launch of its own, which also finishes those rows
+        a.rows_elsewhere = 1;
+        if (c.max_chunks > 0) {
+            if (V == 4) { if (a.table == 0) table_pass_dispatch<4, 0>(c, a, G, nvec, 0, s); else table_pass_dispatch<4, 1>(c, a, G, nvec, 0, s); }
+            else        { if (a.table == 0) table_pass_dispatch<1, 0>(c, a, G, nvec, 0, s); else table_pass_dispatch<1, 1>(c, a, G, nvec, 0, s); }
+        }
+        if (V == 4) { if (a.table == 0) entry_walk_dispatch<4, 0>(c, a, nvec, s); else entry_walk_dispatch<4, 1>(c, a, nvec, s); }
+        else        { if (a.table == 0) entry_walk_dispatch<1, 0>(c, a, nvec, s); else entry_walk_dispatch<1, 1>(c, a, nvec, s); }
+        return;
     }
     if (V == 4) { if (a.table == 0) table_pass_dispatch<4, 0>(c, a, G, nvec, row_items, s); else table_pass_dispatch<4, 1>(c, a, G, nvec, row_items, s); }
     else        { if (a.table == 0) table_pass_dispatch<1, 0>(c, a, G, nvec, row_items, s); else table_pass_dispatch<1, 1>(c, a, G, nvec, row_items, s); }

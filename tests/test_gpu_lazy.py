@@ -112,3 +112,47 @@ def test_tables_smaller_than_the_batch_stay_eager():
     m.profile_enable(True)
     m.step(ca.Batch(words, labels, ww, iw), 1e-3, entity_ids=ids)
     assert not any(k.startswith("lazy_") for k in m.profile())
+
+
+@pytest.mark.parametrize("lazy", [1, 0])
+@pytest.mark.parametrize("method,dims", [("sparse_adam", (256, 256)), ("sgd", (256, 64)), ("adagrad", (64, 256)),
+                                         ("sparse_adam", (12, 16)), ("sparse_adam", (300, 256)), ("adagrad", (7, 5))])
+def test_entry_walk_equals_the_list_walk(method, dims, lazy, monkeypatch):
+    """Tables larger than the batch: the rows with entries are done by walking the sorted entries (update.hip
+    entry_walk_kernel, rows up to one wave wide) instead of a list of rows. Same sums in the same order: bit-identical to the
+    three-launch form, which walks the list. The batches mix rows of one or two entries with rows of 30-64 (they straddle the
+    64-position ranges of the waves) and a few of several hundred (chunk tree, finished by the chunk-only launch)."""
+    spec = dict(num_words=6000, num_entities=9000, word_dim=dims[0], entity_dim=dims[1], window=10, num_random=4,
+                nonlinearity="hard_tanh", batch_norm=True, update_method=method)
+    spec["lambda"] = 0.01
+    B = 512
+    rs = np.random.RandomState(21)
+    params = random_params(spec, rs)
+    batches = []
+    for _ in range(4):
+        words, ww, labels, iw, ids = random_batch(spec, rs, B)
+        u = rs.rand(words.size)
+        words = np.where(u < 0.06, 7, np.where(u < 0.20, 100 + (rs.randint(0, 14, words.size)), words)).astype(words.dtype)
+        u = rs.rand(ids.size)
+        ids = np.where(u < 0.08, 3, np.where(u < 0.3, 500 + rs.randint(0, 12, ids.size), ids)).astype(ids.dtype)
+        batches.append((words, ww, labels, iw, ids))
+    cw, ce = np.bincount(batches[0][0]), np.bincount(batches[0][4])
+    assert cw.max() > 256 and ce.max() > 128 and ((cw > 30) & (cw <= 64)).sum() >= 8 and ((ce > 30) & (ce <= 64)).sum() >= 8
+    monkeypatch.setenv("NVSM_LAZY_DECAY", str(lazy))
+    monkeypatch.setenv("NVSM_LAZY_MIN_MB", "0")
+    results = []
+    try:
+        for one_launch in (1, 0):
+            ca._lib.check(ca.lib().nvsm_debug_set_table_pass_form(one_launch))
+            g = gpu_model(spec, B)
+            load_params(g, params, True)
+            for s, (words, ww, labels, iw, ids) in enumerate(batches):
+                if s % 2:
+                    g.step(ca.Batch(words, labels, ww, iw), 0.001, entity_ids=ids)
+                else:
+                    g.compute_cost(ca.Batch(words, labels, ww, iw), ids); g.compute_gradients(); g.update(0.001)
+            results.append({p: g.get_param(p) for p in list(PARAMS) + STATE[method]})
+    finally:
+        ca._lib.check(ca.lib().nvsm_debug_set_table_pass_form(1))
+    for p in results[0]:
+        np.testing.assert_array_equal(results[0][p], results[1][p], err_msg=p)

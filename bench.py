@@ -61,7 +61,7 @@ def workload(args):
               nonlinearity="hard_tanh", batch_norm=1, bias_negative_samples=0, lr=1e-3, update_method="sparse_adam")
     wl.update(PRESETS[args.config])
     for k, v in (("num_words", args.num_words), ("num_entities", args.num_entities), ("batch", args.batch),
-                 ("update_method", args.update_method)):
+                 ("update_method", args.update_method), ("word_dim", getattr(args, "word_dim", None))):
         if v is not None:                      # explicit flags win over the preset
             wl[k] = v
     args.update_method = wl.pop("update_method")
@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default 51200)")
     ap.add_argument("--num-words", type=int, default=None)
     ap.add_argument("--num-entities", type=int, default=None)
+    ap.add_argument("--word-dim", type=int, default=None, help="experiments (row alignment): d_word other than the config's 300")
     ap.add_argument("--strong-scaling", action="store_true", help="make the strong split (51 200 / N windows per rank, SURVEY §8d row 3) "
                     "the headline `value` instead of the weak one; both are always measured and reported when N > 1")
     ap.add_argument("--test-shared-gpu", action="store_true", help="test of the N > 1 control flow on a 1-GPU box: every rank on "

@@ -195,12 +195,18 @@ struct RowPassArgs {
 // The reference rewrites EVERY row of a table on every update (θ·(1 − λ·lr), Adam m·β₁, v·β₂: cpp/storage.cu:65-67,
 // cpp/updates_adam.cu:196-252): at |D| = 2 M that is 8 of the 10 GB a step moves. A row without entries only ever gets
 // multiplied by those per-update constants, so the multiplications can wait until somebody looks at the row: every row
-// carries the number of updates applied to it (stamp); before a step reads or updates a row — the rows of the batch, i.e.
-// the touched list of the CSR — launch_lazy_refresh applies the pending updates' factors ONE BY ONE, in fp32, in update
-// order (the factors of the last kLazyHistory updates travel in the kernel arguments), which is exactly the sequence of
-// roundings the dense pass would have produced: parameters and optimiser state stay bit-identical to the eager path
-// (tests/test_gpu_lazy.py compares them). Every kLazyHistory updates, and before anything else looks at a whole table
-// (get_param, set_param, replica averaging), all rows are brought up to date.
+// carries the number of updates applied to it (stamp), and whoever reads a row applies the factors of the updates it sat
+// out ONE BY ONE, in fp32, in update order (the factors of the last kLazyHistory updates travel in the kernel arguments:
+// LazyView) — exactly the sequence of roundings the dense passes would have produced, so parameters and optimiser state
+// stay bit-identical to the eager path (tests/test_gpu_lazy.py compares them):
+//   * the gathers of the forward pass (word gather-mean, loss kernel) do it in registers and write nothing back;
+//   * the row passes of the update do it to the rows of the batch before the optimiser's formula and store the result;
+//     the per-row scalar (Adam v / Adagrad accumulator) of those rows is brought up to date into a snapshot buffer by a
+//     small launch in front of the passes (launch_lazy_refresh, scalars_only), and the rows' stamps are set by a small
+//     launch behind the last pass (launch_stamp_rows) — not inside it, where another wave of the row's thread group could
+//     still be about to read the old stamp;
+//   * every kLazyHistory updates, and before anything else looks at a whole table (get_param, set_param, replica
+//     averaging), launch_lazy_refresh brings all rows up to date.
 struct LazyRefreshArgs {
     float* P; float* m;                 // table rows, first moments (null: none)
     float* sc;                          // per-row scalar state (Adam v / Adagrad accumulator; null: none)

@@ -94,16 +94,29 @@ __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, co
     }
 }
 
+// Workgroups per CSR kernel (they grid-stride). For a table much larger than the batch the bounds / chunk kernels are
+// scattered 4-byte accesses into row-indexed arrays of many MB; spread over every CU they sit next to the loss kernel and
+// slow its row gathers (378 vs 217 us at |D| = 2 M) — a few waves per CU on half the CUs do the same work in the time they
+// have (configs[4]: 1.99 -> 1.93 ms per step; no effect at the NVSM shape, where the arrays live in L2).
+// NVSM_CSR_GRID_CAP overrides (experiments).
+static int csr_grid(int64_t items, bool sparse_table) {
+    static const int cap_env = [] { const char* e = std::getenv("NVSM_CSR_GRID_CAP"); return e ? std::atoi(e) : -1; }();
+    const int cap = cap_env >= 0 ? cap_env : (sparse_table ? 128 : 0);
+    const int g = stream_grid(items, 256);
+    return (cap > 0 && g > cap) ? cap : g;
+}
+
 void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared) {
     // row_begin | row_end | num_chunks | num_touched are one allocation (model.cpp), padded so that one fill kernel does it
+    const bool sparse = row_pass_split(c);
     if (!counters_cleared) (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * csr_counter_ints(c.rows), s);
     if (c.n > 0)
-        hipLaunchKernelGGL(csr_bounds_kernel, dim3(stream_grid(c.n, 256)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end,
+        hipLaunchKernelGGL(csr_bounds_kernel, dim3(csr_grid(c.n, sparse)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end,
                            row_pass_split(c) ? c.touched : nullptr, c.num_touched);
-    hipLaunchKernelGGL(csr_chunks_kernel, dim3(stream_grid(c.rows, 256)), dim3(256), 0, s, c.row_begin, c.row_end, c.rows,
+    hipLaunchKernelGGL(csr_chunks_kernel, dim3(csr_grid(c.rows, sparse)), dim3(256), 0, s, c.row_begin, c.row_end, c.rows,
                        c.chunk_base, c.chunk2_base, c.num_chunks);
     if (c.n > 0)
-        hipLaunchKernelGGL(csr_chunk_fill_kernel, dim3(stream_grid(c.n, 256)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin,
+        hipLaunchKernelGGL(csr_chunk_fill_kernel, dim3(csr_grid(c.n, sparse)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin,
                            c.row_end, c.chunk_base, c.chunk2_base, c.chunk_desc, c.chunk2_desc, c.max_chunks, c.max_chunks2);
 }
 
@@ -685,7 +698,7 @@ __device__ __forceinline__ void walk_entries(const RowPassArgs& a, uint32_t src,
 }
 
 template <int V, int TABLE, int KIND>
-__global__ __launch_bounds__(256) void entry_walk_kernel(Csr c, RowPassArgs a, int nvec) {
+__global__ __launch_bounds__(256) void entry_walk_kernel(Csr c, RowPassArgs a, int nvec, int ppw) {
     __shared__ float hist[kLazyHistory];
     if (a.pending.stamp) {
         for (int i = threadIdx.x; i < kLazyHistory; i += blockDim.x) hist[i] = a.pending.decay[i];
@@ -694,16 +707,18 @@ __global__ __launch_bounds__(256) void entry_walk_kernel(Csr c, RowPassArgs a, i
     const int lane = threadIdx.x & 63;
     const int dim = a.dim;
     const int64_t n = c.n;
-    const int64_t nblocks = (n + 63) >> 6;
+    // ppw (a power of two <= 64): sorted positions per wave. 64 when the batch has waves to spare; a small batch gets short
+    // ranges so that its rows spread over the machine instead of queueing fifty to a wave (lanes >= ppw then only work on columns)
+    const int64_t nblocks = (n + ppw - 1) / ppw;
     const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
     for (int64_t blk = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; blk < nblocks; blk += nwaves) {
-        const int64_t base = blk << 6;
+        const int64_t base = blk * ppw;
         const int64_t i = base + lane;
-        const bool in = i < n;
+        const bool in = lane < ppw && i < n;
         const int key = in ? c.sorted_key[i] : -1;
         const int prev = (in && i > 0) ? c.sorted_key[i - 1] : -1;
         const uint32_t en = in ? static_cast<uint32_t>(c.sorted_entry[i]) : 0u;
-        const int next_key = (base + 64 < n) ? c.sorted_key[base + 64] : -1;            // wave-uniform
+        const int next_key = (base + ppw < n) ? c.sorted_key[base + ppw] : -1;          // wave-uniform
         uint32_t src; float cf, sq;
         entry_terms<TABLE>(a, en, in, src, cf, sq);
         const bool head = in && key != prev;
@@ -717,8 +732,8 @@ __global__ __launch_bounds__(256) void entry_walk_kernel(Csr c, RowPassArgs a, i
             const int cnt1 = __popcll(__ballot(key == row));                           // lanes h .. h + cnt1 - 1 (sorted)
             int cnt2 = 0;
             uint32_t src2 = 0; float cf2 = 0.f, sq2 = 0.f;
-            if (h + cnt1 == 64 && next_key == row) {                                    // the row runs on past this wave's range
-                const int64_t i2 = base + 64 + lane;
+            if (h + cnt1 == ppw && next_key == row) {                                   // the row runs on past this wave's range
+                const int64_t i2 = base + ppw + lane;
                 const bool in2 = i2 < n;
                 const int key2 = in2 ? c.sorted_key[i2] : -1;
                 const uint32_t en2 = in2 ? static_cast<uint32_t>(c.sorted_entry[i2]) : 0u;
@@ -1016,15 +1031,22 @@ static bool entry_walk_enabled() {
     static const bool on = [] { const char* e = std::getenv("NVSM_ENTRY_WALK"); return !(e && e[0] == '0'); }();
     return on;
 }
+// NVSM_ENTRY_WALK_MIN (tests: 0 sends small batches through the entry walk too)
+static int64_t entry_walk_min_entries() {
+    const char* e = std::getenv("NVSM_ENTRY_WALK_MIN");      // (read per launch: tests switch it)
+    return e ? std::atoll(e) : 64ll * 4096;
+}
 static bool entry_walk_kind(int kind) { return kind == ROW_SGD || kind == ROW_ADAGRAD_ENT || kind == ROW_ADAM_MV || kind == ROW_ADAM_SPARSE_ENT; }
 
 template <int V, int TABLE>
 static void entry_walk_dispatch(const Csr& c, const RowPassArgs& a, int nvec, hipStream_t s) {
     if (c.n <= 0) return;
-    int64_t blocks = ((c.n + 63) / 64 + 3) / 4;          // a wave per 64 sorted positions
+    int ppw = 64;                                        // sorted positions per wave: enough waves to fill the machine
+    while (ppw > 4 && c.n / ppw < 8192) ppw >>= 1;
+    int64_t blocks = ((c.n + ppw - 1) / ppw + 3) / 4;
     if (blocks > 256 * 64) blocks = 256 * 64;
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
-#define NVSM_WALK_CASE(K) case K: hipLaunchKernelGGL((entry_walk_kernel<V, TABLE, K>), grid, block, 0, s, c, a, nvec); break;
+#define NVSM_WALK_CASE(K) case K: hipLaunchKernelGGL((entry_walk_kernel<V, TABLE, K>), grid, block, 0, s, c, a, nvec, ppw); break;
     switch (a.kind) {
         NVSM_WALK_CASE(ROW_SGD)
         NVSM_WALK_CASE(ROW_ADAGRAD_ENT)
@@ -1050,7 +1072,9 @@ void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
         a.shallow = c.rows >= c.n;
         row_items = c.n < c.rows ? c.n : c.rows;
     }
-    if (a.touched_only && nvec <= 64 && entry_walk_enabled() && entry_walk_kind(a.kind)) {      // (rows of one wave's width)
+    // (rows of one wave's width; batches of a few thousand windows are a chain of launch latencies, not of round trips per
+    //  row, and keep the one-launch list walk: LSE batch 4096 0.234 vs 0.254 ms per step)
+    if (a.touched_only && nvec <= 64 && c.n >= entry_walk_min_entries() && entry_walk_enabled() && entry_walk_kind(a.kind)) {
         // the rows with entries, by walking the sorted entries; the chunk tree (if the batch can have rows that long) in a
         // launch of its own, which also finishes those rows
         a.rows_elsewhere = 1;

@@ -140,6 +140,7 @@ def test_entry_walk_equals_the_list_walk(method, dims, lazy, monkeypatch):
     assert cw.max() > 256 and ce.max() > 128 and ((cw > 30) & (cw <= 64)).sum() >= 8 and ((ce > 30) & (ce <= 64)).sum() >= 8
     monkeypatch.setenv("NVSM_LAZY_DECAY", str(lazy))
     monkeypatch.setenv("NVSM_LAZY_MIN_MB", "0")
+    monkeypatch.setenv("NVSM_ENTRY_WALK_MIN", "0")          # batches this small take the list walk otherwise
     results = []
     try:
         for one_launch in (1, 0):

@@ -114,13 +114,15 @@ def pmc_traffic(kernel, signature):
     pref = PMC_KERNEL.get(kernel)
     if not files or not pref:
         return None, None
-    with open(files[-1]) as f:
-        js = json.load(f)
-    if js.get("workload") != signature:
+    for path in reversed(files):                 # the newest summary taken on this workload
+        with open(path) as f:
+            js = json.load(f)
+        if js.get("workload") != signature:
+            continue
+        for name, e in js["kernels"].items():
+            if name.startswith(pref):
+                return int(e["fetch_bytes_corrected"] + e["write_bytes"]), os.path.basename(path)
         return None, None
-    for name, e in js["kernels"].items():
-        if name.startswith(pref):
-            return int(e["fetch_bytes_corrected"] + e["write_bytes"]), os.path.basename(files[-1])
     return None, None
 
 

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restric
                                                           const float* __restrict__ wts, int window,
                                                           uint32_t total, uint32_t nvec, float* __restrict__ out,
                                                           typename std::conditional<LAZY, LazyView, NoLazyView>::type lazy) {
+#pragma clang fp contract(on)       // fused by the language rule, so that the LAZY and eager forms round alike
     const float fw = static_cast<float>(window);
     __shared__ float hist[LAZY ? kLazyHistory : 1];      // the factor history, out of the kernel arguments (per-lane index)
     if (LAZY) {
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restric
                 }
             }
 #pragma unroll
-            for (int i = 0; i < V; ++i) acc[i] = __builtin_fmaf(wt, x[i], acc[i]);      // (written out: the LAZY and eager forms must round alike)
+            for (int i = 0; i < V; ++i) acc[i] += wt * x[i];
         }
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[i] = acc[i] / fw;

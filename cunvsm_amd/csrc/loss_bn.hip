@@ -17,7 +17,7 @@ namespace cunvsm {
 template <int V>
 __device__ __forceinline__ void bn_stats_from_sums(const double* __restrict__ sums, int dim, int c, double n, float eps,
                                                    float (&mean)[V], float (&inv_std)[V]) {
-#pragma clang fp contract(off)      // the same values in every kernel this is inlined into
+#pragma clang fp contract(on)       // by the language rule: the same values in every kernel this is inlined into
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const double m = sums[c + i] / n;
@@ -325,10 +325,12 @@ __device__ __forceinline__ void loss_refresh_row(int from, int now, float dlo, f
 
 template <int RB, bool LAZY = false>
 __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_wave) {
-    // Which products get fused into the following sum is written out (fmaf in the dot products and the gradient / statistics
-    // sums, nothing else), not left to the compiler: the LAZY and the eager instantiation — different loop structures
-    // around the same arithmetic — were contracted differently (Σdy came out one ulp apart) and have to agree bit for bit.
-#pragma clang fp contract(off)
+    // Floating-point contraction by the language rule (a product and a sum in ONE expression fuse, nothing else does),
+    // not by the optimiser's choice: the LAZY and the eager instantiation — different loop structures around the same
+    // arithmetic — were contracted differently under the default (Σdy came out one ulp apart) and have to agree bit for bit.
+    // (Spelling the fusions out with fmaf under contract(off) pinned them too but kept the compiler from pairing them into
+    // v_pk_fma_f32: 155 -> 166 us.)
+#pragma clang fp contract(on)
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int de = a.de, R = a.R;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
             y = (a.nonlinearity == 0) ? tanhf(y) : fminf(fmaxf(y, a.clip_min), a.clip_max);
             y = valid ? y : 0.f;
             out[i] = y;
-            ssq = __builtin_fmaf(y, y, ssq);
+            ssq += y * y;
         }
         if (valid) stv<4>(a.proj + b * de + c, out);
         ssq = wave_sum(ssq);
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
             for (int u = 0; u < RB; ++u) {
                 float d = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d = __builtin_fmaf(out[i], e[u][i], d);
+                for (int i = 0; i < 4; ++i) d += out[i] * e[u][i];
                 dot[u] = d;
             }
 #pragma unroll
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
             const float dd = (a.nonlinearity == 0) ? (1.f - y * y) : ((y > a.clip_min && y < a.clip_max) ? 1.f : 0.f);
             g[i] = valid ? dd * gp[i] : 0.f;
             sdy[i] += g[i];
-            sdyx[i] = __builtin_fmaf(g[i], xhat[i], sdyx[i]);
+            sdyx[i] += g[i] * xhat[i];
         }
         if (valid) stv<4>(a.dy + b * de + c, g);
     }

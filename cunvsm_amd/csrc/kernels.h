@@ -130,6 +130,7 @@ struct Csr {
     int* chunk_desc;      // [max_chunks][3] row, begin, end
     int* chunk2_base;     // [rows]  first level-2 chunk of a very long row
     int* chunk2_desc;     // [max_chunks2][2] first, last (exclusive) level-1 chunk
+    int* chunk_order;     // [max_chunks] level-1 chunks ordered by the position of their first entry in the batch (null: as numbered)
     int* num_chunks;      // [2]  level-1 / level-2 chunks in use
     int* num_touched;     // [1]  rows with at least one entry (num_chunks + 2)
     int* touched;         // [min(rows, max entries)] those rows, in no particular order (rows are independent)
@@ -149,6 +150,10 @@ constexpr int kFan = 64;      // level-1 partials per level-2 chunk
 // bounds + long-row chunk list, from sorted_key; counters_cleared: row_begin | row_end | num_chunks | num_touched (one
 // allocation of csr_counter_ints(rows) ints) are already zero (sort_pairs cleared them), otherwise a memset does it
 void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared = false);
+// Csr::chunk_order: the level-1 chunks by where in the batch their entries start (512 buckets; update.hip table_pass_kernel
+// gives each XCD one eighth of the batch so that the chunks of different hot rows over the same windows share an L2).
+// key_in / key_out: [max_chunks] scratch; sort_temp: a sort_pairs workspace for max_chunks pairs
+void launch_chunk_order(const Csr& c, int* key_in, int* key_out, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
 inline int64_t csr_counter_ints(int64_t rows) { return (2 * rows + 3 + 63) / 64 * 64; }
 bool row_pass_split(const Csr& c);                    // rows · ratio >= entries: touched-row list + streaming pass over the rest
 double table_split_ratio();                           // that ratio (2 unless NVSM_SPLIT_RATIO says otherwise)

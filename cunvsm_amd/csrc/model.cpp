@@ -208,6 +208,11 @@ struct ProfScope {
 #define PROF_ON(name, strm) ProfScope _prof_scope(prof, name, strm)
 
 // ---------------------------------------------------------------------------------------------
+// NVSM_CHUNK_ORDER=0 (A/B runs): level-1 chunks as numbered instead of in batch order
+static bool chunk_order_enabled() {
+    const char* e = std::getenv("NVSM_CHUNK_ORDER");
+    return !(e && e[0] == '0');
+}
 static int bits_for(int64_t n) {
     int b = 1;
     while ((int64_t(1) << b) < n) ++b;
@@ -235,7 +240,10 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
         x.chunk_desc.alloc(static_cast<size_t>(t.max_chunks) * 3, true);
         x.chunk2_base.alloc(rows, true);
         x.chunk2_desc.alloc(static_cast<size_t>(t.max_chunks2) * 2, true);
+        // (batches of a few thousand windows are launch-latency chains: no extra launches there)
+        if (chunk_order_enabled() && max_entries >= 64 * 4096) x.chunk_order.alloc(t.max_chunks, true);
     }
+    if (t.idx[0].chunk_order.p) { t.chunk_key.alloc(t.max_chunks, true); t.chunk_key_sorted.alloc(t.max_chunks, true); }
     t.partial.alloc(static_cast<size_t>(t.max_chunks) * dim);
     t.partial_q.alloc(t.max_chunks, true);
     t.partial2.alloc(static_cast<size_t>(t.max_chunks2) * dim);
@@ -914,14 +922,14 @@ float Model::adam_bc(uint64_t t) const {
 }
 
 Csr Model::csr_of(TableState& t, int64_t n) {
-    Csr c;
+    Csr c{};
     TableState::CsrIndex& x = t.idx[t.idx_cur];
     c.sorted_key = x.sorted_key.p; c.sorted_entry = x.sorted_entry.p;
     c.row_begin = x.csr_zeroed.p; c.row_end = x.csr_zeroed.p + t.rows; c.chunk_base = x.chunk_base.p;
     c.chunk_desc = x.chunk_desc.p; c.num_chunks = x.csr_zeroed.p + 2 * t.rows;
     c.num_touched = c.num_chunks + 2; c.touched = x.touched.p;
     c.partial = t.partial.p; c.partial_q = t.partial_q.p;
-    c.chunk2_base = x.chunk2_base.p; c.chunk2_desc = x.chunk2_desc.p;
+    c.chunk2_base = x.chunk2_base.p; c.chunk2_desc = x.chunk2_desc.p; c.chunk_order = x.chunk_order.p;
     c.partial2 = t.partial2.p; c.partial2_q = t.partial2_q.p;
     c.arrive_row = t.arrive_row.p; c.arrive2 = t.arrive2.p;
     c.n = n; c.rows = t.rows; c.max_chunks = t.max_chunks; c.max_chunks2 = t.max_chunks2;
@@ -935,6 +943,7 @@ void Model::build_csr(TableState& t, const int* keys, int64_t n, hipStream_t s) 
     sort_pairs(t.sort_temp.p, t.sort_temp_bytes, &t.sort_epoch, keys, x.sorted_key.p, nullptr, x.sorted_entry.p, n, t.sort_bits, err_host_, s,
                x.csr_zeroed.p, csr_counter_ints(t.rows));
     launch_csr_build(csr_of(t, n), s, n > 0);
+    if (x.chunk_order.p) launch_chunk_order(csr_of(t, n), t.chunk_key.p, t.chunk_key_sorted.p, t.sort_temp.p, t.sort_temp_bytes, s);
 }
 
 static void fill_adam_consts(RowPassArgs& a, float bc, float sl);

@@ -85,12 +85,14 @@ struct TableState {           // one embedding table + its optimiser state + its
     struct CsrIndex {
         DevBuf<int> sorted_key, sorted_entry, chunk_base, chunk_desc, chunk2_base, chunk2_desc;
         DevBuf<int> touched;      // rows with entries (Csr::touched)
+        DevBuf<int> chunk_order;  // Csr::chunk_order (large batches only)
         DevBuf<int> csr_zeroed;   // [row_begin (rows) | row_end (rows) | num_chunks (2) | num_touched | pad]: cleared by the sort's first launch
     };
     CsrIndex idx[2];
     int idx_sets = 1, idx_cur = 0;
     DevBuf<int> arrive_row, arrive2;      // arrival counters of the one-launch table pass (Csr)
     DevBuf<float> partial, partial_q, partial2, partial2_q;
+    DevBuf<int> chunk_key, chunk_key_sorted;      // scratch of launch_chunk_order
     DevBuf<char> sort_temp;
     size_t sort_temp_bytes = 0;
     uint64_t sort_epoch = 0;      // (unused by the two-launch sort)

@@ -515,9 +515,12 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
         const int nchunks = min(c.num_chunks[0], c.max_chunks);
         // (one turn when the launch has a workgroup per gpb chunks, as the one-launch pass does; the chunk-only launch next to
         //  entry_walk_kernel has a bounded grid and strides)
-        for (int cb = blockIdx.x; cb * gpb < nchunks; cb += chunk_blocks) {
-        const int ci = cb * gpb + group;
-        const bool active = group < gpb && ci < nchunks;
+        // workgroup cb runs on XCD cb % 8 (round-robin dispatch): with a chunk order, XCD x takes the x-th eighth of it
+        const int nslots = (nchunks + gpb - 1) / gpb, per_xcd = (nslots + 7) >> 3;
+        for (int cb = blockIdx.x; cb < (c.chunk_order ? per_xcd * 8 : nslots); cb += chunk_blocks) {
+        const int pos = (c.chunk_order ? (cb & 7) * per_xcd + (cb >> 3) : cb) * gpb + group;
+        const bool active = group < gpb && pos < nchunks;
+        const int ci = active ? (c.chunk_order ? c.chunk_order[pos] : pos) : 0;
         int row = 0, nch = 0, c_in_row = 0;
         if (active) {
             row = c.chunk_desc[ci * 3 + 0];
@@ -1000,7 +1003,9 @@ void set_table_pass_one_launch(bool on) { merged_pass_flag() = on; }
 template <int V, int TABLE>
 static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nvec, int64_t row_items, hipStream_t s) {
     const int gpb = 256 / G;
-    int chunk_blocks = (c.n > 0 && c.max_chunks > 0) ? (c.max_chunks + gpb - 1) / gpb : 0;
+    int chunk_blocks = (c.n > 0 && c.max_chunks > 0) ? (c.max_chunks + gpb - 1) / gpb + 8 : 0;      // (+ 8: an eighth per XCD, rounded up)
+    static const int cb_cap = [] { const char* e = std::getenv("NVSM_CHUNK_BLOCKS"); return e ? std::atoi(e) : 0; }();      // experiments
+    if (cb_cap > 0 && chunk_blocks > cb_cap) chunk_blocks = cb_cap;
     if (a.rows_elsewhere && chunk_blocks > 256) chunk_blocks = 256;      // normally there is no chunk at all: a launch that costs nothing
     int64_t row_blocks = (row_items + gpb - 1) / gpb;
     if (row_blocks > 256 * 64) row_blocks = 256 * 64;
@@ -1024,6 +1029,31 @@ static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
         default: break;
     }
 #undef NVSM_TABLE_CASE
+}
+
+// ---- level-1 chunks in batch order --------------------------------------------------------------------------------------
+// A chunk is 64 consecutive entries of one hot row, and a row's entries are in batch order (stable sort): chunk c of a row
+// that sits in a fraction p of the windows covers about 64 / p consecutive windows. The chunks of DIFFERENT hot rows over
+// the same windows gather the same source rows (a window's gradient row goes to every word of the window: 4.4 of a
+// window's 10 words are among the 88 hottest at Zipf(1)), but numbered row by row they run at different times on
+// different XCDs, whose L2s do not talk to each other: every one of those reads misses. Ordered by the batch position of
+// their first entry, with each XCD given one eighth of the batch (table_pass_kernel), they meet in one L2 within
+// microseconds of each other. Same chunks, same sums: results do not change.
+__global__ void chunk_order_key_kernel(Csr c, int* __restrict__ key) {
+    const int nchunks = min(c.num_chunks[0], c.max_chunks);
+    for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < c.max_chunks; ci += gridDim.x * blockDim.x) {
+        int k = 511;                                                           // unused slots sort behind the chunks (stable)
+        if (ci < nchunks) {
+            const uint64_t e = static_cast<uint32_t>(c.sorted_entry[c.chunk_desc[ci * 3 + 1]]);
+            k = static_cast<int>(min<uint64_t>(511, e * 512 / static_cast<uint64_t>(c.n)));
+        }
+        key[ci] = k;
+    }
+}
+void launch_chunk_order(const Csr& c, int* key_in, int* key_out, void* sort_temp, size_t sort_temp_bytes, hipStream_t s) {
+    if (!c.chunk_order || c.n <= 0 || c.max_chunks <= 0) return;
+    hipLaunchKernelGGL(chunk_order_key_kernel, dim3(stream_grid(c.max_chunks, 256)), dim3(256), 0, s, c, key_in);
+    sort_pairs(sort_temp, sort_temp_bytes, nullptr, key_in, key_out, nullptr, c.chunk_order, c.max_chunks, 9, nullptr, s, nullptr, 0);
 }
 
 // NVSM_ENTRY_WALK=0 (A/B runs, tests): the list walk for the rows of tables much larger than the batch

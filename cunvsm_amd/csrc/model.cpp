@@ -1206,11 +1206,19 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     // 195 → 402 us, step 1.099 → 1.126 ms. (NVSM_DOCS_AFTER_DX=0/1 overrides.)
     static const int docs_after_dx_env = [] { const char* e = std::getenv("NVSM_DOCS_AFTER_DX"); return e ? std::atoi(e) : -1; }();
     const bool docs_after_dx = docs_after_dx_env >= 0 ? docs_after_dx_env != 0 : B_ >= 16384;
-    if (docs_after_dx) backward_dx();
-    update_entities(lr, sl, aux_stream_, docs_after_dx ? ev_bwdx_ : nullptr);
-    NVSM_HIP_CHECK(hipEventRecord(ev_E_done_, aux_stream_));
-    E_pending_ = true;
-    if (!docs_after_dx) backward_dx();
+    // NVSM_DOCS_ON_MAIN (experiments): 1 = the documents update on the main stream in front of the words update, 2 = behind
+    // it (two HBM-bound passes one after the other instead of next to each other)
+    static const int docs_on_main = [] { const char* e = std::getenv("NVSM_DOCS_ON_MAIN"); return e ? std::atoi(e) : 0; }();
+    if (docs_after_dx || docs_on_main) backward_dx();
+    if (docs_on_main == 1) {
+        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
+        update_entities(lr, sl, stream_, nullptr);
+    } else if (docs_on_main == 0) {
+        update_entities(lr, sl, aux_stream_, docs_after_dx ? ev_bwdx_ : nullptr);
+        NVSM_HIP_CHECK(hipEventRecord(ev_E_done_, aux_stream_));
+        E_pending_ = true;
+    }
+    if (!docs_after_dx && !docs_on_main) backward_dx();
     if (dp) {
         backward_T(stream_);
     } else {
@@ -1226,6 +1234,10 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     }
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
     update_words(lr, sl);
+    if (docs_on_main == 2) {
+        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
+        update_entities(lr, sl, stream_, nullptr);
+    }
     if (dp) update_transform(lr, sl, stream_);
     NVSM_HIP_CHECK(hipGetLastError());
     have_grads_ = false;

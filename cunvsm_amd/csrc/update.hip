@@ -670,14 +670,15 @@ __device__ __forceinline__ void entry_terms(const RowPassArgs& a, uint32_t en, b
 }
 
 constexpr int kWalkUnroll = 4;
-// g, q += the entries held by lanes [first, first + count) of (src, cf, sq), in lane order
-template <int V>
-__device__ __forceinline__ void walk_entries(const RowPassArgs& a, uint32_t src, float cf, float sq, int first, int count, int col,
-                                             bool valid, float (&g)[V], float& q) {
+// g, q += the entries held by lanes [first, first + count) of (src, cf, sq), in lane order. NT column turns of 64 lanes each
+// are held in registers side by side (a 300-column row is two: 64 + 11 lanes), so that a row still costs ONE round of loads.
+template <int V, int NT>
+__device__ __forceinline__ void walk_entries(const RowPassArgs& a, uint32_t src, float cf, float sq, int first, int count,
+                                             const int (&col)[NT], const bool (&valid)[NT], float (&g)[NT][V], float& q) {
 #pragma clang fp contract(off)
     const bool need_q = (a.sq_src != nullptr);
     for (int j = 0; j < count; j += kWalkUnroll) {
-        float x[kWalkUnroll][V], cu[kWalkUnroll], su[kWalkUnroll];
+        float x[kWalkUnroll][NT][V], cu[kWalkUnroll], su[kWalkUnroll];
 #pragma unroll
         for (int u = 0; u < kWalkUnroll; ++u) {
             const bool ok = (j + u) < count;
@@ -688,19 +689,25 @@ __device__ __forceinline__ void walk_entries(const RowPassArgs& a, uint32_t src,
             cu[u] = ok ? c1 : 0.f;
             su[u] = ok ? s1 : 0.f;
 #pragma unroll
-            for (int i = 0; i < V; ++i) x[u][i] = 0.f;
-            if (valid) ldv<V>(a.X + static_cast<size_t>(s) * a.dim + col, x[u]);
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) x[u][t][i] = 0.f;
+                if (valid[t]) ldv<V>(a.X + static_cast<size_t>(s) * a.dim + col[t], x[u][t]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < kWalkUnroll; ++u) {
             if (need_q) q += su[u];
 #pragma unroll
-            for (int i = 0; i < V; ++i) g[i] = __builtin_fmaf(cu[u], x[u][i], g[i]);
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) g[t][i] = __builtin_fmaf(cu[u], x[u][t][i], g[t][i]);
+            }
         }
     }
 }
 
-template <int V, int TABLE, int KIND>
+template <int V, int TABLE, int KIND, int NT>
 __global__ __launch_bounds__(256) void entry_walk_kernel(Csr c, RowPassArgs a, int nvec, int ppw) {
     __shared__ float hist[kLazyHistory];
     if (a.pending.stamp) {
@@ -710,6 +717,9 @@ __global__ __launch_bounds__(256) void entry_walk_kernel(Csr c, RowPassArgs a, i
     const int lane = threadIdx.x & 63;
     const int dim = a.dim;
     const int64_t n = c.n;
+    int col[NT]; bool valid[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { valid[t] = (t * 64 + lane) < nvec; col[t] = (valid[t] ? t * 64 + lane : 0) * V; }
     // ppw (a power of two <= 64): sorted positions per wave. 64 when the batch has waves to spare; a small batch gets short
     // ranges so that its rows spread over the machine instead of queueing fifty to a wave (lanes >= ppw then only work on columns)
     const int64_t nblocks = (n + ppw - 1) / ppw;
@@ -746,24 +756,22 @@ __global__ __launch_bounds__(256) void entry_walk_kernel(Csr c, RowPassArgs a, i
             const int cnt = cnt1 + cnt2;
             if (cnt > kChunk) continue;                                                  // chunk tree (table_pass_kernel)
             const float sc_old = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_mine), h));
-            for (int cv = lane; cv - lane < nvec; cv += 64) {                           // (whole waves: the lanes hand entries around)
-                const bool valid = cv < nvec;
-                const int col = (valid ? cv : 0) * V;
-                const size_t off = static_cast<size_t>(row) * dim + col;
-                float p[V], m[V], v[V];
+            float p[NT][V], m[NT][V], v[NT][V], g[NT][V];
 #pragma unroll
-                for (int k = 0; k < V; ++k) { p[k] = 0.f; m[k] = 0.f; v[k] = 0.f; }
-                if (valid) {
-                    load_row_state<V, KIND>(a, off, cnt, true, p, m, v);
-                    refresh_row_state<V, KIND>(a, hist, row, p, m);
-                }
-                float g[V];
+            for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                for (int k = 0; k < V; ++k) g[k] = 0.f;
-                float q = 0.f;
-                walk_entries<V>(a, src, cf, sq, h, cnt1, col, valid, g, q);
-                if (cnt2) walk_entries<V>(a, src2, cf2, sq2, 0, cnt2, col, valid, g, q);
-                if (valid) apply_row_formula_sc<V, KIND>(a, row, cv == 0, off, cnt, true, g, q, p, m, v, sc_old);
+                for (int k = 0; k < V; ++k) { p[t][k] = 0.f; m[t][k] = 0.f; v[t][k] = 0.f; g[t][k] = 0.f; }
+                if (valid[t]) load_row_state<V, KIND>(a, static_cast<size_t>(row) * dim + col[t], cnt, true, p[t], m[t], v[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { if (valid[t]) refresh_row_state<V, KIND>(a, hist, row, p[t], m[t]); }
+            float q = 0.f;
+            walk_entries<V, NT>(a, src, cf, sq, h, cnt1, col, valid, g, q);
+            if (cnt2) walk_entries<V, NT>(a, src2, cf2, sq2, 0, cnt2, col, valid, g, q);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (valid[t]) apply_row_formula_sc<V, KIND>(a, row, t == 0 && lane == 0, static_cast<size_t>(row) * dim + col[t], cnt, true,
+                                                            g[t], q, p[t], m[t], v[t], sc_old);
             }
         }
     }
@@ -1006,7 +1014,7 @@ static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
     int chunk_blocks = (c.n > 0 && c.max_chunks > 0) ? (c.max_chunks + gpb - 1) / gpb + 8 : 0;      // (+ 8: an eighth per XCD, rounded up)
     static const int cb_cap = [] { const char* e = std::getenv("NVSM_CHUNK_BLOCKS"); return e ? std::atoi(e) : 0; }();      // experiments
     if (cb_cap > 0 && chunk_blocks > cb_cap) chunk_blocks = cb_cap;
-    if (a.rows_elsewhere && chunk_blocks > 256) chunk_blocks = 256;      // normally there is no chunk at all: a launch that costs nothing
+    if (a.rows_elsewhere && chunk_blocks > 2048) chunk_blocks = 2048;      // normally there is no chunk at all: a launch that costs nothing
     int64_t row_blocks = (row_items + gpb - 1) / gpb;
     if (row_blocks > 256 * 64) row_blocks = 256 * 64;
     if (a.max_blocks > 0 && row_blocks > a.max_blocks) row_blocks = a.max_blocks;
@@ -1076,7 +1084,10 @@ static void entry_walk_dispatch(const Csr& c, const RowPassArgs& a, int nvec, hi
     int64_t blocks = ((c.n + ppw - 1) / ppw + 3) / 4;
     if (blocks > 256 * 64) blocks = 256 * 64;
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
-#define NVSM_WALK_CASE(K) case K: hipLaunchKernelGGL((entry_walk_kernel<V, TABLE, K>), grid, block, 0, s, c, a, nvec, ppw); break;
+#define NVSM_WALK_CASE(K) case K: \
+        if (nvec <= 64) hipLaunchKernelGGL((entry_walk_kernel<V, TABLE, K, 1>), grid, block, 0, s, c, a, nvec, ppw); \
+        else hipLaunchKernelGGL((entry_walk_kernel<V, TABLE, K, 2>), grid, block, 0, s, c, a, nvec, ppw); \
+        break;
     switch (a.kind) {
         NVSM_WALK_CASE(ROW_SGD)
         NVSM_WALK_CASE(ROW_ADAGRAD_ENT)
@@ -1102,9 +1113,9 @@ void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
         a.shallow = c.rows >= c.n;
         row_items = c.n < c.rows ? c.n : c.rows;
     }
-    // (rows of one wave's width; batches of a few thousand windows are a chain of launch latencies, not of round trips per
+    // (rows of up to two waves' width, held side by side in registers; batches of a few thousand windows are a chain of launch latencies, not of round trips per
     //  row, and keep the one-launch list walk: LSE batch 4096 0.234 vs 0.254 ms per step)
-    if (a.touched_only && nvec <= 64 && c.n >= entry_walk_min_entries() && entry_walk_enabled() && entry_walk_kind(a.kind)) {
+    if (a.touched_only && nvec <= 128 && c.n >= entry_walk_min_entries() && entry_walk_enabled() && entry_walk_kind(a.kind)) {
         // the rows with entries, by walking the sorted entries; the chunk tree (if the batch can have rows that long) in a
         // launch of its own, which also finishes those rows
         a.rows_elsewhere = 1;

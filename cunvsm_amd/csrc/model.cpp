@@ -676,11 +676,11 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     ++step_count_;
 
     // Row-order (CSR) of both tables for the update, on the side streams: needs only the indices.
+    static const int csr_after = [] { const char* e = std::getenv("NVSM_CSR_AFTER"); return e ? std::atoi(e) : 0; }();
     NVSM_HIP_CHECK(hipEventRecord(ev_inputs_, stream_));
     inputs_recorded_ = true;
     // two side streams: the sorts are latency-bound chains of small launches, so the two tables' builds run next to
     // each other (at batch 4096 one behind the other they were the longest chain of the whole step)
-    static const int csr_after = [] { const char* e = std::getenv("NVSM_CSR_AFTER"); return e ? std::atoi(e) : 0; }();
     // Which side stream builds which table's CSR. Side stream 1 still carries the PREVIOUS step's documents update when this
     // step begins (it runs ~150 us into it), so a sort queued there starts late and lands on the loss kernel; side stream 2
     // (dT GEMM + projection update of the previous step) is free by then. NVSM_SORT_LAYOUT: 0 = documents on side stream 1,
@@ -1197,15 +1197,21 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     static const bool t_on_main = std::getenv("NVSM_DP_T_ON_MAIN") != nullptr;
     const bool dp = cfg_.world_size > 1 && t_on_main;
     RangeScope range_bu("ComputeGradients+UpdateParameters");      // cpp/main.cu:414,429 — one interleaved region here
-    NVSM_HIP_CHECK(hipEventRecord(ev_loss_, stream_));
-    // side stream 1 (behind the documents CSR build): the documents update, HBM-bound — next to the MFMA-bound dx GEMM
-    // now, and free to run on next to the next step's projection GEMM; the next loss kernel joins it
-    NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_loss_, 0));
+    static const bool fewer_events = [] { const char* e = std::getenv("NVSM_FEWER_EVENTS"); return !(e && e[0] == '0'); }();
     // ... but only once the dx GEMM is through at large batches: next to the MFMA-bound GEMM the row pass (100 k short-lived
     // waves) keeps the GEMM's workgroups from becoming resident — measured at B = 51 200: dx GEMM 132 → 203 us, dT GEMM
     // 195 → 402 us, step 1.099 → 1.126 ms. (NVSM_DOCS_AFTER_DX=0/1 overrides.)
     static const int docs_after_dx_env = [] { const char* e = std::getenv("NVSM_DOCS_AFTER_DX"); return e ? std::atoi(e) : -1; }();
     const bool docs_after_dx = docs_after_dx_env >= 0 ? docs_after_dx_env != 0 : B_ >= 16384;
+    // side stream 1 (behind the documents CSR build): the documents update, HBM-bound — free to run on next to the next
+    // step's projection GEMM; the next loss kernel joins it. It needs the loss kernel's outputs; when it is held behind the
+    // dx GEMM anyway, that GEMM's event stands for the loss kernel's too (an event recorded between two kernels of the main
+    // stream costs the stream a bubble of several microseconds).
+    const bool loss_event = !(docs_after_dx && fewer_events);
+    if (loss_event) {
+        NVSM_HIP_CHECK(hipEventRecord(ev_loss_, stream_));
+        NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_loss_, 0));
+    }
     // NVSM_DOCS_ON_MAIN (experiments): 1 = the documents update on the main stream in front of the words update, 2 = behind
     // it (two HBM-bound passes one after the other instead of next to each other)
     static const int docs_on_main = [] { const char* e = std::getenv("NVSM_DOCS_ON_MAIN"); return e ? std::atoi(e) : 0; }();
@@ -1214,7 +1220,8 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
         update_entities(lr, sl, stream_, nullptr);
     } else if (docs_on_main == 0) {
-        update_entities(lr, sl, aux_stream_, docs_after_dx ? ev_bwdx_ : nullptr);
+        if (!loss_event) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_bwdx_, 0));
+        update_entities(lr, sl, aux_stream_, (docs_after_dx && loss_event) ? ev_bwdx_ : nullptr);
         NVSM_HIP_CHECK(hipEventRecord(ev_E_done_, aux_stream_));
         E_pending_ = true;
     }

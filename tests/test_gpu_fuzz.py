@@ -41,8 +41,7 @@ def draw_spec(rs):
     return spec, B
 
 
-@pytest.mark.parametrize("seed", range(120))
-def test_random_configuration(seed):
+def _run_configuration(seed):
     rs = np.random.RandomState(1000 + seed)
     spec, B = draw_spec(rs)
     params = random_params(spec, rs, scale=0.3 if (spec["l2_phrase"] or spec["l2_entity"]) else None)
@@ -67,3 +66,18 @@ def test_random_configuration(seed):
         # fp32 noise level of a small batch take a visibly different step (see tests/test_gpu_configs.py)
         tol = (2e-2 if adam else 5e-4) * max(delta, 1e-12) + 2e-7 * np.linalg.norm(o.get(p)) + 1e-9
         assert err <= tol, (spec, B, p, err, delta)
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_configuration(seed):
+    _run_configuration(seed)
+
+
+@pytest.mark.parametrize("seed", range(0, 120, 3))
+def test_random_configuration_large_table_paths(seed, monkeypatch):
+    """The same draws with the paths of tables much larger than the batch switched on whatever the sizes: lazy dense decay
+    (rows brought up to date as they are read) and the walk over the sorted entries instead of the list of rows —
+    update.hip entry_walk_kernel, which a batch this small would not take by itself."""
+    monkeypatch.setenv("NVSM_LAZY_MIN_MB", "0")
+    monkeypatch.setenv("NVSM_ENTRY_WALK_MIN", "0")
+    _run_configuration(seed)

@@ -407,12 +407,12 @@ int gemm_split_k_slabs(int K, int want) {
 
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
-                 hipStream_t s, double* colstats, float* rowsq, float rowsq_scale, int* rowsq_parts) {
+                 hipStream_t s, double* colstats, float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip) {
     if (M <= 0 || N <= 0) return;
     if (rowsq_parts) *rowsq_parts = rowsq ? tiled_rowsq_parts(N) : 0;
     // batch-sized products against the projection matrix: the matrix stationary in LDS (gemm_tstat.hip)
     if (split_k <= 1 && launch_gemm_tstat(a_layout, b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, s, colstats, rowsq,
-                                          rowsq_scale, rowsq_parts))
+                                          rowsq_scale, rowsq_parts, busy_chip))
         return;
     GemmArgs g;
     g.colstats = (split_k > 1) ? nullptr : colstats;

@@ -30,7 +30,8 @@ void launch_gather_mean(const float* table, int dim, const int* idx, const float
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
                  hipStream_t s, double* colstats = nullptr,     // colstats [2][N] (no split-K): += Σ_rows C, Σ_rows C²
-                 float* rowsq = nullptr, float rowsq_scale = 0.f, int* rowsq_parts = nullptr);
+                 float* rowsq = nullptr, float rowsq_scale = 0.f, int* rowsq_parts = nullptr,
+                 bool busy_chip = false);     // the launch lands next to long-running kernels of other streams (kernel choice)
 // rowsq [gemm_rowsq_parts(N)][M]: rowsq_scale · Σ_cols C² per row, split by column tile (128 columns in the tiled kernel,
 // 16 in the LDS-stationary one): *rowsq_parts = the number of parts this launch wrote; launch_sum_parts adds them in
 // order (a runtime-length loop over the parts inside the row passes' unrolled gather was measured: it halves their
@@ -39,7 +40,7 @@ int gemm_rowsq_parts(int N);             // upper bound of *rowsq_parts: sizes t
 // LDS-stationary kernel for the batch-sized projection products (gemm_tstat.hip); false = shape not covered
 bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                        int lda, int ldb, int ldc, float alpha, const float* bias_n, hipStream_t s, double* colstats,
-                       float* rowsq, float rowsq_scale, int* rowsq_parts);
+                       float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip = false);
 void gemm_set_tstat_enabled(bool on);    // experiments / tests: force the tiled kernel
 void launch_sum_parts(const float* parts, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
 void gemm_set_panel_enabled(bool on);    // experiments / tests: force the tiled kernel

@@ -735,7 +735,8 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         PROF("gemm_fwd");
         launch_gemm(0, 0, phrase_p_, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
                     cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_,
-                    cfg_.batch_normalization ? stats_fwd_ : nullptr);
+                    cfg_.batch_normalization ? stats_fwd_ : nullptr, nullptr, 0.f, nullptr,
+                    /*busy_chip=*/words_.lazy || ents_.lazy);      // long sorts and a long documents-update tail next to it
     }
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);

@@ -14,8 +14,11 @@ namespace cunvsm {
 // out[b][t] = (Σ_j wt[b,j]·table[idx[b,j]][t]) / window     — divides by window even when weighted.
 // =============================================================================================
 // LAZY: the table decays lazily (kernels.h LazyView): a gathered row first gets the factors of the updates it sat out.
+// U rows of the window are in flight per lane: their ids first, then the rows (and stamps) — a plain loop over the window
+// compiles to id load → wait → row load → wait per word (twenty dependent round trips for a window of ten: 64 us where
+// the bytes would take 45). The sum still runs over the window in order, one fused multiply-add per word.
 struct NoLazyView { const int* stamp; int now; float decay[1]; };      // the eager kernel carries no 0.5 KB of factors
-template <int V, bool LAZY>
+template <int V, bool LAZY, int U>
 __global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restrict__ table, int dim,
                                                           const int* __restrict__ idx,
                                                           const float* __restrict__ wts, int window,
@@ -36,20 +39,33 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restric
         for (int i = 0; i < V; ++i) acc[i] = 0.f;
         const int* ip = idx + static_cast<size_t>(b) * window;
         const float* wp = wts ? wts + static_cast<size_t>(b) * window : nullptr;
-        for (int j = 0; j < window; ++j) {
-            const size_t row = static_cast<size_t>(ip[j]);
-            const float wt = wp ? wp[j] : 1.f;
-            float x[V];
-            ldv<V>(table + row * dim + c, x);
-            if (LAZY) {
-                for (int u = lazy.stamp[row]; u < lazy.now; ++u) {
-                    const float d = hist[u % kLazyHistory];
+        for (int j0 = 0; j0 < window; j0 += U) {
+            size_t row[U]; float wt[U], x[U][V]; int st[U];
 #pragma unroll
-                    for (int i = 0; i < V; ++i) x[i] *= d;
-                }
+            for (int u = 0; u < U; ++u) {
+                const int j = min(j0 + u, window - 1);           // (past the window: a harmless re-read, not added)
+                row[u] = static_cast<size_t>(ip[j]);
+                wt[u] = wp ? wp[j] : 1.f;
             }
 #pragma unroll
-            for (int i = 0; i < V; ++i) acc[i] += wt * x[i];
+            for (int u = 0; u < U; ++u) {
+                ldv<V>(table + row[u] * dim + c, x[u]);
+                st[u] = LAZY ? lazy.stamp[row[u]] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j0 + u < window) {
+                    if (LAZY) {
+                        for (int k = st[u]; k < lazy.now; ++k) {
+                            const float d = hist[k % kLazyHistory];
+#pragma unroll
+                            for (int i = 0; i < V; ++i) x[u][i] *= d;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[i] += wt[u] * x[u][i];
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[i] = acc[i] / fw;
@@ -57,24 +73,37 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restric
     }
 }
 
+// rows in flight per lane: the whole window up to ten words, eight at a time beyond
+int window_unroll(int window) { return window <= 10 ? (window < 1 ? 1 : window) : 8; }
+
+template <int V, bool LAZY, typename View>
+static void gather_mean_dispatch(int U, dim3 grid, hipStream_t s, const float* table, int dim, const int* idx, const float* wts,
+                                 int window, uint32_t total, uint32_t nvec, float* out, const View& view) {
+#define NVSM_GATHER_CASE(N) case N: hipLaunchKernelGGL((gather_mean_kernel<V, LAZY, N>), grid, dim3(256), 0, s, table, dim, idx, wts, \
+                                                       window, total, nvec, out, view); break;
+    switch (U) {
+        NVSM_GATHER_CASE(1) NVSM_GATHER_CASE(2) NVSM_GATHER_CASE(3) NVSM_GATHER_CASE(4) NVSM_GATHER_CASE(5)
+        NVSM_GATHER_CASE(6) NVSM_GATHER_CASE(7) NVSM_GATHER_CASE(8) NVSM_GATHER_CASE(9) NVSM_GATHER_CASE(10)
+        default: break;
+    }
+#undef NVSM_GATHER_CASE
+}
+
 void launch_gather_mean(const float* table, int dim, const int* idx, const float* wts, int window,
                         int64_t num_out, float* out, hipStream_t s, const LazyView* lazy) {
     if (num_out <= 0) return;
     const bool lz = lazy && lazy->stamp;
-    if (dim % 4 == 0) {
-        const uint32_t nvec = dim / 4;
-        const uint32_t total = static_cast<uint32_t>(num_out * nvec);
-        if (lz) hipLaunchKernelGGL((gather_mean_kernel<4, true>), dim3(stream_grid(total, 256)), dim3(256), 0, s,
-                                   table, dim, idx, wts, window, total, nvec, out, *lazy);
-        else hipLaunchKernelGGL((gather_mean_kernel<4, false>), dim3(stream_grid(total, 256)), dim3(256), 0, s,
-                                table, dim, idx, wts, window, total, nvec, out, NoLazyView{});
+    const int U = window_unroll(window);
+    const bool vec = dim % 4 == 0;
+    const uint32_t nvec = vec ? dim / 4 : dim;
+    const uint32_t total = static_cast<uint32_t>(num_out * nvec);
+    const dim3 grid(stream_grid(total, 256));
+    if (vec) {
+        if (lz) gather_mean_dispatch<4, true>(U, grid, s, table, dim, idx, wts, window, total, nvec, out, *lazy);
+        else gather_mean_dispatch<4, false>(U, grid, s, table, dim, idx, wts, window, total, nvec, out, NoLazyView{});
     } else {
-        const uint32_t nvec = dim;
-        const uint32_t total = static_cast<uint32_t>(num_out * nvec);
-        if (lz) hipLaunchKernelGGL((gather_mean_kernel<1, true>), dim3(stream_grid(total, 256)), dim3(256), 0, s,
-                                   table, dim, idx, wts, window, total, nvec, out, *lazy);
-        else hipLaunchKernelGGL((gather_mean_kernel<1, false>), dim3(stream_grid(total, 256)), dim3(256), 0, s,
-                                table, dim, idx, wts, window, total, nvec, out, NoLazyView{});
+        if (lz) gather_mean_dispatch<1, true>(U, grid, s, table, dim, idx, wts, window, total, nvec, out, *lazy);
+        else gather_mean_dispatch<1, false>(U, grid, s, table, dim, idx, wts, window, total, nvec, out, NoLazyView{});
     }
 }
 

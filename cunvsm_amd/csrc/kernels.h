@@ -22,6 +22,8 @@ struct LazyView {
 void launch_gather_mean(const float* table, int dim, const int* idx, const float* wts, int window,
                         int64_t num_out, float* out, hipStream_t s, const LazyView* lazy = nullptr);
 
+int window_unroll(int window);      // rows of a window in flight per lane in the window-major gathers (gather-mean, adam_u)
+
 // ---- fp32 MFMA GEMM (F5, B6, B7; replaces the cuBLAS calls at cpp/params.cu:417,528, objective.cu:453)
 // C[M][N] = alpha * A·B (+ bias[n]).  a_layout 0: A is [M][K] (lda); 1: A is stored [K][M] (lda).
 //                                      b_layout 0: B is [K][N] (ldb); 1: B is stored [N][K] (ldb).

@@ -1150,10 +1150,11 @@ void launch_adagrad_scale(const float* acc, const int* idx, int window, int64_t 
 }
 
 // U[b] = bc · mean_j m[idx[b,j]] / (sqrt(mean_j v[idx[b,j]]) + ε)      (adam_sparse_update_kernel, cpp/updates_adam.cu:132-151)
-template <int V>
+// (U rows of the window in flight per lane, ids first — see gather_mean_kernel; sums in window order)
+template <int V, int U>
 __global__ __launch_bounds__(256) void adam_u_kernel(const float* __restrict__ m, const float* __restrict__ v, int dim,
                                                      const int* __restrict__ idx, int window, uint32_t total, uint32_t nvec,
-                                                     float bc, float eps, float* __restrict__ U) {
+                                                     float bc, float eps, float* __restrict__ Uout) {
     const float fw = static_cast<float>(window);
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
         const uint32_t b = q / nvec;
@@ -1163,31 +1164,47 @@ __global__ __launch_bounds__(256) void adam_u_kernel(const float* __restrict__ m
 #pragma unroll
         for (int i = 0; i < V; ++i) am[i] = 0.f;
         float av = 0.f;
-        for (int j = 0; j < window; ++j) {
-            const size_t row = static_cast<size_t>(ip[j]);
-            float x[V];
-            ldv<V>(m + row * dim + c, x);
+        for (int j0 = 0; j0 < window; j0 += U) {
+            size_t row[U]; float x[U][V], vv[U];
 #pragma unroll
-            for (int i = 0; i < V; ++i) am[i] += x[i];
-            av += v[row];
+            for (int u = 0; u < U; ++u) row[u] = static_cast<size_t>(ip[min(j0 + u, window - 1)]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { ldv<V>(m + row[u] * dim + c, x[u]); vv[u] = v[row[u]]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j0 + u < window) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) am[i] += x[u][i];
+                    av += vv[u];
+                }
+            }
         }
         av /= fw;
         const float denom = sqrtf(av) + eps;
 #pragma unroll
         for (int i = 0; i < V; ++i) am[i] = bc * (am[i] / fw) / denom;
-        stv<V>(U + static_cast<size_t>(b) * dim + c, am);
+        stv<V>(Uout + static_cast<size_t>(b) * dim + c, am);
     }
+}
+template <int V>
+static void adam_u_dispatch(int U, dim3 grid, hipStream_t s, const float* m, const float* v, int dim, const int* idx, int window,
+                            uint32_t total, uint32_t nvec, float bc, float eps, float* Uout) {
+#define NVSM_ADAMU_CASE(N) case N: hipLaunchKernelGGL((adam_u_kernel<V, N>), grid, dim3(256), 0, s, m, v, dim, idx, window, total, nvec, bc, eps, Uout); break;
+    switch (U) {
+        NVSM_ADAMU_CASE(1) NVSM_ADAMU_CASE(2) NVSM_ADAMU_CASE(3) NVSM_ADAMU_CASE(4) NVSM_ADAMU_CASE(5)
+        NVSM_ADAMU_CASE(6) NVSM_ADAMU_CASE(7) NVSM_ADAMU_CASE(8) NVSM_ADAMU_CASE(9) NVSM_ADAMU_CASE(10)
+        default: break;
+    }
+#undef NVSM_ADAMU_CASE
 }
 void launch_adam_u(const float* m, const float* v, int dim, const int* idx, int window, int64_t B, float bc, float eps,
                    float* U, hipStream_t s) {
     if (B <= 0) return;
-    if (dim % 4 == 0) {
-        const uint32_t nvec = dim / 4, total = static_cast<uint32_t>(B * nvec);
-        hipLaunchKernelGGL(adam_u_kernel<4>, dim3(stream_grid(total, 256)), dim3(256), 0, s, m, v, dim, idx, window, total, nvec, bc, eps, U);
-    } else {
-        const uint32_t nvec = dim, total = static_cast<uint32_t>(B * nvec);
-        hipLaunchKernelGGL(adam_u_kernel<1>, dim3(stream_grid(total, 256)), dim3(256), 0, s, m, v, dim, idx, window, total, nvec, bc, eps, U);
-    }
+    const bool vec = dim % 4 == 0;
+    const uint32_t nvec = vec ? dim / 4 : dim, total = static_cast<uint32_t>(B * nvec);
+    const dim3 grid(stream_grid(total, 256));
+    if (vec) adam_u_dispatch<4>(window_unroll(window), grid, s, m, v, dim, idx, window, total, nvec, bc, eps, U);
+    else adam_u_dispatch<1>(window_unroll(window), grid, s, m, v, dim, idx, window, total, nvec, bc, eps, U);
 }
 
 // =============================================================================================

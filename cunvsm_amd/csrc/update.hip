@@ -1137,10 +1137,19 @@ void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
 // scale[b] = 1 / sqrt(mean_j acc[idx[b,j]] + ε)      (adagrad_update_kernel, cpp/updates_adagrad.cu:83-97)
 __global__ void adagrad_scale_kernel(const float* __restrict__ acc, const int* __restrict__ idx, int window, int64_t B,
                                      float eps, float* __restrict__ scale) {
+    constexpr int U = 4;      // ids, then accumulators, four in flight (summed in window order)
     for (int64_t b = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; b < B;
          b += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         float s = 0.f;
-        for (int j = 0; j < window; ++j) s += acc[idx[b * window + j]];
+        for (int j0 = 0; j0 < window; j0 += U) {
+            int r[U]; float a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = idx[b * window + min(j0 + u, window - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u] = acc[r[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (j0 + u < window) s += a[u];
+        }
         s /= static_cast<float>(window);
         scale[b] = 1.f / sqrtf(s + eps);
     }

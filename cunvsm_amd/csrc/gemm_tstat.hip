@@ -260,6 +260,14 @@ __global__ __launch_bounds__(kTstatThreads) void gemm_tstat_kernel(TstatArgs g) 
     };
     float4 a[KG];
     if (total > 0) tstat_load_a<KG, 0, H>(g, task_rb(0), li, q, a);
+    // The two waves of a SIMD (w and w + 4) otherwise run the same instruction stream in step — both in their MFMA range,
+    // then both in their epilogue and load waits with the matrix pipe idle: the second one starts a few microseconds late
+    // (harness, alone: forward 86.8 -> 77.7 us, backward 93.9 -> 85 us; the forward product gains with any offset at all,
+    // the backward one up to about five microseconds).
+    if (w >= 4) {
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     // one loop per block shape (each with a fixed number of loads and stores per iteration, see tstat_block)
     if (!MIXED || nt == NT) {
         for (int t = 0; t < full; ++t)

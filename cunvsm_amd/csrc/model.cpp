@@ -593,9 +593,12 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // about to rewrite: the main stream must be behind them. In steady state both are long finished (update() / step()
     // joined them before the row passes), so the waits cost nothing; they matter for compute_cost; compute_cost without
     // an update in between and for the documents build, which step() never joins on the main stream.
+    // (A wait is a packet the main stream stops at for several microseconds even when the event has long fired: the fused
+    //  step joins both builds in one place, in front of the words update, and nothing is waited for here then.)
     if (inputs_recorded_) {
-        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
-        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
+        if (!csr_joined_ents_) NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
+        if (!csr_joined_words_) NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
+        csr_joined_ents_ = csr_joined_words_ = true;
     }
 
     // device-sampler mode: zeroing the statistics, narrowing the word ids and drawing the document ids are one launch
@@ -697,6 +700,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         NVSM_HIP_CHECK(hipStreamWaitEvent(sw, after, 0));
         // (the documents table has two sets of CSR arrays: its build does not wait for the previous documents update)
         if (se != aux_stream_ && E_pending_ && ents_.idx_sets < 2) NVSM_HIP_CHECK(hipStreamWaitEvent(se, ev_E_done_, 0));
+        csr_joined_ents_ = csr_joined_words_ = false;
         auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, ids_.p, N, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
         auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, widx_.p, B * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
         if (layout == 1) { wrds(); ents(); } else { ents(); wrds(); }
@@ -1171,6 +1175,7 @@ void Model::update(float lr, float scaled_lambda) {
     RangeScope range_up("UpdateParameters");            // cpp/main.cu:429
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));     // join the side-stream CSR builds
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
+    csr_joined_ents_ = csr_joined_words_ = true;
     update_entities(lr, scaled_lambda, stream_);
     update_words(lr, scaled_lambda);
     update_transform(lr, scaled_lambda, stream_);
@@ -1241,6 +1246,10 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         T_pending_ = true;
     }
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
+    // (the documents build too — finished long ago, its update is running —, so that the next step's prologue, which
+    //  rewrites the ids both builds read, does not have to stop for either)
+    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
+    csr_joined_ents_ = csr_joined_words_ = true;
     update_words(lr, sl);
     if (docs_on_main == 2) {
         NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));

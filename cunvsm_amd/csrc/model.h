@@ -224,6 +224,7 @@ class Model {
     bool E_pending_ = false, T_pending_ = false;      // side-stream tails of the last nvsm_step not yet joined
     DevBuf<float> phrase_, pre_, proj_, dy_, gphrase_, coef_, probs_, pp_, msq_w_, msq_parts_, U_, scale_w_, grad_entity_;
     DevBuf<double> stats_;                   // [2 de | 1 + 2 de] = Σx Σx² | loss Σdy Σdy·x̂ — cleared by one memset per step
+    bool csr_joined_words_ = true, csr_joined_ents_ = true;      // the main stream is behind the current CSR builds
     double* stats_fwd_ = nullptr;
     double* stats_bwd_ = nullptr;
     DevBuf<float> bn_mean_, bn_inv_std_, dbeta_, dgamma_;

@@ -457,6 +457,7 @@ void Model::initialize_from_rng_state() {
     glorot(ents_.P, cfg_.entity_repr_size, cfg_.num_entities);
     glorot(T_, cfg_.entity_repr_size, cfg_.word_repr_size);
     NVSM_HIP_CHECK(hipMemset(b_.p, 0, b_.n * sizeof(float)));                                   // params.cu:368-369
+    NVSM_HIP_CHECK(hipStreamSynchronize(nullptr));      // (queued on the null stream, which the handle's streams do not wait for)
 }
 
 uint64_t Model::rng_get_state() { std::stringstream ss; ss << rng_; uint64_t s; ss >> s; return s; }

@@ -4,6 +4,7 @@
 // compute_gradients / update / get_cost, same argument meaning.
 #pragma once
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -31,6 +32,8 @@ struct Error : std::runtime_error {
             throw ::cunvsm::Error(NVSM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+inline bool devbuf_poison() { const char* e = std::getenv("NVSM_POISON"); return e && e[0] == '1'; }
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -44,7 +47,14 @@ struct DevBuf {
         n = count;
         if (count == 0) return;
         NVSM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
-        if (zero) NVSM_HIP_CHECK(hipMemset(p, 0, count * sizeof(T)));
+        // NVSM_POISON=1 (tests): buffers that are not cleared start as 0xFF bytes (NaN floats, -1 ints) instead of whatever
+        // the allocator hands back — a kernel that reads one before it is written shows up at once
+        if (!zero && !devbuf_poison()) return;
+        NVSM_HIP_CHECK(hipMemset(p, zero ? 0 : 0xFF, count * sizeof(T)));
+        // hipMemset of device memory returns once the fill is queued on the null stream, and the handle's streams are
+        // non-blocking (no implicit order with the null stream): without this wait a kernel of the handle could read the
+        // buffer before it was cleared (seen as a memory fault of lazy_refresh_kernel on a recycled, not yet zeroed stamp array)
+        NVSM_HIP_CHECK(hipStreamSynchronize(nullptr));
     }
     void release() {
         if (p) (void)hipFree(p);

@@ -823,7 +823,9 @@ __global__ __launch_bounds__(256) void lazy_refresh_kernel(LazyRefreshArgs a) {
     const int64_t limit = a.list ? static_cast<int64_t>(*a.list_count) : a.rows;
     for (int64_t it = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; it < limit; it += waves) {
         const int64_t row = a.list ? static_cast<int64_t>(a.list[it]) : it;
-        const int from = a.stamp[row];
+        // (wave-uniform, in a scalar register: the factor below is then a scalar load from the kernel arguments instead of a
+        //  per-lane index into a private copy of the array; never further back than the history reaches)
+        const int from = max(__builtin_amdgcn_readfirstlane(a.stamp[row]), a.now - kLazyHistory);
         if (from != a.now) {
             for (int c = lane * V; c < a.dim; c += 64 * V) {
                 const size_t off = static_cast<size_t>(row) * a.dim + c;

@@ -424,7 +424,7 @@ __global__ void sum_parts_kernel(const float* __restrict__ parts, int nparts, in
     }
 }
 void launch_sum_parts(const float* parts, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(sum_parts_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, parts, nparts, stride, out, n);
+    if (n > 0) NVSM_LAUNCH(sum_parts_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, parts, nparts, stride, out, n);
 }
 
 int gemm_split_k_slabs(int K, int want) {
@@ -647,7 +647,7 @@ void launch_step_prologue(const int64_t* words64, int* widx, int64_t nW, const i
     int grid = stream_grid(N > nW ? N : nW, 256);
     const int need = (nstats + 255) / 256;
     if (grid < need) grid = need;
-    hipLaunchKernelGGL(step_prologue_kernel, dim3(grid), dim3(256), 0, s, words64, widx, nW, labels, N, R,
+    NVSM_LAUNCH(step_prologue_kernel, dim3(grid), dim3(256), 0, s, words64, widx, nW, labels, N, R,
                        static_cast<uint64_t>(num_words), static_cast<uint64_t>(num_entities), seed, step, ids, stats, nstats,
                        err_flag);
 }

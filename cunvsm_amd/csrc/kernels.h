@@ -4,9 +4,25 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace cunvsm {
+
+// An event recorded behind a kernel is a packet of its own which the stream's next kernel waits for: a bubble of 6-10 us
+// per record on the step's critical stream. A kernel launched through NVSM_LAUNCH right after set_stop_event(ev) carries
+// `ev` as its own completion event instead (hipExtLaunchKernelGGL's stopEvent): same meaning for whoever waits on `ev`,
+// no packet between the kernel and its successor. take_stop_event() hands the pending event to the launch (or back to
+// the caller, who records it the plain way when the launcher launched nothing). Per host thread.
+void set_stop_event(hipEvent_t ev);
+hipEvent_t take_stop_event();
+#define NVSM_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                       \
+    do {                                                                                                          \
+        if (hipEvent_t _stop = ::cunvsm::take_stop_event())                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, _stop, 0, __VA_ARGS__);            \
+        else                                                                                                      \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                  \
+    } while (0)
 
 // How a reader brings the rows of a lazily decayed table up to date while it gathers them (see "lazy dense decay" below):
 // row r has had `stamp[r]` updates applied, the table `now`; the factors of the updates in between are applied to the

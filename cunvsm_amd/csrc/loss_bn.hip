@@ -34,7 +34,7 @@ __global__ void colsum_finalize_kernel(const double* __restrict__ sums, int dim,
 }
 
 void launch_colsum_finalize(const double* sums, int dim, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, s, sums, dim, out);
+    NVSM_LAUNCH(colsum_finalize_kernel, dim3(ceil_div(dim, 256)), dim3(256), 0, s, sums, dim, out);
 }
 
 // dx = invσ · (dy − (dβ + x̂·dγ) / N)       (= invσ/N · (N·dy − dβ − x̂·dγ), cuDNN per-activation backward)
@@ -78,11 +78,11 @@ void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* i
     const float inv_n = static_cast<float>(1.0 / n_global);
     if (dim % 4 == 0) {
         const uint32_t nvec = dim / 4, total = static_cast<uint32_t>(rows * nvec);
-        hipLaunchKernelGGL(bn_dx_kernel<4>, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, pre, mean, inv_std,
+        NVSM_LAUNCH(bn_dx_kernel<4>, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, pre, mean, inv_std,
                            sums, dbeta, dgamma, grad_bias, inv_n, total, nvec, dim);
     } else {
         const uint32_t nvec = dim, total = static_cast<uint32_t>(rows * nvec);
-        hipLaunchKernelGGL(bn_dx_kernel<1>, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, pre, mean, inv_std,
+        NVSM_LAUNCH(bn_dx_kernel<1>, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, pre, mean, inv_std,
                            sums, dbeta, dgamma, grad_bias, inv_n, total, nvec, dim);
     }
 }
@@ -484,8 +484,8 @@ template <int V, int NITER>
 static void launch_loss_t(const LossArgs& a, hipStream_t s) {
     const int grid = ceil_div(a.B, 4 * kExamplesPerWave);
     const size_t shmem = (8 * static_cast<size_t>(a.de) + 4) * sizeof(float);
-    if (a.l2_entity) hipLaunchKernelGGL((loss_kernel<V, NITER, true>), dim3(grid), dim3(256), shmem, s, a);
-    else hipLaunchKernelGGL((loss_kernel<V, NITER, false>), dim3(grid), dim3(256), shmem, s, a);
+    if (a.l2_entity) NVSM_LAUNCH((loss_kernel<V, NITER, true>), dim3(grid), dim3(256), shmem, s, a);
+    else NVSM_LAUNCH((loss_kernel<V, NITER, false>), dim3(grid), dim3(256), shmem, s, a);
 }
 
 template <int RB>
@@ -499,8 +499,8 @@ static void launch_loss_rows(const LossArgs& a, hipStream_t s) {
     if (epw_env > 0) epw = epw_env;
     const int grid = ceil_div(a.B, 4 * epw);
     const size_t shmem = (8 * static_cast<size_t>(a.de) + 4) * sizeof(float);
-    if (a.lazyE.stamp) hipLaunchKernelGGL((loss_rows_kernel<RB, true>), dim3(grid), dim3(256), shmem, s, a, epw);
-    else hipLaunchKernelGGL((loss_rows_kernel<RB, false>), dim3(grid), dim3(256), shmem, s, a, epw);
+    if (a.lazyE.stamp) NVSM_LAUNCH((loss_rows_kernel<RB, true>), dim3(grid), dim3(256), shmem, s, a, epw);
+    else NVSM_LAUNCH((loss_rows_kernel<RB, false>), dim3(grid), dim3(256), shmem, s, a, epw);
 }
 
 bool loss_reads_lazily(int de, int R, bool l2_entity) { return de % 4 == 0 && de <= 256 && R <= 64 && !l2_entity; }

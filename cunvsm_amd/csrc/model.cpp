@@ -207,6 +207,21 @@ struct ProfScope {
 #define PROF(name) ProfScope _prof_scope(prof, name, stream_)
 #define PROF_ON(name, strm) ProfScope _prof_scope(prof, name, strm)
 
+// kernels.h: the event the next NVSM_LAUNCH of this host thread carries as its completion event
+static thread_local hipEvent_t tl_stop_event = nullptr;
+void set_stop_event(hipEvent_t ev) { tl_stop_event = ev; }
+hipEvent_t take_stop_event() { hipEvent_t e = tl_stop_event; tl_stop_event = nullptr; return e; }
+// `launch` enqueues ONE kernel on `s` through NVSM_LAUNCH; `ev` then stands for everything queued on `s` up to and including
+// it, exactly as a hipEventRecord behind it would (NVSM_STOP_EVENTS=0: that plain record, for A/B runs)
+template <class F>
+static void launch_and_record(hipEvent_t ev, hipStream_t s, F&& launch) {
+    static const bool bound = [] { const char* e = std::getenv("NVSM_STOP_EVENTS"); return !(e && e[0] == '0'); }();
+    if (bound) set_stop_event(ev);
+    launch();
+    if (!bound) { NVSM_HIP_CHECK(hipEventRecord(ev, s)); return; }
+    if (hipEvent_t left = take_stop_event()) NVSM_HIP_CHECK(hipEventRecord(left, s));      // nothing was launched
+}
+
 // ---------------------------------------------------------------------------------------------
 // NVSM_CHUNK_ORDER=0 (A/B runs): level-1 chunks as numbered instead of in batch order
 static bool chunk_order_enabled() {
@@ -314,11 +329,18 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux3_stream_, hipStreamNonBlocking, aux3_prio == 0 ? lo : (aux3_prio == 2 ? hi : (lo + hi) / 2)));
         copy_stream_ = aux3_stream_;
     }
-    NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, hipEventDisableTiming));
-    NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, hipEventDisableTiming));
-    NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, hipEventDisableTiming));
-    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_copied_, &ev_step_begin_[0], &ev_step_begin_[1],
-                          &ev_host_ids_[0], &ev_host_ids_[1], &ev_gathered_})
+    // Events that only order this device's streams among themselves are made without the system-scope fence of a default
+    // event (hipEventDisableSystemFence: what it gives up — visibility to the host and to other devices — nobody asks of
+    // them; the host-visible results travel behind stream synchronisations and the events of their copies): LSE batch 4096
+    // 0.209 -> 0.203 ms per step, no effect at the NVSM shape. NVSM_EVENT_FENCE=0: default events, 2: device-scope release.
+    static const int ev_fence = [] { const char* e = std::getenv("NVSM_EVENT_FENCE"); return e ? std::atoi(e) : 1; }();
+    const unsigned dev_flags = hipEventDisableTiming | (ev_fence == 1 ? hipEventDisableSystemFence : 0u) | (ev_fence == 2 ? hipEventReleaseToDevice : 0u);
+    NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, dev_flags));
+    NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, dev_flags));
+    NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, dev_flags));
+    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_step_begin_[0], &ev_step_begin_[1], &ev_gathered_, &ev_csr_all_})
+        NVSM_HIP_CHECK(hipEventCreateWithFlags(e, dev_flags));
+    for (hipEvent_t* e : {&ev_copied_, &ev_host_ids_[0], &ev_host_ids_[1]})
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&err_host_), sizeof(int), hipHostMallocDefault));
     *err_host_ = 0;
@@ -362,7 +384,7 @@ Model::~Model() {
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
     for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_, ev_copied_, ev_step_begin_[0], ev_step_begin_[1],
-                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_}) if (e) (void)hipEventDestroy(e);
+                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_, ev_csr_all_}) if (e) (void)hipEventDestroy(e);
     for (int p = 0; p < 2; ++p) if (host_ids_pin_[p]) (void)hipHostFree(host_ids_pin_[p]);
     if (err_host_) (void)hipHostFree(err_host_);
     // (copy_stream_ is side stream 3)
@@ -672,16 +694,19 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             host_ids_used_[hp] = true;
             launch_narrow_i64(in_ids64_.p, ids_.p, N, cfg_.num_entities, err_host_, NVSM_BAD_ENTITY_ID, stream_);
         } else {
-            launch_step_prologue(words_dev, widx_.p, B * w, labels_dev_, B, R_, cfg_.num_words, cfg_.num_entities,
-                                 device_seed_ + 0x9E37u * cfg_.rank, step_count_, ids_.p, stats_.p, static_cast<int>(stats_.n),
-                                 err_host_, stream_);
+            // (the prologue carries "inputs consumed, ids final" as its completion event: no packet between it and the gather)
+            launch_and_record(ev_inputs_, stream_, [&] {
+                launch_step_prologue(words_dev, widx_.p, B * w, labels_dev_, B, R_, cfg_.num_words, cfg_.num_entities,
+                                     device_seed_ + 0x9E37u * cfg_.rank, step_count_, ids_.p, stats_.p, static_cast<int>(stats_.n),
+                                     err_host_, stream_);
+            });
         }
     }
     ++step_count_;
 
     // Row-order (CSR) of both tables for the update, on the side streams: needs only the indices.
     static const int csr_after = [] { const char* e = std::getenv("NVSM_CSR_AFTER"); return e ? std::atoi(e) : 0; }();
-    NVSM_HIP_CHECK(hipEventRecord(ev_inputs_, stream_));
+    if (!fused_prologue) NVSM_HIP_CHECK(hipEventRecord(ev_inputs_, stream_));
     inputs_recorded_ = true;
     // two side streams: the sorts are latency-bound chains of small launches, so the two tables' builds run next to
     // each other (at batch 4096 one behind the other they were the longest chain of the whole step)
@@ -705,6 +730,10 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, ids_.p, N, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
         auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, widx_.p, B * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
         if (layout == 1) { wrds(); ents(); } else { ents(); wrds(); }
+        // one event for "both builds done", made on a side stream (where a wait costs nothing that matters): the fused step's
+        // main stream then stops at one wait packet in front of the words update instead of two
+        if (se != sw) NVSM_HIP_CHECK(hipStreamWaitEvent(sw, ev_csr_ents_, 0));
+        NVSM_HIP_CHECK(hipEventRecord(ev_csr_all_, sw));
         if (se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
     };
     const bool any_lazy = words_.lazy || ents_.lazy;
@@ -789,7 +818,9 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
                 lazy_refresh(ents_, &ce, stream_);
             }
         }
-        launch_loss(a, stream_);
+        // (the fused step at small batches starts the documents update behind the loss kernel: ev_loss_ rides on the kernel)
+        if (loss_stop_event_) { launch_and_record(loss_stop_event_, stream_, [&] { launch_loss(a, stream_); }); loss_stop_event_ = nullptr; }
+        else launch_loss(a, stream_);
     }
     if (csr_after == 3 && !csr_first) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     NVSM_HIP_CHECK(hipGetLastError());      // a failed launch of any kernel above surfaces here, not at the next sync
@@ -832,24 +863,33 @@ void Model::backward_dx() {
     // B5: bias gradient / BN backward (params.cu:509-521)
     {
         PROF("bn_backward");
+        // dx is final behind the last kernel of this block: the dT GEMM of the fused step may start (ev_dx_ rides on that
+        // kernel as its completion event)
+        auto dx_final = [&](auto&& launch) { launch_and_record(ev_dx_, stream_, launch); };
+        auto bn_dx = [&](double n) {
+            launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, stats_bwd_ + 1, dbeta_.p, dgamma_.p, gb_.p, n, B, de, stream_);
+        };
+        auto colsum = [&] { launch_colsum_finalize(stats_bwd_ + 1, de, gb_.p, stream_); };
         if (cfg_.batch_normalization) {
             if (dp && cfg_.sync_batch_norm) {
                 allreduce_f64(stats_bwd_, 1 + 2 * de);
-                launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, stats_bwd_ + 1, dbeta_.p, dgamma_.p, gb_.p, B_global, B, de, stream_);
+                dx_final([&] { bn_dx(B_global); });
+            } else if (dp) {
+                bn_dx(static_cast<double>(B));
+                allreduce_f64(stats_bwd_, 1 + 2 * de);
+                dx_final(colsum);
             } else {
-                launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, stats_bwd_ + 1, dbeta_.p, dgamma_.p, gb_.p, static_cast<double>(B), B, de, stream_);
-                if (dp) { allreduce_f64(stats_bwd_, 1 + 2 * de); launch_colsum_finalize(stats_bwd_ + 1, de, gb_.p, stream_); }
+                dx_final([&] { bn_dx(static_cast<double>(B)); });
             }
         } else {
             if (dp) allreduce_f64(stats_bwd_, 1 + de);
-            launch_colsum_finalize(stats_bwd_ + 1, de, gb_.p, stream_);
+            dx_final(colsum);
         }
     }
     // B7 + B9: gphrase[B][dw] = dx[B][de] · T (stored [dw][de]) / w   (objective.cu:447-476)
     {
         PROF("gemm_bwd_x");
         const float inv_w = static_cast<float>(std::exp(-std::log(static_cast<double>(w))));
-        NVSM_HIP_CHECK(hipEventRecord(ev_dx_, stream_));        // dx is final: the dT GEMM may start (fused step)
         // the words update of Adam (sparse / dense_update) and Adagrad needs mean_t(gphrase[b][t]²) per window
         // (cpp/updates_adam.cu:232-240, updates_adagrad.cu:136-143): emitted by the GEMM epilogue, per 128-column tile
         const bool need_msq = cfg_.update_method == NVSM_ADAGRAD ||
@@ -860,11 +900,16 @@ void Model::backward_dx() {
         int msq_parts = 0;
         launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, l2p ? 1.f : inv_w, nullptr, 1, 0, stream_,
                     nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw, &msq_parts);
-        if (l2p)        // Normalizer::backward, then the division by the window (objective.cu:461-476); mean of squares of the result
+        // ev_bwdx_: the dx GEMM, the last reader of T before its update, is through (and gphrase / its row statistics final)
+        if (l2p) {      // Normalizer::backward, then the division by the window (objective.cu:461-476); mean of squares of the result
             launch_l2_rows_backward(gphrase_.p, phrase_raw_.p, phrase_norms_.p, B, dw, inv_w, gphrase_.p,
                                     need_msq ? msq_w_.p : nullptr, stream_);
-        else if (need_msq) launch_sum_parts(msq_parts_.p, msq_parts, B, msq_w_.p, B, stream_);
-        NVSM_HIP_CHECK(hipEventRecord(ev_bwdx_, stream_));      // last reader of T before its update
+            NVSM_HIP_CHECK(hipEventRecord(ev_bwdx_, stream_));
+        } else if (need_msq) {
+            launch_and_record(ev_bwdx_, stream_, [&] { launch_sum_parts(msq_parts_.p, msq_parts, B, msq_w_.p, B, stream_); });
+        } else {
+            NVSM_HIP_CHECK(hipEventRecord(ev_bwdx_, stream_));
+        }
     }
     if (dp) loss_reduced_ = true;
 }
@@ -1193,7 +1238,13 @@ void Model::update(float lr, float scaled_lambda) {
 // and the two side-stream tails are joined by the NEXT compute_cost where it needs T and E (join_T / join_E), not here.
 // Results are identical to compute_cost; compute_gradients; update — only the interleaving differs.
 void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, float* cost) {
-    compute_cost(batch, entity_ids);
+    static const bool fewer_events = [] { const char* e = std::getenv("NVSM_FEWER_EVENTS"); return !(e && e[0] == '0'); }();
+    static const int docs_after_dx_env = [] { const char* e = std::getenv("NVSM_DOCS_AFTER_DX"); return e ? std::atoi(e) : -1; }();
+    const bool docs_after_dx = docs_after_dx_env >= 0 ? docs_after_dx_env != 0 : batch.num_instances >= 16384;
+    const bool loss_event = !(docs_after_dx && fewer_events);      // (see below)
+    loss_stop_event_ = loss_event ? ev_loss_ : nullptr;
+    try { compute_cost(batch, entity_ids); } catch (...) { loss_stop_event_ = nullptr; throw; }
+    loss_stop_event_ = nullptr;
     const float sl = scaled_regularization_lambda();
     if (lr < 0.f || sl < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");
     // Data parallel: the dT GEMM, the all-reduce of the projection gradient and the projection update ride on side stream 2
@@ -1204,21 +1255,14 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     static const bool t_on_main = std::getenv("NVSM_DP_T_ON_MAIN") != nullptr;
     const bool dp = cfg_.world_size > 1 && t_on_main;
     RangeScope range_bu("ComputeGradients+UpdateParameters");      // cpp/main.cu:414,429 — one interleaved region here
-    static const bool fewer_events = [] { const char* e = std::getenv("NVSM_FEWER_EVENTS"); return !(e && e[0] == '0'); }();
     // ... but only once the dx GEMM is through at large batches: next to the MFMA-bound GEMM the row pass (100 k short-lived
     // waves) keeps the GEMM's workgroups from becoming resident — measured at B = 51 200: dx GEMM 132 → 203 us, dT GEMM
     // 195 → 402 us, step 1.099 → 1.126 ms. (NVSM_DOCS_AFTER_DX=0/1 overrides.)
-    static const int docs_after_dx_env = [] { const char* e = std::getenv("NVSM_DOCS_AFTER_DX"); return e ? std::atoi(e) : -1; }();
-    const bool docs_after_dx = docs_after_dx_env >= 0 ? docs_after_dx_env != 0 : B_ >= 16384;
     // side stream 1 (behind the documents CSR build): the documents update, HBM-bound — free to run on next to the next
     // step's projection GEMM; the next loss kernel joins it. It needs the loss kernel's outputs; when it is held behind the
     // dx GEMM anyway, that GEMM's event stands for the loss kernel's too (an event recorded between two kernels of the main
     // stream costs the stream a bubble of several microseconds).
-    const bool loss_event = !(docs_after_dx && fewer_events);
-    if (loss_event) {
-        NVSM_HIP_CHECK(hipEventRecord(ev_loss_, stream_));
-        NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_loss_, 0));
-    }
+    if (loss_event) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_loss_, 0));      // (recorded with the loss kernel)
     // NVSM_DOCS_ON_MAIN (experiments): 1 = the documents update on the main stream in front of the words update, 2 = behind
     // it (two HBM-bound passes one after the other instead of next to each other)
     static const int docs_on_main = [] { const char* e = std::getenv("NVSM_DOCS_ON_MAIN"); return e ? std::atoi(e) : 0; }();
@@ -1246,10 +1290,9 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         NVSM_HIP_CHECK(hipEventRecord(ev_T_done_, aux2_stream_));
         T_pending_ = true;
     }
-    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
     // (the documents build too — finished long ago, its update is running —, so that the next step's prologue, which
-    //  rewrites the ids both builds read, does not have to stop for either)
-    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
+    //  rewrites the ids both builds read, does not have to stop for either: ev_csr_all_ stands for both)
+    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_all_, 0));
     csr_joined_ents_ = csr_joined_words_ = true;
     update_words(lr, sl);
     if (docs_on_main == 2) {

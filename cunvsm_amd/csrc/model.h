@@ -198,6 +198,8 @@ class Model {
     // dx GEMM and the words update on the main stream
     hipEvent_t ev_gathered_ = nullptr;
     hipEvent_t ev_loss_ = nullptr, ev_dx_ = nullptr, ev_bwdx_ = nullptr, ev_E_done_ = nullptr, ev_T_done_ = nullptr;
+    hipEvent_t ev_csr_all_ = nullptr;           // both tables' CSR builds of this step are done (recorded on the words build's stream)
+    hipEvent_t loss_stop_event_ = nullptr;      // set by step(): the loss kernel of this compute_cost carries it as its completion event
     std::minstd_rand0 rng_;           // include/cuNVSM/base.h:36
     uint64_t device_seed_ = 1, step_count_ = 0;
 

@@ -126,17 +126,14 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     int pre = 0, tot = 0;
     if (tid < NB) {
         const int G = gridDim.x, me = blockIdx.x;
-        int t = 0;
-        for (; t + 16 <= G; t += 16) {
+        // sixteen loads in flight per turn, the last turn too (slots past G re-read workgroup G - 1 and count as 0): a
+        // one-by-one remainder loop was a chain of up to 15 dependent L2 round trips in a launch that is pure latency
+        for (int t = 0; t < G; t += 16) {
             int c[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) c[u] = counts[(t + u) * kSortMaxBuckets + tid];
+            for (int u = 0; u < 16; ++u) c[u] = counts[min(t + u, G - 1) * kSortMaxBuckets + tid];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { tot += c[u]; pre += (t + u < me) ? c[u] : 0; }
-        }
-        for (; t < G; ++t) {
-            const int c = counts[t * kSortMaxBuckets + tid];
-            tot += c; pre += (t < me) ? c : 0;
+            for (int u = 0; u < 16; ++u) { tot += (t + u < G) ? c[u] : 0; pre += (t + u < me) ? c[u] : 0; }
         }
     }
     // exclusive scan of tot over the digits (tid): wave-inclusive by shuffles, then the wave totals

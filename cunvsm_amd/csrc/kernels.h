@@ -249,8 +249,11 @@ void launch_stamp_rows(const Csr& c, int* stamp, int value, int64_t max_rows, hi
 void launch_lazy_refresh(const LazyRefreshArgs& a, int64_t max_rows, hipStream_t s);
 
 void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
-void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
-void launch_table_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);      // both, in one launch (update.hip)
+// untouched_s: the stream the streaming pass over the rows WITHOUT entries of a split dense pass is queued on (null: `s`).
+// Those rows and the rows with entries are disjoint, so the two launches need no order between them — only the CSR bounds
+// in front of both and the table's next reader behind both.
+void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s, hipStream_t untouched_s = nullptr);
+void launch_table_pass(const Csr& c, const RowPassArgs& a, hipStream_t s, hipStream_t untouched_s = nullptr);      // both, in one launch (update.hip)
 void set_table_pass_one_launch(bool on);      // tests / A-B runs: false = the three-launch form (also NVSM_MERGED_PASS=0)
 
 // words, window > 1 (cpp/updates_adagrad.cu:83-97, cpp/updates_adam.cu:132-151)

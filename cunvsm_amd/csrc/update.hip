@@ -983,7 +983,8 @@ static void untouched_dispatch(const Csr& c, const RowPassArgs& a, int nvec, hip
 #undef NVSM_UNT_CASE
 }
 
-void launch_row_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
+void launch_row_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hipStream_t untouched_s) {
+    if (!untouched_s) untouched_s = s;
     if (c.rows <= 0) return;
     int V, nvec, G;
     group_geometry(a_in.dim, V, nvec, G);
@@ -993,7 +994,7 @@ void launch_row_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
     // Table much larger than the batch (at most one entry per row on average): the rows with entries go through the
     // row pass by list, all the others — if the pass is dense — through the streaming pass.
     if (row_pass_split(c) && kind_is_row_local_when_untouched(a.kind)) {
-        if (a.dense && !a.lazy) { if (V == 4) untouched_dispatch<4>(c, a, nvec, s); else untouched_dispatch<1>(c, a, nvec, s); }
+        if (a.dense && !a.lazy) { if (V == 4) untouched_dispatch<4>(c, a, nvec, untouched_s); else untouched_dispatch<1>(c, a, nvec, untouched_s); }
         a.touched_only = 1;
         a.shallow = c.rows >= c.n;      // at most one entry per row on average
         cc.rows = c.n < c.rows ? c.n : c.rows;      // upper bound of the list length: sizes the grid
@@ -1101,8 +1102,9 @@ static void entry_walk_dispatch(const Csr& c, const RowPassArgs& a, int nvec, hi
 }
 
 // one pass over a table: chunk tree of the long rows + row formula, in one launch (table_pass_kernel)
-void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
-    if (!merged_pass_enabled()) { launch_chunk_pass(c, a_in, s); launch_row_pass(c, a_in, s); return; }
+void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hipStream_t untouched_s) {
+    if (!untouched_s) untouched_s = s;
+    if (!merged_pass_enabled()) { launch_chunk_pass(c, a_in, s); launch_row_pass(c, a_in, s, untouched_s); return; }
     if (c.rows <= 0) return;
     int V, nvec, G;
     group_geometry(a_in.dim, V, nvec, G);
@@ -1110,7 +1112,7 @@ void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s) {
     a.touched_only = 0; a.shallow = 0;
     int64_t row_items = c.rows;
     if (row_pass_split(c) && kind_is_row_local_when_untouched(a.kind)) {      // as launch_row_pass
-        if (a.dense && !a.lazy) { if (V == 4) untouched_dispatch<4>(c, a, nvec, s); else untouched_dispatch<1>(c, a, nvec, s); }
+        if (a.dense && !a.lazy) { if (V == 4) untouched_dispatch<4>(c, a, nvec, untouched_s); else untouched_dispatch<1>(c, a, nvec, untouched_s); }
         a.touched_only = 1;
         a.shallow = c.rows >= c.n;
         row_items = c.n < c.rows ? c.n : c.rows;

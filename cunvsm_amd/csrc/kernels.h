@@ -10,16 +10,19 @@
 namespace cunvsm {
 
 // An event recorded behind a kernel is a packet of its own which the stream's next kernel waits for: a bubble of 6-10 us
-// per record on the step's critical stream. A kernel launched through NVSM_LAUNCH right after set_stop_event(ev) carries
-// `ev` as its own completion event instead (hipExtLaunchKernelGGL's stopEvent): same meaning for whoever waits on `ev`,
-// no packet between the kernel and its successor. take_stop_event() hands the pending event to the launch (or back to
-// the caller, who records it the plain way when the launcher launched nothing). Per host thread.
-void set_stop_event(hipEvent_t ev);
-hipEvent_t take_stop_event();
+// per record on the step's critical stream. A kernel launched through NVSM_LAUNCH right after set_launch_events(start, stop)
+// carries them as its own start / completion events instead (hipExtLaunchKernelGGL): `stop` means the same for whoever waits
+// on it as a record behind the kernel, and a (start, stop) pair made with timing brackets exactly the kernel's execution —
+// no packet between the kernel and its neighbours either way. take_launch_events() hands the pending events to the launch
+// (or back to the caller, who records them the plain way when the launcher launched nothing). Per host thread.
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
+hipEvent_t take_launch_events(hipEvent_t* start);      // returns the stop event
 #define NVSM_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                       \
     do {                                                                                                          \
-        if (hipEvent_t _stop = ::cunvsm::take_stop_event())                                                       \
-            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, _stop, 0, __VA_ARGS__);            \
+        hipEvent_t _start = nullptr;                                                                              \
+        hipEvent_t _stop = ::cunvsm::take_launch_events(&_start);                                                 \
+        if (_stop || _start)                                                                                      \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, _start, _stop, 0, __VA_ARGS__);             \
         else                                                                                                      \
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                  \
     } while (0)

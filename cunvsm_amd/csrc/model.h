@@ -73,6 +73,11 @@ class Profiler {
     std::string only;          // when not empty, only these kernel groups (comma-separated) are timed (a few events per step instead of ~50)
     void begin(const char* name, hipStream_t s);
     void end(hipStream_t s);
+    // the next event pair of group `name`, NOT recorded: the caller hands it to a single launch as that kernel's start / stop
+    // events (kernels.h set_launch_events) — the group's time is then the kernel's own execution time, and nothing is queued
+    // in front of or behind the kernel. false: the group is not being timed.
+    bool bind(const char* name, hipEvent_t* start, hipEvent_t* stop);
+    bool selected(const char* name) const;
     void reset();
     std::vector<std::string> names() const;
     bool get(const std::string& name, double* ms, int64_t* launches);

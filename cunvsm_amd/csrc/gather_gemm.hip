@@ -585,6 +585,34 @@ void launch_scale(float* x, int64_t n, float a, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, x, n, a);
 }
 
+// 16 B per lane and turn, four turns in flight: enough outstanding reads to fill the PCIe link from a few dozen workgroups
+__global__ __launch_bounds__(256) void host_pull_kernel(HostPull p) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (int a = 0; a < p.count; ++a) {
+        const size_t n16 = p.bytes[a] / 16;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* __restrict__ src = static_cast<const u32x4*>(p.src[a]);
+        u32x4* __restrict__ dst = static_cast<u32x4*>(p.dst[a]);
+        size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+        for (; i + 3 * stride < n16; i += 4 * stride) {
+            const u32x4 v0 = __builtin_nontemporal_load(src + i), v1 = __builtin_nontemporal_load(src + i + stride);
+            const u32x4 v2 = __builtin_nontemporal_load(src + i + 2 * stride), v3 = __builtin_nontemporal_load(src + i + 3 * stride);
+            dst[i] = v0; dst[i + stride] = v1; dst[i + 2 * stride] = v2; dst[i + 3 * stride] = v3;
+        }
+        for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+        // tail of fewer than 16 bytes (sizes are multiples of 4)
+        const size_t done = n16 * 16, rest = (p.bytes[a] - done) / 4;
+        if (blockIdx.x == 0 && threadIdx.x < rest)
+            reinterpret_cast<uint32_t*>(static_cast<char*>(p.dst[a]) + done)[threadIdx.x] =
+                reinterpret_cast<const uint32_t*>(static_cast<const char*>(p.src[a]) + done)[threadIdx.x];
+    }
+}
+void launch_host_pull(const HostPull& p, hipStream_t s) {
+    if (p.count <= 0) return;
+    static const int blocks = [] { const char* e = std::getenv("NVSM_PULL_BLOCKS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 8; }();      // (4-8 workgroups saturate the link; more only take wave slots from the step: 64 -> 8: 1.12 -> 1.075 ms)
+    hipLaunchKernelGGL(host_pull_kernel, dim3(blocks), dim3(256), 0, s, p);
+}
+
 __global__ void delay_kernel(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);

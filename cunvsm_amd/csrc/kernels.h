@@ -85,6 +85,12 @@ void launch_step_prologue(const int64_t* words64, int* widx, int64_t nW, const i
                           int nstats, int* err_flag, hipStream_t s);
 void launch_check_finite(const float* x, int64_t n, int* err_flag, int code, hipStream_t s);   // NVSM_DEBUG (CHECK_MATRIX)
 void launch_scale(float* x, int64_t n, float a, hipStream_t s);      // x *= a (replica averaging)
+// Host batch → HBM by a kernel that READS page-locked host memory over PCIe (up to four arrays in one launch) instead of
+// hipMemcpyAsync: the runtime's copy call held the calling thread for most of a step (0.55-0.8 ms per step measured for the
+// four arrays of a 51 200-window batch while the GPU was busy), so the host never got ahead of the GPU and every step began
+// with the GPU waiting for its launches. src: device-visible addresses of page-locked memory; bytes: multiples of 4.
+struct HostPull { void* dst[4]; const void* src[4]; size_t bytes[4]; int count; };
+void launch_host_pull(const HostPull& p, hipStream_t s);
 void launch_delay(int microseconds, hipStream_t s);      // one wave spinning on the 100 MHz wall clock (profiling aid)
 void launch_iota(int* dst, int64_t n, hipStream_t s);
 

@@ -679,21 +679,42 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             // ev_step_begin_[p] was recorded on the main stream when the previous step's compute_cost started, i.e. behind
             // everything the step before that one — the last reader of this staging set — had queued there.
             const int p = in_parity_ ^= 1;
-            NVSM_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_step_begin_[p ^ 1], 0));
-            NVSM_HIP_CHECK(hipEventRecord(ev_step_begin_[p], stream_));
-            NVSM_HIP_CHECK(hipMemcpyAsync(in_words_[p].p, batch.features, B * w * sizeof(int64_t), hipMemcpyHostToDevice, copy_stream_));
-            NVSM_HIP_CHECK(hipMemcpyAsync(in_labels_[p].p, batch.labels, B * sizeof(int64_t), hipMemcpyHostToDevice, copy_stream_));
+            // When the copy stream is also the stream of the documents CSR build (the default layout), that order is there
+            // already: this copy is queued behind the previous step's documents sort, which waited for that step's prologue,
+            // i.e. for everything the step before it had on the main stream — no event, and no record packet in front of
+            // the prologue on the critical stream.
+            static const bool copies_behind_sort = [] {
+                const char* a = std::getenv("NVSM_CSR_AFTER"); const char* l = std::getenv("NVSM_SORT_LAYOUT");
+                return (!a || std::atoi(a) == 0) && (!l || std::atoi(l) == 4);
+            }();
+            if (!(copies_behind_sort && copy_stream_ == aux3_stream_ && aux3_stream_)) {
+                NVSM_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_step_begin_[p ^ 1], 0));
+                NVSM_HIP_CHECK(hipEventRecord(ev_step_begin_[p], stream_));
+            }
+            // Page-locked arrays (nvsm_host_alloc / hipHostMalloc: the trainer's and the reference's batches) are pulled by ONE
+            // kernel that reads them over PCIe; anything else (pageable memory) goes through hipMemcpyAsync, which stages it.
+            // The runtime's copy call occupied this thread for most of a step even for page-locked sources (kernels.h HostPull).
+            HostPull pull{};
+            auto bring = [&](void* dst, const void* src, size_t bytes) {
+                static const bool use_pull = [] { const char* e = std::getenv("NVSM_HOST_PULL"); return !(e && e[0] == '0'); }();
+                void* dev_view = nullptr;
+                hipPointerAttribute_t at{};
+                if (use_pull && bytes % 4 == 0 && hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost &&
+                    hipHostGetDevicePointer(&dev_view, const_cast<void*>(src), 0) == hipSuccess && dev_view) {
+                    pull.dst[pull.count] = dst; pull.src[pull.count] = dev_view; pull.bytes[pull.count] = bytes; ++pull.count;
+                } else {
+                    (void)hipGetLastError();      // (a failed attribute query of a pageable pointer is not an error of ours)
+                    NVSM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, copy_stream_));
+                }
+            };
+            bring(in_words_[p].p, batch.features, B * w * sizeof(int64_t));
+            bring(in_labels_[p].p, batch.labels, B * sizeof(int64_t));
             words_dev = in_words_[p].p;
             labels_dev_ = in_labels_[p].p;
             wwts_ = nullptr; instw_ = nullptr;
-            if (batch.feature_weights) {
-                NVSM_HIP_CHECK(hipMemcpyAsync(in_wwts_[p].p, batch.feature_weights, B * w * sizeof(float), hipMemcpyHostToDevice, copy_stream_));
-                wwts_ = in_wwts_[p].p;
-            }
-            if (batch.weights) {
-                NVSM_HIP_CHECK(hipMemcpyAsync(in_instw_[p].p, batch.weights, B * sizeof(float), hipMemcpyHostToDevice, copy_stream_));
-                instw_ = in_instw_[p].p;
-            }
+            if (batch.feature_weights) { bring(in_wwts_[p].p, batch.feature_weights, B * w * sizeof(float)); wwts_ = in_wwts_[p].p; }
+            if (batch.weights) { bring(in_instw_[p].p, batch.weights, B * sizeof(float)); instw_ = in_instw_[p].p; }
+            launch_host_pull(pull, copy_stream_);
             NVSM_HIP_CHECK(hipEventRecord(ev_copied_, copy_stream_));
             NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_copied_, 0));
             copied_recorded_ = true;

@@ -12,6 +12,7 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="nvsm")
 ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--host-batches", action="store_true")
 a = ap.parse_args()
 class A: pass
 args = A(); args.config = a.config; args.num_words = args.num_entities = args.batch = args.update_method = args.word_dim = None
@@ -26,10 +27,17 @@ m = ca.Model(cfg); m.initialize(1)
 dev = torch.device("cuda", 0)
 rs = np.random.RandomState(1)
 pool = []
+keep = []
 for i in range(4):
-    words = torch.from_numpy(bench.zipf_ids(rs, wl["num_words"], B * w)).to(dev)
-    labels = torch.from_numpy(rs.randint(0, wl["num_entities"], size=B).astype(np.int64)).to(dev)
-    pool.append(ca.Batch(words, labels, torch.ones(B * w, dtype=torch.float32, device=dev), torch.ones(B, dtype=torch.float32, device=dev)))
+    words = bench.zipf_ids(rs, wl["num_words"], B * w)
+    labels = rs.randint(0, wl["num_entities"], size=B).astype(np.int64)
+    if a.host_batches:
+        pins = [ca.model.pinned_copy(x) for x in (words, labels, np.ones(B * w, np.float32), np.ones(B, np.float32))]
+        keep.append(pins)
+        pool.append(ca.Batch(pins[0].array, pins[1].array, pins[2].array, pins[3].array))
+    else:
+        pool.append(ca.Batch(torch.from_numpy(words).to(dev), torch.from_numpy(labels).to(dev),
+                             torch.ones(B * w, dtype=torch.float32, device=dev), torch.ones(B, dtype=torch.float32, device=dev)))
 for i in range(10):
     m.step_deferred(pool[i % 4], wl["lr"])
 m.synchronize()
@@ -44,4 +52,4 @@ for i in range(a.steps):
     m.step_deferred(pool[i % 4], wl["lr"])
 host = (time.perf_counter() - t0) / a.steps
 m.synchronize()
-print(json.dumps({"config": a.config, "host_enqueue_us_per_step": round(host * 1e6, 1), "free_running_us_per_step": round(free * 1e6, 1)}))
+print(json.dumps({"config": a.config, "host_batches": a.host_batches, "host_enqueue_us_per_step": round(host * 1e6, 1), "free_running_us_per_step": round(free * 1e6, 1)}))

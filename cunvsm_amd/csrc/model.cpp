@@ -936,7 +936,13 @@ void Model::backward_dx() {
         PROF("bn_backward");
         // dx is final behind the last kernel of this block: the dT GEMM of the fused step may start (ev_dx_ rides on that
         // kernel as its completion event)
-        auto dx_final = [&](auto&& launch) { launch_and_record(ev_dx_, stream_, launch); };
+        // (A wait on a kernel-borne event is resolved when it is ISSUED: issued after more kernels have been queued behind
+        //  the one that carries the event, it ends up behind those too — the dT GEMM started after the dx GEMM's row
+        //  statistics instead of next to the dx GEMM. The stream that is to follow dx waits right here.)
+        auto dx_final = [&](auto&& launch) {
+            launch_and_record(ev_dx_, stream_, launch);
+            if (dx_follower_) NVSM_HIP_CHECK(hipStreamWaitEvent(dx_follower_, ev_dx_, 0));
+        };
         auto bn_dx = [&](double n) {
             launch_bn_dx(dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, stats_bwd_ + 1, dbeta_.p, dgamma_.p, gb_.p, n, B, de, stream_);
         };
@@ -1337,6 +1343,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     // NVSM_DOCS_ON_MAIN (experiments): 1 = the documents update on the main stream in front of the words update, 2 = behind
     // it (two HBM-bound passes one after the other instead of next to each other)
     static const int docs_on_main = [] { const char* e = std::getenv("NVSM_DOCS_ON_MAIN"); return e ? std::atoi(e) : 0; }();
+    dx_follower_ = dp ? nullptr : aux2_stream_;      // side stream 2 runs the dT GEMM as soon as dx is final
     if (docs_after_dx || docs_on_main) backward_dx();
     if (docs_on_main == 1) {
         NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
@@ -1348,13 +1355,14 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         E_pending_ = true;
     }
     if (!docs_after_dx && !docs_on_main) backward_dx();
+    dx_follower_ = nullptr;
     if (dp) {
         backward_T(stream_);
     } else {
         // side stream 2 (behind the words CSR build): the MFMA-bound dT GEMM next to the HBM-bound words update, then the
         // projection update; the next projection GEMM joins it
         // (started as soon as dx is final rather than after the dx GEMM: 1.084 vs 1.100 ms per step, interleaved A/B)
-        NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_dx_, 0));
+        // (the wait for ev_dx_ was issued by backward_dx, right behind the kernel that carries the event)
         backward_T(aux2_stream_);
         NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_bwdx_, 0));      // the dx GEMM is the last reader of T
         update_transform(lr, sl, aux2_stream_);

@@ -206,6 +206,7 @@ class Model {
     hipEvent_t ev_csr_all_ = nullptr;           // both tables' CSR builds of this step are done (recorded on the words build's stream)
     hipStream_t words_untouched_stream_ = nullptr;      // set by step() around update_words (kernels.h launch_table_pass untouched_s)
     bool words_tail_pending_ = false;                   // side stream 2 still decays words rows: the next word gather joins it
+    hipStream_t dx_follower_ = nullptr;                 // set by step(): the stream that waits for ev_dx_ (issued inside backward_dx)
     hipEvent_t loss_stop_event_ = nullptr;      // set by step(): the loss kernel of this compute_cost carries it as its completion event
     std::minstd_rand0 rng_;           // include/cuNVSM/base.h:36
     uint64_t device_seed_ = 1, step_count_ = 0;

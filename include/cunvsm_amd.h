@@ -86,7 +86,9 @@ void nvsm_config_default(nvsm_config* cfg);
 
 /*
  * Replaces TextEntity::Batch (include/cuNVSM/data.h:114-177, cpp/data.cu:8-124): four flat arrays.
- * on_device = 0: host pointers (the reference's pinned-host batch; copied H2D asynchronously);
+ * on_device = 0: host pointers (the reference's pinned-host batch). Page-locked arrays (nvsm_host_alloc, hipHostMalloc,
+ *                hipHostRegister) are read over PCIe by a kernel on the engine's copy stream, a step ahead of their use, and
+ *                the call never holds the calling thread; pageable arrays are staged by hipMemcpyAsync, which does;
  * on_device = 1: device pointers already resident in HBM (no copy).
  */
 typedef struct {
@@ -120,7 +122,7 @@ int nvsm_rng_set_state(nvsm_model* m, uint64_t state);
 int nvsm_initialize_from_rng_state(nvsm_model* m);
 
 /* Pinned host memory for batches handed over with on_device = 0 — what TextEntity::Batch allocates with
- * cudaHostAlloc (cpp/data.cu:16-27), so that the H2D copies of compute_cost are truly asynchronous. */
+ * cudaHostAlloc (cpp/data.cu:16-27), so that bringing a batch into HBM is truly asynchronous (see nvsm_batch). */
 int nvsm_host_alloc(size_t bytes, void** out);
 int nvsm_host_free(void* p);
 

@@ -127,12 +127,23 @@ void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared) {
 // two). Out-of-range slots of the last batch re-read the segment's last entry with coefficient 0 (branch-free).
 // src = entry / div by multiply-shift: exact for entry < 2^26, div <= 2048 (checked by the host).
 // =============================================================================================
-constexpr int kSegUnrollDeep = 8;
+// Source rows in flight per lane in the gather of a row's / chunk's entries. Eight (one round for a row of up to eight
+// entries) was the first choice; interleaved A/B over 3-8 for either table at the NVSM shape says five for both: 1.030 ->
+// 1.007 ms per step. Not a per-kernel optimum — alone the passes like eight — but the two updates run next to each other
+// and share the memory system: w8 d5 1.062, w5 d8 1.028, w5 d5 1.010, w5 d4 1.055 (97 registers: a fifth wave per SIMD for
+// the documents pass, which then crowds out the words chain the step waits for), w5 d6 1.022, w4 d5 1.011, w6 d5 1.011.
+#ifndef NVSM_SEG_UNROLL_WORDS
+#define NVSM_SEG_UNROLL_WORDS 5
+#endif
+#ifndef NVSM_SEG_UNROLL_DOCS
+#define NVSM_SEG_UNROLL_DOCS 5
+#endif
+template <int TABLE> struct SegUnrollDeep { static constexpr int value = TABLE == 0 ? NVSM_SEG_UNROLL_WORDS : NVSM_SEG_UNROLL_DOCS; };
 // rows of a table much larger than the batch hold one or two entries: two slots in flight per lane leave registers for
 // 2-3x as many rows in flight per CU, which is what bounds that regime (a dependent chain of four loads per row)
 constexpr int kSegUnrollShallow = 2;
 
-template <int V, int TABLE, bool VEC, int kSegUnroll = kSegUnrollDeep>
+template <int V, int TABLE, bool VEC, int kSegUnroll = SegUnrollDeep<TABLE>::value>
 __device__ __forceinline__ void accumulate_segment(const RowPassArgs& a, const int* __restrict__ sorted_entry,
                                                    int begin, int end, int col, float (&g)[V], float& q) {
     // Which products the compiler fuses with the following add may differ from one kernel this is inlined into to the
@@ -948,7 +959,7 @@ static void row_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nve
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 #define NVSM_ROW_CASE(K) case K: \
         if (a.shallow) hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec); \
-        else hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K, kSegUnrollDeep>), grid, block, 0, s, c, a, G, nvec); \
+        else hipLaunchKernelGGL((row_pass_kernel<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec); \
         break;
     switch (a.kind) {
         NVSM_ROW_CASE(ROW_SGD)
@@ -1027,7 +1038,7 @@ static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
     const dim3 grid(static_cast<unsigned>(chunk_blocks + row_blocks)), block(256);
 #define NVSM_TABLE_CASE(K) case K: \
         if (a.shallow) hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
-        else hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, kSegUnrollDeep>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+        else hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
         break;
     switch (a.kind) {
         NVSM_TABLE_CASE(ROW_SGD)

@@ -141,7 +141,7 @@ void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared) {
 template <int TABLE> struct SegUnrollDeep { static constexpr int value = TABLE == 0 ? NVSM_SEG_UNROLL_WORDS : NVSM_SEG_UNROLL_DOCS; };
 // rows of a table much larger than the batch hold one or two entries: two slots in flight per lane leave registers for
 // 2-3x as many rows in flight per CU, which is what bounds that regime (a dependent chain of four loads per row)
-constexpr int kSegUnrollShallow = 2;
+constexpr int kSegUnrollShallow = 4;      // (2 at first; A/B over 2-4: LSE batch 4096 0.197 -> 0.193 ms, |D| = 2 M unchanged)
 
 template <int V, int TABLE, bool VEC, int kSegUnroll = SegUnrollDeep<TABLE>::value>
 __device__ __forceinline__ void accumulate_segment(const RowPassArgs& a, const int* __restrict__ sorted_entry,

@@ -1004,7 +1004,8 @@ void Model::backward_T(hipStream_t strm) {
             launch_gemm(1, 0, phrase_p_, dy_.p, gT_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr, 1, 0, strm);
         } else {
             launch_gemm(1, 0, phrase_p_, dy_.p, gT_partial_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr,
-                        gemm_slabs_want_, stride, strm);
+                        gemm_slabs_want_, stride, strm, nullptr, nullptr, 0.f, nullptr,
+                        /*busy_chip=*/strm != stream_);      // fused step: next to the words / documents update
             launch_splitk_reduce(gT_partial_.p, slabs, stride, gT_.p, static_cast<int64_t>(stride), strm);
         }
     }

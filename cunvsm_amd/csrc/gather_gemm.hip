@@ -79,7 +79,7 @@ int window_unroll(int window) { return window <= 10 ? (window < 1 ? 1 : window) 
 template <int V, bool LAZY, typename View>
 static void gather_mean_dispatch(int U, dim3 grid, hipStream_t s, const float* table, int dim, const int* idx, const float* wts,
                                  int window, uint32_t total, uint32_t nvec, float* out, const View& view) {
-#define NVSM_GATHER_CASE(N) case N: hipLaunchKernelGGL((gather_mean_kernel<V, LAZY, N>), grid, dim3(256), 0, s, table, dim, idx, wts, \
+#define NVSM_GATHER_CASE(N) case N: NVSM_LAUNCH((gather_mean_kernel<V, LAZY, N>), grid, dim3(256), 0, s, table, dim, idx, wts, \
                                                        window, total, nvec, out, view); break;
     switch (U) {
         NVSM_GATHER_CASE(1) NVSM_GATHER_CASE(2) NVSM_GATHER_CASE(3) NVSM_GATHER_CASE(4) NVSM_GATHER_CASE(5)

@@ -306,7 +306,7 @@ static bool tstat_launch_epi(const TstatArgs& g, size_t lds, int wgs, hipStream_
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_tstat_kernel<KG, NT, BLAY, MIXED, EPI>), dim3(wgs), dim3(kTstatThreads), lds, s, g);
+    NVSM_LAUNCH((gemm_tstat_kernel<KG, NT, BLAY, MIXED, EPI>), dim3(wgs), dim3(kTstatThreads), lds, s, g);
     return true;
 }
 

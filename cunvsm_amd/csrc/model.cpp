@@ -256,6 +256,26 @@ static void launch_and_record(hipEvent_t ev, hipStream_t s, F&& launch) {
     if (hipEvent_t left = take_launch_events(nullptr)) NVSM_HIP_CHECK(hipEventRecord(left, s));      // nothing was launched
 }
 
+// A kernel group that is ONE launch through NVSM_LAUNCH, timed by the profiler: its event pair rides on the launch as start /
+// stop events (the kernel's own execution time, nothing queued around it); `single` false: the plain records around the group.
+template <class F>
+static void timed_launch(Profiler& prof, const char* name, hipStream_t s, bool single, F&& launch) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (single && stop_events_enabled() && prof.bind(name, &a, &b)) {
+        RangeScope r(name);
+        set_launch_events(a, b);
+        launch();
+        hipEvent_t ls = nullptr;
+        if (hipEvent_t le = take_launch_events(&ls)) {      // nothing was launched: an empty interval
+            NVSM_HIP_CHECK(hipEventRecord(ls, s));
+            NVSM_HIP_CHECK(hipEventRecord(le, s));
+        }
+        return;
+    }
+    ProfScope scope(prof, name, s);
+    launch();
+}
+
 // ---------------------------------------------------------------------------------------------
 // NVSM_CHUNK_ORDER=0 (A/B runs): level-1 chunks as numbered instead of in batch order
 static bool chunk_order_enabled() {
@@ -807,12 +827,13 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     if (join_e_at == 2) join_E();
     if (words_tail_pending_) { join_T(); words_tail_pending_ = false; }      // the previous step's streaming decay of the words table (step())
     {
-        PROF("gather_mean_words");
         const bool l2p = cfg_.l2_normalize_phrase_reprs != 0;
         const LazyView lv = lazy_view(words_);
-        launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, l2p ? phrase_raw_.p : phrase_p_, stream_, &lv);
-        // optional phrase normaliser (objective.cu:136-142): the raw means stay cached for its backward pass
-        if (l2p) launch_l2_rows_forward(phrase_raw_.p, B, dw, phrase_p_, phrase_norms_.p, stream_);
+        timed_launch(prof, "gather_mean_words", stream_, /*single=*/!l2p, [&] {
+            launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, l2p ? phrase_raw_.p : phrase_p_, stream_, &lv);
+            // optional phrase normaliser (objective.cu:136-142): the raw means stay cached for its backward pass
+            if (l2p) launch_l2_rows_forward(phrase_raw_.p, B, dw, phrase_p_, phrase_norms_.p, stream_);
+        });
     }
     if (csr_after == 1 && !csr_first) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
     debug_check(phrase_p_, B * dw, 0);                  // CHECK_MATRIX(*result->phrase_reprs_), objective.cu:134,141

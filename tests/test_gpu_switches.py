@@ -1,0 +1,79 @@
+"""The engine's orchestration switches change WHEN and HOW work is queued, never what is computed: events carried by
+kernel launches vs plain records, intra-device events with / without the system fence, page-locked batches pulled by a
+kernel vs copied by the runtime, the streaming decay of the untouched word rows on a side stream vs the main stream, the
+panel vs the tiled GEMM... Each variant trains the same few steps in a process of its own (the switches are read once per
+process) and must leave bit-identical parameters and costs."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import cunvsm_amd as ca
+from tests.helpers import PARAMS, gpu_model
+shape = sys.argv[1]
+if shape == "split":      # tables larger than the batch: touched-row list + streaming pass over the rest (LSE-like)
+    spec = dict(num_words=20000, num_entities=30000, word_dim=64, entity_dim=96, window=5, num_random=4, nonlinearity="tanh",
+                batch_norm=False, bias_negative_samples=True, update_method="adagrad", **{"lambda": 0.01})
+    B = 512
+else:                      # batch larger than the tables: dense passes, chunk tree, batch-norm, sparse Adam (NVSM-like)
+    spec = dict(num_words=3000, num_entities=5000, word_dim=60, entity_dim=64, window=6, num_random=5, nonlinearity="hard_tanh",
+                batch_norm=True, bias_negative_samples=False, update_method="sparse_adam", **{"lambda": 0.01})
+    B = 8192
+m = gpu_model(spec, B, sampler=ca.SAMPLER_DEVICE)
+m.initialize(7)
+rs = np.random.RandomState(5)
+costs, keep = [], []
+for step in range(6):
+    words = (rs.zipf(1.3, B * spec["window"]) %% spec["num_words"]).astype(np.int64)
+    labels = rs.randint(0, spec["num_entities"], B).astype(np.int64)
+    ww = rs.uniform(0.5, 1.5, B * spec["window"]).astype(np.float32)
+    iw = rs.uniform(0.5, 1.5, B).astype(np.float32)
+    pins = [ca.model.pinned_copy(x) for x in (words, labels, ww, iw)]      # page-locked host batches: the pull / copy path
+    keep.append(pins)
+    costs.append(m.step(ca.Batch(pins[0].array, pins[1].array, pins[2].array, pins[3].array), 0.01, want_cost=(step %% 2 == 1)))
+h = hashlib.sha256()
+for p in PARAMS:
+    h.update(np.ascontiguousarray(m.get_param(p)).tobytes())
+print("RESULT " + json.dumps({"params": h.hexdigest(), "costs": [c for c in costs if c is not None]}))
+"""
+
+VARIANTS = [
+    {},
+    {"NVSM_STOP_EVENTS": "0"},
+    {"NVSM_EVENT_FENCE": "0"},
+    {"NVSM_HOST_PULL": "0"},
+    {"NVSM_PULL_BLOCKS": "3"},
+    {"NVSM_UNTOUCHED_ASIDE": "0"},
+    {"NVSM_GEMM_PANEL": "0"},
+    {"NVSM_STOP_EVENTS": "0", "NVSM_EVENT_FENCE": "0", "NVSM_HOST_PULL": "0", "NVSM_UNTOUCHED_ASIDE": "0"},
+]
+
+
+def _run(shape, env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, shape], env=env, capture_output=True, text=True, cwd=ROOT,
+                       timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, (env_extra, r.stdout[-2000:], r.stderr[-2000:])
+    return json.loads(lines[-1][len("RESULT "):])
+
+
+@pytest.mark.parametrize("shape", ["split", "dense"])
+def test_orchestration_switches_do_not_change_results(shape):
+    base = _run(shape, VARIANTS[0])
+    assert len(base["costs"]) == 3 and all(c == c for c in base["costs"])
+    for v in VARIANTS[1:]:
+        got = _run(shape, v)
+        assert got == base, (shape, v, got, base)

@@ -680,7 +680,10 @@ __device__ __forceinline__ void entry_terms(const RowPassArgs& a, uint32_t en, b
     cf = (TABLE == 0 && a.src_scale) ? c * scl : c;
 }
 
-constexpr int kWalkUnroll = 4;
+// (source rows of one table row in flight per lane. Four at first; the two entry walks of a step — words and documents — run
+//  next to each other for 0.7 ms at |V| = 500 k, |D| = 2 M and, like the row passes of the NVSM shape, do better as a
+//  pair when each is less greedy: interleaved A/B 1 / 2 / 3 / 4 / 6 in flight: 1.81 / 1.79 / 1.82 / 1.88 / 1.90 ms per step)
+constexpr int kWalkUnroll = 2;
 // g, q += the entries held by lanes [first, first + count) of (src, cf, sq), in lane order. NT column turns of 64 lanes each
 // are held in registers side by side (a 300-column row is two: 64 + 11 lanes), so that a row still costs ONE round of loads.
 template <int V, int NT>

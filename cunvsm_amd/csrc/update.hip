@@ -1096,7 +1096,10 @@ static bool entry_walk_kind(int kind) { return kind == ROW_SGD || kind == ROW_AD
 template <int V, int TABLE>
 static void entry_walk_dispatch(const Csr& c, const RowPassArgs& a, int nvec, hipStream_t s) {
     if (c.n <= 0) return;
-    int ppw = 64;                                        // sorted positions per wave: enough waves to fill the machine
+    // sorted positions per wave: enough waves to fill the machine, and at most sixteen — a wave goes through the rows that
+    // open in its range one after the other, and with 64 positions (≈50 rows at one entry per row) it was a chain of fifty
+    // dependent rounds of loads: 64 / 32 / 16 / 8 / 4 positions: 1.834 / 1.80 / 1.75 / 1.755 / 1.79 ms per step at |D| = 2 M
+    int ppw = 16;
     while (ppw > 4 && c.n / ppw < 8192) ppw >>= 1;
     int64_t blocks = ((c.n + ppw - 1) / ppw + 3) / 4;
     if (blocks > 256 * 64) blocks = 256 * 64;

@@ -1029,7 +1029,9 @@ template <int V, int TABLE>
 static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int nvec, int64_t row_items, hipStream_t s) {
     const int gpb = 256 / G;
     int chunk_blocks = (c.n > 0 && c.max_chunks > 0) ? (c.max_chunks + gpb - 1) / gpb + 8 : 0;      // (+ 8: an eighth per XCD, rounded up)
-    static const int cb_cap = [] { const char* e = std::getenv("NVSM_CHUNK_BLOCKS"); return e ? std::atoi(e) : 0; }();      // experiments
+    // (at most 2048 chunk workgroups — a multiple of 8: workgroup cb runs on XCD cb % 8 —, which stride over the chunks in
+    //  use; one per gpb chunk SLOTS, most of them empty, was 5300: 0.994 -> 0.989 ms per step; 256: 1.06. NVSM_CHUNK_BLOCKS overrides)
+    static const int cb_cap = [] { const char* e = std::getenv("NVSM_CHUNK_BLOCKS"); return e ? std::atoi(e) : 2048; }();
     if (cb_cap > 0 && chunk_blocks > cb_cap) chunk_blocks = cb_cap;
     if (a.rows_elsewhere && chunk_blocks > 2048) chunk_blocks = 2048;      // normally there is no chunk at all: a launch that costs nothing
     int64_t row_blocks = (row_items + gpb - 1) / gpb;

@@ -34,7 +34,7 @@ constexpr int kSortMaxDigitBits = 9;
 constexpr int kSortMaxBuckets = 1 << kSortMaxDigitBits;
 constexpr int kSortMaxBlocks = 128;
 constexpr int kSortUnroll = 4;
-constexpr int64_t kSortMinTile = 4096;          // entries per workgroup before a second workgroup is worth its barrier
+constexpr int64_t kSortMinTile = 1024;          // entries per workgroup before a second workgroup is worth its barrier (4096 at first: batch 4096 0.194 -> 0.187 ms per step)
 
 // lanes of this wave (among `active`) whose digit equals mine
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, int D, uint64_t active) {

@@ -387,7 +387,10 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     // event (hipEventDisableSystemFence: what it gives up — visibility to the host and to other devices — nobody asks of
     // them; the host-visible results travel behind stream synchronisations and the events of their copies): LSE batch 4096
     // 0.209 -> 0.203 ms per step, no effect at the NVSM shape. NVSM_EVENT_FENCE=0: default events, 2: device-scope release.
-    static const int ev_fence = [] { const char* e = std::getenv("NVSM_EVENT_FENCE"); return e ? std::atoi(e) : 1; }();
+    // (Data parallel handles keep the default events: memory that peers write over xGMI is in play there, the gain is
+    //  confined to launch-latency-bound shapes, and a multi-GPU node has not been available to measure on.)
+    static const int ev_fence_env = [] { const char* e = std::getenv("NVSM_EVENT_FENCE"); return e ? std::atoi(e) : -1; }();
+    const int ev_fence = ev_fence_env >= 0 ? ev_fence_env : (cfg.world_size > 1 ? 0 : 1);
     const unsigned dev_flags = hipEventDisableTiming | (ev_fence == 1 ? hipEventDisableSystemFence : 0u) | (ev_fence == 2 ? hipEventReleaseToDevice : 0u);
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, dev_flags));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, dev_flags));

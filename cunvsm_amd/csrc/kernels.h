@@ -262,7 +262,9 @@ void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
 // Those rows and the rows with entries are disjoint, so the two launches need no order between them — only the CSR bounds
 // in front of both and the table's next reader behind both.
 void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s, hipStream_t untouched_s = nullptr);
-void launch_table_pass(const Csr& c, const RowPassArgs& a, hipStream_t s, hipStream_t untouched_s = nullptr);      // both, in one launch (update.hip)
+// both, in one launch (update.hip). Returns how the rows with entries were walked (tests assert which path a shape took).
+enum TablePassPath { TABLE_PASS_DENSE = 0, TABLE_PASS_LIST_WALK = 1, TABLE_PASS_ENTRY_WALK = 2 };
+int launch_table_pass(const Csr& c, const RowPassArgs& a, hipStream_t s, hipStream_t untouched_s = nullptr);
 void set_table_pass_one_launch(bool on);      // tests / A-B runs: false = the three-launch form (also NVSM_MERGED_PASS=0)
 
 // words, window > 1 (cpp/updates_adagrad.cu:83-97, cpp/updates_adam.cu:132-151)

@@ -199,13 +199,17 @@ void Profiler::end(hipStream_t s) {
 }
 void Profiler::reset() {
     for (auto& kv : slots_) kv.second.used = 0;
+    notes_.clear();
 }
 std::vector<std::string> Profiler::names() const {
     std::vector<std::string> v;
     for (auto& kv : slots_) v.push_back(kv.first);
+    for (auto& kv : notes_) v.push_back(kv.first);
     return v;
 }
 bool Profiler::get(const std::string& name, double* ms, int64_t* launches) {
+    auto nt = notes_.find(name);
+    if (nt != notes_.end()) { *ms = 0.0; *launches = nt->second; return true; }
     auto it = slots_.find(name);
     if (it == slots_.end()) return false;
     double total = 0.0;
@@ -1229,7 +1233,9 @@ void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row
     }
     a.nt_m = nt_mask() & 1; a.nt_p = (nt_mask() >> 1) & 1;
     if (row_pass_after) NVSM_HIP_CHECK(hipStreamWaitEvent(strm, row_pass_after, 0));
-    { PROF_ON("row_pass_entities", strm); launch_table_pass(c, a, strm); }
+    int path;
+    { PROF_ON("row_pass_entities", strm); path = launch_table_pass(c, a, strm); }
+    if (path == TABLE_PASS_ENTRY_WALK) prof.note("entry_walk_entities");
     if (swap_sc) t.sc_cur ^= 1;
     lazy_end_update(t, c, strm);
 }
@@ -1289,7 +1295,9 @@ void Model::update_words(float lr, float sl) {
     a.nt_m = (nt_mask() >> 2) & 1;
     lazy_begin_update(t, a, true);
     lazy_scalar_snapshot(t, c, stream_);
-    { PROF("row_pass_words_mv"); launch_table_pass(c, a, stream_, words_untouched_stream_); }
+    int path;
+    { PROF("row_pass_words_mv"); path = launch_table_pass(c, a, stream_, words_untouched_stream_); }
+    if (path == TABLE_PASS_ENTRY_WALK) prof.note("entry_walk_words");
     if (!t.lazy) t.sc_cur ^= 1;
     { PROF("adam_u_words"); launch_adam_u(t.m.p, t.sc[t.sc_cur].p, dw, widx_.p, w, B_, a.bc, a.eps, U_.p, stream_); }
     RowPassArgs r = a;

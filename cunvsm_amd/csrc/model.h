@@ -78,6 +78,7 @@ class Profiler {
     // in front of or behind the kernel. false: the group is not being timed.
     bool bind(const char* name, hipEvent_t* start, hipEvent_t* stop);
     bool selected(const char* name) const;
+    void note(const char* name) { if (enabled) ++notes_[name]; }      // a counter without events: which code path a launch took
     void reset();
     std::vector<std::string> names() const;
     bool get(const std::string& name, double* ms, int64_t* launches);
@@ -85,6 +86,7 @@ class Profiler {
  private:
     struct Slot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
     std::map<std::string, Slot> slots_;
+    std::map<std::string, int64_t> notes_;
     Slot* cur_ = nullptr;
 };
 

@@ -1123,10 +1123,14 @@ static void entry_walk_dispatch(const Csr& c, const RowPassArgs& a, int nvec, hi
 }
 
 // one pass over a table: chunk tree of the long rows + row formula, in one launch (table_pass_kernel)
-void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hipStream_t untouched_s) {
+int launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hipStream_t untouched_s) {
     if (!untouched_s) untouched_s = s;
-    if (!merged_pass_enabled()) { launch_chunk_pass(c, a_in, s); launch_row_pass(c, a_in, s, untouched_s); return; }
-    if (c.rows <= 0) return;
+    const bool split = row_pass_split(c) && kind_is_row_local_when_untouched(a_in.kind);
+    if (!merged_pass_enabled()) {
+        launch_chunk_pass(c, a_in, s); launch_row_pass(c, a_in, s, untouched_s);
+        return split ? TABLE_PASS_LIST_WALK : TABLE_PASS_DENSE;
+    }
+    if (c.rows <= 0) return TABLE_PASS_DENSE;
     int V, nvec, G;
     group_geometry(a_in.dim, V, nvec, G);
     RowPassArgs a = a_in;
@@ -1150,10 +1154,11 @@ void launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hip
         }
         if (V == 4) { if (a.table == 0) entry_walk_dispatch<4, 0>(c, a, nvec, s); else entry_walk_dispatch<4, 1>(c, a, nvec, s); }
         else        { if (a.table == 0) entry_walk_dispatch<1, 0>(c, a, nvec, s); else entry_walk_dispatch<1, 1>(c, a, nvec, s); }
-        return;
+        return TABLE_PASS_ENTRY_WALK;
     }
     if (V == 4) { if (a.table == 0) table_pass_dispatch<4, 0>(c, a, G, nvec, row_items, s); else table_pass_dispatch<4, 1>(c, a, G, nvec, row_items, s); }
     else        { if (a.table == 0) table_pass_dispatch<1, 0>(c, a, G, nvec, row_items, s); else table_pass_dispatch<1, 1>(c, a, G, nvec, row_items, s); }
+    return a.touched_only ? TABLE_PASS_LIST_WALK : TABLE_PASS_DENSE;
 }
 
 // =============================================================================================

@@ -3,8 +3,11 @@
 * configs[3] — LSE, |V| = 200k, d_word = 128, batch 4096, tanh, no batch-norm, bias_negative_samples, Adagrad, lr 0.01
   (`cpp/main.cu:713-716`); |D|, d_doc, window and negatives inherited from configs[1]. Three steps
   against the fp64 oracle at full size.
-* configs[4] — NVSM, |V| = 500k, |D| = 2M (E alone is 2 GB: byte offsets past 2^31), one rank's share of the batch
-  (51 200 / 8 = 6 400 windows). The oracle cannot hold 2 x 660M fp64 values in seconds, so the comparison uses a
+* configs[4] — NVSM, |V| = 500k, |D| = 2M (E alone is 2 GB: byte offsets past 2^31), at one rank's share of the batch
+  (51 200 / 8 = 6 400 windows: touched-row list walk) AND at the full 51 200 windows the large-table bench line runs
+  (`bench.py --config large_tables`, profiles/*_large_*: lazy dense decay + the walk over the sorted entries,
+  `entry_walk_kernel` — the test asserts that this is the path that ran), Zipf and uniform word ids, sparse_adam and
+  the reference recipe's full_adam. The oracle cannot hold 2 x 660M fp64 values in seconds, so the comparison uses a
   size-independent property of the path: every table row is updated independently of the rows around it, hence the
   tables restricted to the ids a run touches — relabelled 0..U-1 — must evolve exactly as the oracle evolves a U-row
   model on the relabelled batch, and every other row follows the closed form of the dense decay.
@@ -59,13 +62,24 @@ def _f32_uniform(rng, n, a):
     return out
 
 
-@pytest.mark.parametrize("method", ["sparse_adam", "adagrad"])
-def test_large_tables_rows_evolve_as_compacted_oracle(method):
-    nV, nD, dw, de, w, k = 500000, 2000000, 300, 256, 10, 16
+# (method, windows per batch, steps, word ids): the per-rank share of configs[4]; then the shape behind the large-table
+# bench line — entry walk + lazy decay (cpp/storage.cu:37-102, cpp/updates_adam.cu:153-385 are the semantics) — with three
+# steps so that rows sit out one or two updates before a batch gathers / updates them again
+# The last case is larger than configs[4] on purpose: W (1.8 M x 1200 B) and E (2.2 M x 1024 B) both reach past byte offset
+# 2^31 (at configs[4]'s own size E ends 100 MB short of it), and the batches are made to touch those rows.
+LARGE_CASES = [("sparse_adam", 6400, 2, "zipf", 500000, 2000000), ("adagrad", 6400, 2, "zipf", 500000, 2000000),
+               ("sparse_adam", 51200, 3, "zipf", 500000, 2000000), ("sparse_adam", 51200, 3, "uniform", 500000, 2000000),
+               ("full_adam", 51200, 2, "zipf", 500000, 2000000), ("sparse_adam", 51200, 2, "zipf", 1800000, 2200000)]
+
+
+@pytest.mark.parametrize("method,B,steps,word_ids,nV,nD", LARGE_CASES,
+                         ids=["%s-B%d-%s-V%dk-D%dk" % (m, b, d, v // 1000, e // 1000) for m, b, _, d, v, e in LARGE_CASES])
+def test_large_tables_rows_evolve_as_compacted_oracle(method, B, steps, word_ids, nV, nD):
+    dw, de, w, k = 300, 256, 10, 16
     spec = dict(num_words=nV, num_entities=nD, word_dim=dw, entity_dim=de, window=w, num_random=k,
                 nonlinearity="hard_tanh", batch_norm=True, update_method=method)
     spec["lambda"] = 0.01
-    B, lr, steps = 6400, 1e-3, 2
+    lr = 1e-3
     rng = np.random.default_rng(55)
     rs = np.random.RandomState(55)
     W = _f32_uniform(rng, nV * dw, np.sqrt(6.0 / (dw + nV)) * 20)     # scaled up so that rows are not all ≈ 0
@@ -78,13 +92,15 @@ def test_large_tables_rows_evolve_as_compacted_oracle(method):
 
     batches = []
     for _ in range(steps):
-        words = zipf_ids(rs, nV, B * w)
-        # some windows reach into the far end of both tables (rows whose byte offset is past 2^31)
+        words = zipf_ids(rs, nV, B * w) if word_ids == "zipf" else rs.randint(0, nV, B * w).astype(np.int64)
+        # some windows reach into the far end of both tables
         words[rs.randint(0, B * w, 2000)] = rs.randint(nV - 1000, nV, 2000)
         labels = rs.randint(0, nD, B).astype(np.int64)
         labels[:64] = nD - 1 - np.arange(64)
         ids = rs.randint(0, nD, (B, k + 1)).astype(np.int64)
         ids[:, 0] = labels
+        if nV * dw * 4 > 2 ** 31:
+            assert (words * dw * 4 >= 2 ** 31).sum() >= 2000 and (ids * de * 4 >= 2 ** 31).sum() >= 1000
         batches.append((words, labels, np.ones(B * w, np.float32), np.ones(B, np.float32), ids.ravel()))
 
     # relabel: ids any step touches, plus a sample of rows no step touches
@@ -100,6 +116,7 @@ def test_large_tables_rows_evolve_as_compacted_oracle(method):
         m.set(PARAMS[2], T.astype(np.float64))
         m.set(PARAMS[3], bias.astype(np.float64))
 
+    g.profile_enable(True)
     for words, labels, ww, iw, ids in batches:
         for m in (o, o32):
             m.forward(map_w[words], ww, map_e[ids], iw)
@@ -108,6 +125,16 @@ def test_large_tables_rows_evolve_as_compacted_oracle(method):
         cg = g.step(ca.Batch(words, labels, ww, iw), lr, entity_ids=ids, want_cost=True)
         co = o.get_cost()
         assert abs(co - cg) <= 2e-5 * abs(co), (co, cg)
+    prof = g.profile()
+    g.profile_enable(False)
+    # which path ran (update.hip launch_table_pass): at 51 200 windows the sparse optimisers walk the sorted entries of
+    # both tables and decay lazily; full_adam touches every row of a table on every update whatever the batch
+    walked = {t for t in ("entities", "words") if prof.get("entry_walk_" + t, (0, 0))[1] == steps}
+    lazy = {t for t in ("entities", "words") if prof.get("lazy_stamp_" + t, (0, 0))[1] == steps}
+    if B >= 51200 and method == "sparse_adam":
+        assert walked == {"entities", "words"} and lazy == {"entities", "words"}, prof.keys()
+    elif method == "full_adam":
+        assert not walked and not lazy, prof.keys()
 
     tol = 1e-2 if method.endswith("adam") else 2e-3
     decay = (1.0 - lr * spec["lambda"] / B) ** steps
@@ -119,14 +146,17 @@ def test_large_tables_rows_evolve_as_compacted_oracle(method):
         change = np.linalg.norm(sub_o - old[used].astype(np.float64))
         err = np.linalg.norm(sub_g - sub_o)
         assert err <= tol * change + 1e-7 * np.linalg.norm(sub_o), (name, err, change)
-        # every row outside the relabelled set only saw the dense decay, twice
+        if method == "full_adam":      # folds L2 into the gradient: a row without entries still moves by its own Adam step
+            del new_g                  # (the relabelled set holds 500 such rows per table, compared above)
+            continue
+        # every row outside the relabelled set only saw the dense decay, once per step
         rest = np.ones(old.shape[0], bool)
         rest[used] = False
         idx = np.flatnonzero(rest)[:: max(1, rest.sum() // 200000)]          # an even sample of ~200k rows
         want = old[idx].astype(np.float64) * decay
         assert np.max(np.abs(new_g[idx].astype(np.float64) - want)) <= 2e-7 * np.max(np.abs(want)), name
         del new_g
-    # dense projection: after two Adam steps every component has moved by ≈ 2·lr whatever the size of its gradient, and
+    # dense projection: after a few Adam steps every component has moved by ≈ 2·lr whatever the size of its gradient, and
     # a column sum over 6400 mixed-sign terms that nearly cancels carries a large *relative* fp32 error — which Adam
     # turns into an error of the step. The yardstick is therefore the same arithmetic in fp32 on the CPU: the HIP path
     # must be as close to the fp64 result as the fp32 oracle is (within 4x), or within 2e-3 of the change.

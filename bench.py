@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Benchmark of the NVSM training hot path on MI355X (BASELINE.json metric: n-gram windows/sec).
+"""Benchmark of the NVSM training hot path on MI355X (BASELINE.json metric: n-gram windows/sec, batch = 51 200).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -9,25 +9,36 @@
 rendezvous on 127.0.0.1, a free port), so both call forms work.
 
 One "step" = one pass of the hot path (compute_cost → compute_gradients → update, negatives sampled on
-device) over one synthetic batch of 51 200 windows per GPU that is already resident in HBM. Workload =
-BASELINE.json configs[1]: |V| = 50k, |D| = 100k, d_word = 300, d_doc = 256, window 10, 16 negatives,
-batch 51 200, hard_tanh + batch-norm, Adam (sparse_adam; --update-method selects the others), λ = 1e-2,
-lr = 1e-3, Zipf(1) word ids, uniform document ids, all weights 1. `value` is the weak-scaling figure (every rank
-gets its own 51 200-window batch; the dense projection gradient and the batch-norm statistics are all-reduced over
-RCCL each step); with N > 1 the line also carries `strong` — SURVEY.md §8d row 3, the 51 200-window batch split
-51 200 / N per rank — measured in the same run. With N = 1 it also carries `value_readback_every_step` (the loss
-read back after every step, as the reference's loop does, cpp/main.cu:427-444) and `value_host_batches` (page-locked
-host batches handed over each step, PCIe inclusive) — never used for `value`.
+device) over one synthetic batch that is already resident in HBM. Workload = BASELINE.json configs[1]:
+|V| = 50k, |D| = 100k, d_word = 300, d_doc = 256, window 10, 16 negatives, batch 51 200, hard_tanh + batch-norm, Adam
+(sparse_adam; --update-method selects the others), λ = 1e-2, lr = 1e-3, Zipf(1) word ids, uniform document ids, all
+weights 1.
+
+Timing: W warm-up steps, then `--repeats` timed regions of EXACTLY K steps each, every region bracketed by a
+barrier + synchronize on both sides and taken as the MAX over ranks; `value` comes from the MEDIAN region (all region
+times are in the line: a 20-step region is 20 ms, one region would be a noisy sample).
+
+N = 1: `value` = 51 200-window steps on one GPU. The line also carries
+  * `per_rank_shapes` — the per-rank share of the 8-GPU metric (51 200 / N windows per rank) timed on
+    this one GPU with an engine created for that batch size, and `strong_projection_8gpu` computed from it (compute only:
+    no collective is in it);
+  * `secondary` — the reference recipe's `full_adam` (scripts/functions.sh:395) and the uniform-word-id worst case;
+  * `value_readback_every_step` (the loss read back after every step, as cpp/main.cu:427-444 does) and
+    `value_host_batches` (page-locked host batches handed over each step, PCIe inclusive) — never used for `value`.
+N > 1: the metric says batch = 51 200, so the headline `value` is the STRONG figure: the 51 200-window batch split
+51 200 / N per rank (dense gradients and batch-norm statistics all-reduced over RCCL each step); the weak figure
+(51 200 windows per rank) is measured in the same run and reported beside it (`weak`; `--weak-scaling` makes it the headline).
 
 Rank 0 prints ONE JSON line. `roofline` is for the document-embedding gather + loss kernel (the largest HBM
-gather of the step), timed with HIP events on the engine's stream inside the timed region; `kernel_breakdown`
-comes from a second, untimed pass with events around every kernel group (they cost ≈5 % of a step, so they stay
-out of the timed region); `cpu_baseline` is the CPU oracle (fp32, OpenMP) timed on this box's host cores on a
+gather of the step), timed with HIP events that ride on the kernel's own launch inside the timed regions;
+`kernel_breakdown` comes from a second, untimed pass with events around every kernel group (they cost ≈5 % of a step, so
+they stay out of the timed regions); `cpu_baseline` is the CPU oracle (fp32, OpenMP) timed on this box's host cores on a
 bounded sample of the same workload (N = 1 only).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -68,11 +79,15 @@ def workload(args):
     return wl
 
 
-def algorithmic_bytes(kernel, wl, method):
+def algorithmic_bytes(kernel, wl, method, B, rows=None):
     """Algorithmic HBM bytes per launch of each kernel group (SURVEY.md §8d per-window figures
-    x the windows one launch processes). Index/weight traffic (<1 %) is excluded as in the survey."""
-    B, w, dw, de, R = wl["batch"], wl["window"], wl["word_dim"], wl["entity_dim"], wl["num_random"] + 1
-    nV, nD = wl["num_words"], wl["num_entities"]
+    x the windows one launch processes). Index/weight traffic (<1 %) is excluded as in the survey.
+    rows: {"words": r, "entities": r} — the table rows a row pass reads and writes. A dense pass visits every row of its
+    table; a lazily decayed table (kernels.h: the decay of the rows without entries stays pending) only the rows the batch
+    touches, so the caller passes the touched-row counts for those."""
+    w, dw, de, R = wl["window"], wl["word_dim"], wl["entity_dim"], wl["num_random"] + 1
+    rows = rows or {}
+    nV, nD = rows.get("words", wl["num_words"]), rows.get("entities", wl["num_entities"])
     F = 4
     word_gather = B * w * dw * F              # 12 000 B / window
     ent_gather = B * R * de * F               # 17 408 B / window
@@ -97,18 +112,19 @@ PMC_KERNEL = {"loss_fused": "loss_rows_kernel", "row_pass_entities": "table_pass
               "gather_mean_words": "gather_mean_kernel", "adam_u_words": "adam_u_kernel"}
 
 
-def workload_signature(wl, method, uniform_words):
+def workload_signature(wl, method, uniform_words, B):
     """What a PMC summary must have been taken on to say anything about this run's kernels."""
     return "V%d_D%d_dw%d_de%d_w%d_k%d_B%d_%s_%s" % (wl["num_words"], wl["num_entities"], wl["word_dim"], wl["entity_dim"],
-                                                     wl["window"], wl["num_random"], wl["batch"], method,
+                                                     wl["window"], wl["num_random"], B, method,
                                                      "uniform" if uniform_words else "zipf")
 
 
 def pmc_traffic(kernel, signature):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_hbm_pmc.json,
     written by tools/profile_round.sh from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
-    Counters cannot be read from inside the process. None unless that summary was taken on exactly this workload
-    (its "workload" key equals `signature`): a figure measured on another configuration says nothing about this one."""
+    Counters cannot be read from inside the process: the figure is NOT measured in this run (the line says so). None unless
+    that summary was taken on exactly this workload (its "workload" key equals `signature`): a figure measured on another
+    configuration says nothing about this one."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")))
     pref = PMC_KERNEL.get(kernel)
@@ -126,8 +142,8 @@ def pmc_traffic(kernel, signature):
     return None, None
 
 
-def gemm_flops(wl):
-    return 2.0 * wl["batch"] * wl["word_dim"] * wl["entity_dim"]
+def gemm_flops(wl, B):
+    return 2.0 * B * wl["word_dim"] * wl["entity_dim"]
 
 
 def cpu_baseline(args, wl, method):
@@ -182,25 +198,171 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+class Leg:
+    """One engine handle + its pool of synthetic batches: everything a timed region needs."""
+
+    def __init__(self, env, wl, method, B, uniform_words=False, host_batches=False, seed=1234):
+        import cunvsm_amd as ca
+        self.env, self.wl, self.method, self.B = env, wl, method, B
+        self.uniform_words = uniform_words
+        cfg = ca.default_config(num_words=wl["num_words"], num_entities=wl["num_entities"], word_repr_size=wl["word_dim"],
+                                entity_repr_size=wl["entity_dim"], window_size=wl["window"],
+                                num_random_entities=wl["num_random"], batch_normalization=wl["batch_norm"],
+                                nonlinearity=wl["nonlinearity"], clip_sigmoid=1,
+                                bias_negative_samples=wl["bias_negative_samples"], regularization_lambda=1e-2, update_method=method,
+                                max_batch_size=B, device=env.local_rank, sampler=ca.SAMPLER_DEVICE,
+                                world_size=env.world, rank=env.rank, sync_batch_norm=1)
+        self.model = ca.Model(cfg)
+        self.model.initialize(1)                # --seed 1 (scripts/functions.sh:393); identical replicas on every rank
+        self.transport, self.comm_ranks = env.connect(self.model)
+        self.pool = self.make_pool(seed, host_batches)
+
+    def make_pool(self, seed, host, uniform=None):
+        import cunvsm_amd as ca
+        import torch
+        wl, B, w = self.wl, self.B, self.wl["window"]
+        uniform = self.uniform_words if uniform is None else uniform
+        rs = np.random.RandomState(seed + self.env.rank)
+        pool, self.touched_words = [], []
+        for _ in range(4):
+            words = (rs.randint(0, wl["num_words"], B * w).astype(np.int64) if uniform else zipf_ids(rs, wl["num_words"], B * w))
+            labels = rs.randint(0, wl["num_entities"], B).astype(np.int64)
+            self.touched_words.append(int(np.unique(words).size))
+            if host:        # page-locked host buffers, as the trainer's (and the reference's) batches are
+                pins = [ca.model.pinned_copy(x) for x in (words, labels, np.ones(B * w, np.float32), np.ones(B, np.float32))]
+                self.env.keep.append(pins)
+                pool.append(ca.Batch(pins[0].array, pins[1].array, pins[2].array, pins[3].array))
+            else:
+                dev = self.env.device
+                pool.append(ca.Batch(torch.from_numpy(words).to(dev), torch.from_numpy(labels).to(dev),
+                                     torch.ones(B * w, dtype=torch.float32, device=dev),
+                                     torch.ones(B, dtype=torch.float32, device=dev)))
+        return pool
+
+    def run_steps(self, n, batches=None, read_every=0):
+        args, model, lr = self.env.args, self.model, self.wl["lr"]
+        batches = batches or self.pool
+        for s in range(n):
+            want = read_every > 0 and (s + 1) % read_every == 0
+            if args.gate_us:
+                model.debug_delay(args.gate_us)
+            if args.sequential:
+                model.compute_cost(batches[s % len(batches)])
+                model.compute_gradients()
+                model.update(lr)
+                if want:
+                    model.get_cost()
+            else:
+                model.step(batches[s % len(batches)], lr, want_cost=want)
+
+    def timed(self, n, batches=None, read_every=0):
+        """EXACTLY n steps between barrier + synchronize on both sides; MAX over ranks. Seconds."""
+        import torch
+        env = self.env
+        env.sync_all(self.model)
+        t0 = time.perf_counter()
+        self.run_steps(n, batches, read_every)
+        self.model.synchronize()
+        torch.cuda.synchronize()
+        if env.dist is not None:
+            env.dist.barrier()
+        dt = time.perf_counter() - t0
+        if env.dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if env.args.test_shared_gpu else "cuda")
+            env.dist.all_reduce(t, op=env.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def timed_repeats(self, n, repeats, batches=None, read_every=0):
+        return [self.timed(n, batches, read_every) for _ in range(max(1, repeats))]
+
+    def touched_rows(self):
+        """Table rows one batch touches: words from the pool, documents from the ids the device sampler drew last."""
+        ids = self.model.get_tensor("entity_ids")
+        return {"words": int(round(float(np.mean(self.touched_words)))), "entities": int(np.unique(ids).size)}
+
+
+class Env:
+    """Process-wide state of a run: ranks, device, torch.distributed, the RCCL plumbing of each engine handle."""
+
+    def __init__(self, args, world, rank, local_rank):
+        import torch
+        self.args, self.world, self.rank, self.local_rank = args, world, rank, local_rank
+        self.device = torch.device("cuda", local_rank)
+        self.dist = None
+        self.keep = []
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo" if args.test_shared_gpu else "nccl", rank=rank, world_size=world)
+            self.dist = dist
+
+    def connect(self, model):
+        """The engine's own RCCL communicator (all-reduces on its streams, no host round trip); if it cannot be built on
+        this node, torch.distributed through the host-callback transport so that the run still completes."""
+        if self.world <= 1:
+            return "single", 0
+        import torch
+        from cunvsm_amd.model import comm_unique_id
+        args, dist = self.args, self.dist
+        ok = torch.zeros(1, device="cpu" if args.test_shared_gpu else "cuda")
+        try:
+            if args.test_shared_gpu:
+                raise RuntimeError("shared-GPU test: RCCL cannot put two ranks on one device")
+            obj = [comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(obj, src=0)
+            model.comm_init(obj[0])
+            ok += 1
+        except Exception as e:            # noqa: BLE001
+            if not args.test_shared_gpu:
+                sys.stderr.write("rank %d: nvsm_comm_init failed (%s)\n" % (self.rank, e))
+        dist.all_reduce(ok)
+        if int(ok.item()) == self.world:
+            return "rccl", model.comm_size()      # ncclCommCount
+        from cunvsm_amd import dp
+        if args.test_shared_gpu:
+            model.set_allreduce_callback(dp.torch_allreduce(dist))
+            return "torch.distributed(gloo) via host callback", 0
+        model.set_allreduce_callback(dp.torch_allreduce_device(dist, self.device))
+        return "torch.distributed(nccl) via host callback", 0
+
+    def sync_all(self, model):
+        import torch
+        model.synchronize()
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+
+
+def ms_stats(times, steps):
+    ms = sorted(t * 1e3 / steps for t in times)
+    med = statistics.median(ms)
+    return med, {"repeats": len(ms), "ms_per_step_all": [round(x, 4) for x in ms],
+                 "spread": round((ms[-1] - ms[0]) / med, 4) if med > 0 else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median one is reported")
     ap.add_argument("--config", default="nvsm", choices=sorted(PRESETS), help="nvsm = BASELINE configs[1] (the bench line)")
     ap.add_argument("--update-method", default=None, choices=["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
-    ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default 51200)")
+    ap.add_argument("--batch", type=int, default=None, help="windows per step (default 51200): per GPU at N = 1 and for the weak "
+                    "figure, split over the ranks for the strong one")
     ap.add_argument("--num-words", type=int, default=None)
     ap.add_argument("--num-entities", type=int, default=None)
     ap.add_argument("--word-dim", type=int, default=None, help="experiments (row alignment): d_word other than the config's 300")
-    ap.add_argument("--strong-scaling", action="store_true", help="make the strong split (51 200 / N windows per rank, SURVEY §8d row 3) "
-                    "the headline `value` instead of the weak one; both are always measured and reported when N > 1")
+    ap.add_argument("--weak-scaling", action="store_true", help="N > 1: make the weak figure (51 200 windows per rank) the headline "
+                    "`value` instead of the strong split of the metric's 51 200-window batch; both are always measured")
+    ap.add_argument("--strong-scaling", action="store_true", help="(the default since round 3; kept for older command lines)")
     ap.add_argument("--test-shared-gpu", action="store_true", help="test of the N > 1 control flow on a 1-GPU box: every rank on "
                     "device 0, gloo rendezvous, all-reduces through the host-callback transport (not a measurement)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous only (gloo, no GPU): proves that the N-rank launch works")
     ap.add_argument("--uniform-words", action="store_true", help="uniform instead of Zipf(1) word ids (worst case for caches)")
     ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step in the MAIN timed region too")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the read-back / host-batch / strong-scaling legs")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the read-back / host-batch / per-rank-shape / secondary legs")
     ap.add_argument("--cpu-steps", type=int, default=30, help="full-size steps of the CPU oracle timed for cpu_baseline (≈0.3 s each on the "
                     "16 CPUs the GPU box grants the process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,8 +401,7 @@ def main():
             print(json.dumps({"launch_check": n, "n_gpus": world}), flush=True)
         return
 
-    import cunvsm_amd as ca
-    from cunvsm_amd.model import comm_unique_id
+    import cunvsm_amd as ca  # noqa: F401  (fails loudly without the HIP library: no CPU fallback)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -250,172 +411,130 @@ def main():
         raise SystemExit("--gpus %d but only %d GPU(s) are visible (--test-shared-gpu exercises the N-rank control flow on one)"
                          % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if args.test_shared_gpu else "nccl", rank=rank, world_size=world)
+    env = Env(args, world, rank, local_rank)
+    dist = env.dist
 
     wl = workload(args)
     method = args.update_method
-    cfg = ca.default_config(num_words=wl["num_words"], num_entities=wl["num_entities"], word_repr_size=wl["word_dim"],
-                            entity_repr_size=wl["entity_dim"], window_size=wl["window"],
-                            num_random_entities=wl["num_random"], batch_normalization=wl["batch_norm"],
-                            nonlinearity=wl["nonlinearity"], clip_sigmoid=1,
-                            bias_negative_samples=wl["bias_negative_samples"], regularization_lambda=1e-2, update_method=method,
-                            max_batch_size=wl["batch"], device=local_rank, sampler=ca.SAMPLER_DEVICE,
-                            world_size=world, rank=rank, sync_batch_norm=1)
-    model = ca.Model(cfg)
-    model.initialize(1)                     # --seed 1 (scripts/functions.sh:393); identical replicas on every rank
-    transport, comm_ranks = "single", 0
-    if world > 1:
-        # the engine's own RCCL communicator (all-reduces on its streams, no host round trip); if it cannot be built on
-        # this node, fall back to torch.distributed through the host-callback transport so that the run still completes
-        ok = torch.zeros(1, device="cpu" if args.test_shared_gpu else "cuda")
-        try:
-            if args.test_shared_gpu:
-                raise RuntimeError("shared-GPU test: RCCL cannot put two ranks on one device")
-            obj = [comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(obj, src=0)
-            model.comm_init(obj[0])
-            ok += 1
-        except Exception as e:            # noqa: BLE001
-            sys.stderr.write("rank %d: nvsm_comm_init failed (%s)\n" % (rank, e))
-        dist.all_reduce(ok)
-        if int(ok.item()) == world:
-            transport = "rccl"
-            comm_ranks = model.comm_size()      # ncclCommCount
-        else:
-            from cunvsm_amd import dp
-            if args.test_shared_gpu:
-                model.set_allreduce_callback(dp.torch_allreduce(dist))
-                transport = "torch.distributed(gloo) via host callback"
-            else:
-                model.set_allreduce_callback(dp.torch_allreduce_device(dist, torch.device("cuda", local_rank)))
-                transport = "torch.distributed(nccl) via host callback"
-
-    # synthetic batches, resident in HBM before the timed region
+    Bg = wl["batch"]                          # the metric's batch: per GPU at N = 1 / weak, global for the strong split
     w = wl["window"]
-    dev = torch.device("cuda", local_rank)
-    pinned_keep = []
-
-    def make_pool(B, seed, host):
-        rs = np.random.RandomState(seed + rank)
-        pool = []
-        for _ in range(4):
-            words = (rs.randint(0, wl["num_words"], B * w).astype(np.int64) if args.uniform_words
-                     else zipf_ids(rs, wl["num_words"], B * w))
-            labels = rs.randint(0, wl["num_entities"], B).astype(np.int64)
-            if host:        # page-locked host buffers, as the trainer's (and the reference's) batches are
-                pins = [ca.model.pinned_copy(x) for x in (words, labels, np.ones(B * w, np.float32), np.ones(B, np.float32))]
-                pinned_keep.append(pins)
-                pool.append(ca.Batch(pins[0].array, pins[1].array, pins[2].array, pins[3].array))
-            else:
-                pool.append(ca.Batch(torch.from_numpy(words).to(dev), torch.from_numpy(labels).to(dev),
-                                     torch.ones(B * w, dtype=torch.float32, device=dev),
-                                     torch.ones(B, dtype=torch.float32, device=dev)))
-        return pool
-
-    B = wl["batch"]
-    pool = make_pool(B, 1234, args.host_batches)
-    lr = wl["lr"]
-
-    def sync_all():
-        model.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    def run_steps(n, batches, read_every=0):
-        for s in range(n):
-            want = read_every > 0 and (s + 1) % read_every == 0
-            if args.gate_us:
-                model.debug_delay(args.gate_us)
-            if args.sequential:
-                model.compute_cost(batches[s % len(batches)])
-                model.compute_gradients()
-                model.update(lr)
-                if want:
-                    model.get_cost()
-            else:
-                model.step(batches[s % len(batches)], lr, want_cost=want)
-
-    def timed(n, batches, read_every=0):
-        """EXACTLY n steps between barrier + synchronize on both sides; MAX over ranks."""
-        sync_all()
-        t0 = time.perf_counter()
-        run_steps(n, batches, read_every)
-        model.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.test_shared_gpu else "cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+    quick = args.no_extra_legs or args.sequential or bool(args.gate_us)
+    strong_ok = world > 1 and Bg % world == 0
+    headline_strong = strong_ok and not args.weak_scaling
+    # the leg behind `value` (roofline and kernel breakdown are taken on it) and, for N > 1, the other scaling figure
+    B = Bg // world if headline_strong else Bg
+    main_leg = Leg(env, wl, method, B, uniform_words=args.uniform_words, host_batches=args.host_batches,
+                   seed=4321 if headline_strong else 1234)
+    model = main_leg.model
 
     if world > 1:
         # communicator set-up (connections, first-use kernels) is lazy: two untimed steps take it out of the way even when
         # the caller asks for no warm-up steps
-        run_steps(2, pool)
-    run_steps(args.warmup, pool)
+        main_leg.run_steps(2)
+    main_leg.run_steps(args.warmup)
 
-    # Timed region: HIP events around the two gather kernels only (the document gather + loss kernel and the word
-    # gather-mean: four records per step). Events around every kernel group (~50 records per step) cost ≈5 % of the step,
-    # so the full per-kernel breakdown comes from a second, untimed pass over the same batches (--profile-all puts it back
-    # into the timed region).
+    # Timed regions: HIP events around the two gather kernels only (the document gather + loss kernel and the word
+    # gather-mean; they ride on the kernels' own launches). Events around every kernel group (~50 records per step) cost
+    # ≈5 % of the step, so the full per-kernel breakdown comes from a second, untimed pass over the same batches
+    # (--profile-all puts it back into the timed regions).
     ROOFLINE_KERNEL, GATHER_KERNEL = "loss_fused", "gather_mean_words"
     model.profile_enable(not args.no_profile)
     model.profile_select(None if args.profile_all else ROOFLINE_KERNEL + "," + GATHER_KERNEL)
     model.profile_reset()
-    elapsed = timed(args.steps, pool, args.read_cost_every)
+    times = main_leg.timed_repeats(args.steps, args.repeats, None, args.read_cost_every)
     final_cost = model.get_cost()
     prof_timed = model.profile()
     prof = prof_timed
-    breakdown_steps = args.steps
+    breakdown_steps = args.steps * len(times)
     if not args.no_profile and not args.profile_all:
         breakdown_steps = min(args.steps, 20)
         model.profile_select(None)
         model.profile_reset()
-        run_steps(breakdown_steps, pool)          # every rank takes part (the collectives are in the step)
-        sync_all()
+        main_leg.run_steps(breakdown_steps)          # every rank takes part (the collectives are in the step)
+        env.sync_all(model)
         prof = model.profile()
     model.profile_enable(False)
+    touched = main_leg.touched_rows() if rank == 0 and not args.no_profile else None
 
-    # ---- secondary legs, same model, same number of steps, no events -------------------------------------------
+    def leg_value(leg, batches=None, read_every=0, repeats=None):
+        """windows/s and ms per step of a secondary leg: median of `repeats` regions of --steps steps, all ranks' batches"""
+        ts = leg.timed_repeats(args.steps, repeats or min(args.repeats, 3), batches, read_every)
+        med, st = ms_stats(ts, args.steps)
+        return med, st
+
+    # ---- secondary legs: no events ----------------------------------------------------------------------------------
     extra = {}
-    if not args.no_extra_legs and not args.sequential and not args.gate_us:
+    if not quick:
         if world == 1:
             # (a) loss read back after EVERY step, as iterate_data does (cpp/main.cu:427-444; SURVEY §8d "with the loss read
             #     back every step")
-            run_steps(2, pool, 1)
-            dt = timed(args.steps, pool, 1)
-            extra["value_readback_every_step"] = round(B * args.steps / dt, 1)
+            main_leg.run_steps(2, None, 1)
+            med, _ = leg_value(main_leg, None, 1)
+            extra["value_readback_every_step"] = round(B * 1e3 / med, 1)
             # (b) page-locked HOST batches handed over each step: PCIe-inclusive (never `value`)
             if not args.host_batches:
-                hpool = make_pool(B, 1234, True)
-                run_steps(3, hpool)
-                dt = timed(args.steps, hpool)
-                extra["value_host_batches"] = round(B * args.steps / dt, 1)
-        elif B % world == 0:
-            # (c) strong split of the same global batch: 51 200 / N windows per rank (SURVEY §8d row 3, BASELINE configs[2])
-            Bs = B // world
-            spool = make_pool(Bs, 4321, args.host_batches)
-            run_steps(3, spool)
-            dt = timed(args.steps, spool)
-            extra["strong"] = {"value": round(B * args.steps / dt, 1), "unit": "windows/s", "ms_per_step": round(dt * 1e3 / args.steps, 4),
-                               "scaling": "strong", "global_batch": B, "batch_per_rank": Bs, "steps": args.steps}
+                hpool = main_leg.make_pool(1234, True)
+                main_leg.run_steps(3, hpool)
+                med, _ = leg_value(main_leg, hpool)
+                extra["value_host_batches"] = round(B * 1e3 / med, 1)
+                del hpool
+            # (c) uniform word ids on the same engine (SURVEY §8d: the worst case for the caches)
+            secondary = {}
+            if not args.uniform_words:
+                upool = main_leg.make_pool(777, args.host_batches, uniform=True)
+                main_leg.run_steps(3, upool)
+                med, st = leg_value(main_leg, upool)
+                secondary["uniform_words"] = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), **st)
+            # (d) the reference recipe's optimiser (scripts/functions.sh:395: --update_method full_adam) on an engine of its own
+            if args.config == "nvsm" and method != "full_adam":
+                leg = Leg(env, wl, "full_adam", B)
+                leg.run_steps(max(3, args.warmup))
+                med, st = leg_value(leg)
+                secondary["full_adam"] = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), **st)
+                del leg
+            if secondary:
+                extra["secondary"] = secondary
+            # (e) the per-rank share of the N-GPU metric (51 200 / N windows per rank, SURVEY §8d row 3) on this one GPU, each
+            #     on an engine created for that batch size as rank r of an N-GPU job would create it. Compute only.
+            if args.config == "nvsm" and Bg == 51200:
+                shapes = {}
+                for n in (8, 4, 2):
+                    leg = Leg(env, wl, method, Bg // n)
+                    leg.run_steps(max(10, args.warmup))
+                    med, st = leg_value(leg, repeats=3)
+                    shapes[str(Bg // n)] = dict(ms_per_step=round(med, 4), ranks=n, **st)
+                    del leg
+                extra["per_rank_shapes"] = shapes
+        else:
+            # the other scaling figure of the same run: weak (51 200 windows per rank) beside a strong headline, or the
+            # strong split (SURVEY §8d row 3, BASELINE configs[2]) beside a weak one
+            other_B = Bg if headline_strong else (Bg // world if strong_ok else None)
+            if other_B:
+                leg = Leg(env, wl, method, other_B, uniform_words=args.uniform_words, host_batches=args.host_batches,
+                          seed=1234 if headline_strong else 4321)
+                leg.run_steps(2 + max(3, args.warmup))
+                med, st = leg_value(leg)
+                total = other_B * world if headline_strong else Bg
+                fig = dict(value=round(total * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4),
+                           scaling="weak" if headline_strong else "strong", global_batch=total, batch_per_rank=other_B,
+                           steps=args.steps, **st)
+                extra["weak" if headline_strong else "strong"] = fig
+                del leg
 
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        value = B * world * args.steps / elapsed
-        weak = {"value": round(value, 1), "unit": "windows/s", "ms_per_step": round(ms_per_step, 4), "scaling": "weak",
-                "global_batch": B * world, "batch_per_rank": B, "steps": args.steps}
-        scaling = "weak"
-        if args.strong_scaling and "strong" in extra:
-            value, ms_per_step, scaling = extra["strong"]["value"], extra["strong"]["ms_per_step"], "strong"
+        ms_per_step, tstats = ms_stats(times, args.steps)
+        global_batch = Bg if (headline_strong or world == 1) else Bg * world
+        value = global_batch * 1e3 / ms_per_step
+        scaling = "strong" if headline_strong else "weak"
+        this_fig = dict(value=round(value, 1), unit="windows/s", ms_per_step=round(ms_per_step, 4), scaling=scaling,
+                        global_batch=global_batch, batch_per_rank=B, steps=args.steps, **tstats)
+        # a lazily decayed table's row passes only read and write the rows the batch touches (the engine notes a
+        # `lazy_stamp_<table>` launch per update of such a table)
+        rows = {}
+        if touched:
+            for t in ("words", "entities"):
+                if prof.get("lazy_stamp_" + t, (0, 0))[1] > 0:
+                    rows[t] = touched[t]
         # dominant kernel group and its roofline
         breakdown = {}
         for k, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
@@ -423,11 +542,18 @@ def main():
                 continue
             avg = ms / n
             ent = {"avg_ms": round(avg, 4), "launches_per_step": round(n / breakdown_steps, 2)}
-            ab = algorithmic_bytes(k, wl, method)
+            if ms == 0.0:                       # a path note of the engine (which walk a table pass took), not a timing
+                breakdown[k] = {"launches_per_step": ent["launches_per_step"], "note": True}
+                continue
+            ab = algorithmic_bytes(k, wl, method, B, rows)
             if ab:
                 ent["algorithmic_GBps"] = round(ab / (avg * 1e-3) / 1e9, 1)
+                if ent["algorithmic_GBps"] > HBM_PEAK_GBS:
+                    # more algorithmic bytes per second than HBM can deliver: the gathered rows repeat within the batch and
+                    # are served by L2 / the Infinity Cache (the PMC summaries under profiles/ show the HBM bytes)
+                    ent["served_from_cache"] = True
             if k.startswith("gemm_"):
-                ent["TFLOPs"] = round(gemm_flops(wl) / (avg * 1e-3) / 1e12, 1)
+                ent["TFLOPs"] = round(gemm_flops(wl, B) / (avg * 1e-3) / 1e12, 1)
                 ent["mfma_frac"] = round(ent["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 3)      # of the 157.3 TF/s fp32 MFMA peak
             breakdown[k] = ent
         # Roofline kernel: the document-embedding gather + loss kernel — the HBM gather the north star names, and the
@@ -439,15 +565,16 @@ def main():
                 breakdown[k]["overlapped"] = True
         have = lambda k: prof_timed.get(k, (0, 0))[1] > 0
         roofline = roofline_gather = None
-        sig = workload_signature(wl, method, args.uniform_words)
+        sig = workload_signature(wl, method, args.uniform_words, B)
         if have(ROOFLINE_KERNEL):
             dom = ROOFLINE_KERNEL
-            ab = algorithmic_bytes(dom, wl, method)
-            avg = round(prof_timed[dom][0] / prof_timed[dom][1], 4)      # HIP events inside the timed region
+            ab = algorithmic_bytes(dom, wl, method, B)
+            avg = round(prof_timed[dom][0] / prof_timed[dom][1], 4)      # HIP events inside the timed regions
             ach = ab / (avg * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(dom, sig)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "traffic_measured_in_run": False,      # counters cannot be read in-process: a committed rocprofv3 summary of this workload, or null
                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg,
                         "bytes": "document gather B*(k+1)*d_doc*4 + pre/proj/dy 3*B*d_doc*4"}
             if have(GATHER_KERNEL):
@@ -461,32 +588,49 @@ def main():
                                    "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBS, 4), "traffic": None,
                                    "algorithmic_bytes_per_step": gb, "bytes_per_window": gb // B, "avg_ms": round(t2, 4),
                                    "doc_gather_only_frac": round(B * R * wl["entity_dim"] * 4 / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                # the same two kernels on COUNTER bytes (what HBM actually delivered: the word rows repeat within a batch and
+                # mostly come out of L2): committed PMC summary of this workload over this run's kernel times
+                tw, _ = pmc_traffic(GATHER_KERNEL, sig)
+                if traffic is not None and tw is not None:
+                    ach3 = (traffic + tw) / (t2 * 1e-3) / 1e9
+                    roofline_gather["counter_bytes"] = {"traffic": traffic + tw, "achieved": round(ach3, 1),
+                                                        "frac": round(ach3 / HBM_PEAK_GBS, 4), "traffic_source": traffic_src,
+                                                        "traffic_measured_in_run": False}
         out = {
-            "metric": "n-gram windows/sec (batch=51200, NVSM config)" if args.config == "nvsm" and B == 51200
-                      else "n-gram windows/sec (--config %s, batch=%d)" % (args.config, B), "value": round(value, 1), "unit": "windows/s",
+            "metric": "n-gram windows/sec (batch=51200, NVSM config)" if args.config == "nvsm" and Bg == 51200
+                      else "n-gram windows/sec (--config %s, batch=%d)" % (args.config, Bg), "value": round(value, 1), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s synthetic |V|=%d |D|=%d d_word=%d d_doc=%d window=%d neg=%d batch=%d/GPU "
+            "config": {"workload": "%s synthetic |V|=%d |D|=%d d_word=%d d_doc=%d window=%d neg=%d global batch=%d (%d/GPU) "
                                    "%s%s %s lambda=1e-2 lr=%g %s word ids, inputs %s, device negative sampler"
                                    % ("NVSM" if wl["batch_norm"] else "LSE", wl["num_words"], wl["num_entities"], wl["word_dim"],
-                                      wl["entity_dim"], w, wl["num_random"], B,
+                                      wl["entity_dim"], w, wl["num_random"], global_batch, B,
                                       wl["nonlinearity"], "+BN" if wl["batch_norm"] else "", method, wl["lr"],
                                       "uniform" if args.uniform_words else "Zipf(1)",
                                       "handed over as page-locked host buffers" if args.host_batches else "resident in HBM"),
-                       "global_batch": B * world if scaling == "weak" else B, "parallelism": "dp%d" % world, "update_method": method,
-                       "collectives": transport, "comm_ranks": comm_ranks,
+                       "global_batch": global_batch, "batch_per_rank": B, "parallelism": "dp%d" % world, "update_method": method,
+                       "collectives": main_leg.transport, "comm_ranks": main_leg.comm_ranks,
                        "inputs": "host" if args.host_batches else "hbm", "step": "sequential calls" if args.sequential else "fused nvsm_step",
                        "workload_signature": sig},
+            "timing": tstats,
             "roofline": roofline,
             "roofline_gather": roofline_gather,
             "kernel_breakdown": breakdown,
-            "kernel_breakdown_source": ("timed region" if args.profile_all else
+            "kernel_breakdown_source": ("timed regions" if args.profile_all else
                                         "separate untimed pass of %d steps with events around every kernel group" % breakdown_steps),
+            "rows_touched_per_batch": touched,
             "final_cost": round(float(final_cost), 6),
         }
         if world > 1:
-            out["weak"] = weak
+            out[scaling] = this_fig
         out.update(extra)
+        if "per_rank_shapes" in extra and "6400" in extra["per_rank_shapes"]:
+            # what 8 ranks would deliver on the metric's 51 200-window batch if the per-rank step were all there is (three
+            # latency-bound all-reduces per step come on top: DESIGN.md §6): 8 x 6 400 windows per per-rank step
+            ms8 = extra["per_rank_shapes"]["6400"]["ms_per_step"]
+            out["strong_projection_8gpu"] = {"value": round(51200 * 1e3 / ms8, 1), "unit": "windows/s",
+                                             "speedup_over_1gpu": round(ms_per_step / ms8, 2),
+                                             "basis": "per_rank_shapes[6400] on one GPU, collectives excluded"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, wl, method)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -30,6 +30,10 @@ def _last_json(out):
     return json.loads(lines[0])
 
 
+def roof_ok(roof):
+    return roof["traffic_measured_in_run"] is False and (roof["traffic"] is None or roof["traffic_source"])
+
+
 def test_bench_single_gpu_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-steps", "1"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -38,6 +42,17 @@ def test_bench_single_gpu_line():
     assert REQUIRED <= set(d)
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f32"
     assert d["value"] > 1e6 and abs(d["value"] - 51200 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    # the median of `repeats` timed regions of exactly `steps` steps each, all of them in the line
+    t = d["timing"]
+    assert t["repeats"] == 5 and len(t["ms_per_step_all"]) == 5 and sorted(t["ms_per_step_all"])[2] == d["ms_per_step"]
+    # no row-pass figure above what HBM can deliver without being marked as cache-served
+    for k, e in d["kernel_breakdown"].items():
+        assert e.get("algorithmic_GBps", 0) <= 8000.0 or e.get("served_from_cache"), (k, e)
+    assert roof_ok(d["roofline"])
+    # the per-rank shapes of the 8-GPU metric, the reference recipe's optimiser and the uniform worst case ride along
+    assert set(d["per_rank_shapes"]) == {"6400", "12800", "25600"} and d["per_rank_shapes"]["6400"]["ms_per_step"] > 0
+    assert d["strong_projection_8gpu"]["speedup_over_1gpu"] > 1.0
+    assert d["secondary"]["full_adam"]["value"] > 1e6 and d["secondary"]["uniform_words"]["value"] > 1e6
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.3 < roof["frac"] < 1.0
@@ -54,7 +69,10 @@ def test_bench_two_ranks_control_flow():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 51200 and d["config"]["parallelism"] == "dp2"
+    # the metric says batch = 51 200: the headline is the strong split (25 600 windows per rank), the weak figure rides along
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 51200 and d["config"]["batch_per_rank"] == 25600
+    assert d["scaling"] == "strong" and d["config"]["parallelism"] == "dp2"
     assert d["cpu_baseline"] is None
-    assert abs(d["value"] - 2 * 51200 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    assert abs(d["value"] - 51200 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    assert d["strong"]["value"] == d["value"] and d["weak"]["global_batch"] == 2 * 51200 and d["weak"]["batch_per_rank"] == 51200
     assert d["final_cost"] == d["final_cost"] and d["final_cost"] > 0          # finite global loss

@@ -45,10 +45,13 @@ def test_bench_two_ranks_on_one_gpu_reports_weak_and_strong():
     callback transport): self-launch, both legs, one JSON line. Not a measurement."""
     out = _run(["--gpus", "2", "--test-shared-gpu", "--steps", "3", "--warmup", "1", "--batch", "2048", "--num-words", "5000",
                 "--num-entities", "4000", "--no-cpu-baseline"])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["weak"]["batch_per_rank"] == 2048 and out["weak"]["global_batch"] == 4096
-    assert out["strong"]["batch_per_rank"] == 1024 and out["strong"]["global_batch"] == 2048 and out["strong"]["value"] > 0
-    assert out["strong"]["scaling"] == "strong"
+    assert out["strong"]["batch_per_rank"] == 1024 and out["strong"]["global_batch"] == 2048 and out["strong"]["value"] == out["value"]
+    assert out["strong"]["scaling"] == "strong" and out["weak"]["scaling"] == "weak"
+    weak = _run(["--gpus", "2", "--test-shared-gpu", "--steps", "3", "--warmup", "1", "--batch", "2048", "--num-words", "5000",
+                 "--num-entities", "4000", "--no-cpu-baseline", "--weak-scaling", "--repeats", "1"])
+    assert weak["scaling"] == "weak" and weak["config"]["global_batch"] == 4096 and weak["strong"]["batch_per_rank"] == 1024
     assert out["roofline"]["traffic"] is None            # no PMC profile of THIS workload: no traffic claim
     assert "gloo" in out["config"]["collectives"]
 

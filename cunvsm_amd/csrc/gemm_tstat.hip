@@ -21,6 +21,7 @@
 #include "kernels.h"
 #include "device_utils.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace cunvsm {
@@ -31,6 +32,7 @@ constexpr int kTstatWaves = 8;
 constexpr int kTstatThreads = kTstatWaves * 64;
 constexpr int kTstatMaxParts = 4;
 constexpr size_t kTstatLdsBytes = 163840;
+constexpr int kTstatMaxDevices = 64;
 
 struct TstatArgs {
     const float* A; const float* B; float* C;
@@ -297,17 +299,23 @@ __global__ __launch_bounds__(kTstatThreads) void gemm_tstat_kernel(TstatArgs g) 
 
 template <int KG, int NT, int BLAY, bool MIXED, int EPI>
 static bool tstat_launch_epi(const TstatArgs& g, size_t lds, int wgs, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the opt-in to more than 64 KB of dynamic LDS is per DEVICE (a process may hold handles on several GPUs), and several
+    // host threads may come through here at once: one flag per device ordinal, set after the call that it stands for
+    static std::atomic<bool> attr_set[kTstatMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kTstatMaxDevices) return false;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tstat_kernel<KG, NT, BLAY, MIXED, EPI>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kTstatLdsBytes)) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
+    (void)hipGetLastError();
     NVSM_LAUNCH((gemm_tstat_kernel<KG, NT, BLAY, MIXED, EPI>), dim3(wgs), dim3(kTstatThreads), lds, s, g);
-    return true;
+    // a launch the device refuses (LDS opt-in missing, ...) is reported here, so that launch_gemm can fall back to the tiled kernel
+    return hipGetLastError() == hipSuccess;
 }
 
 // the forward product carries batch-norm column sums or a bias, the backward one row sums of squares or nothing
@@ -361,17 +369,25 @@ bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* 
         if (need <= kTstatLdsBytes) { parts = p; NT = nt; break; }
     }
     if (!parts) return false;
-    static const int num_cus = [] {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }();
-    static float* dump[64] = {};
+    // per device ordinal: the CU count that sizes the grid and the 16 bytes nobody reads
+    static std::atomic<int> cus_of[kTstatMaxDevices];
+    static std::atomic<float*> dump[kTstatMaxDevices];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    if (!dump[dev] && hipMalloc(reinterpret_cast<void**>(&dump[dev]), 256) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kTstatMaxDevices) return false;
+    int num_cus = cus_of[dev].load(std::memory_order_acquire);
+    if (num_cus == 0) {
+        hipDeviceProp_t prop;
+        num_cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus_of[dev].store(num_cus, std::memory_order_release);
+    }
+    if (!dump[dev].load(std::memory_order_acquire)) {
+        float* fresh = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&fresh), 256) != hipSuccess) { (void)hipGetLastError(); return false; }
+        float* expected = nullptr;
+        if (!dump[dev].compare_exchange_strong(expected, fresh, std::memory_order_acq_rel)) (void)hipFree(fresh);      // another thread was first
+    }
     TstatArgs g{};
-    g.dump = dump[dev];
+    g.dump = dump[dev].load(std::memory_order_acquire);
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = alpha; g.bias_n = bias_n; g.colstats = colstats; g.rowsq = rowsq; g.rowsq_scale = rowsq_scale;
     g.parts = parts; g.nblocks = (M + 15) / 16;

@@ -626,34 +626,51 @@ void Model::allreduce_f32(float* dev, int64_t n, hipStream_t strm) {
 // no other branch applies) is   scaling = urng_range / n;  past = n · scaling;  do r = g() − g.min(); while (r ≥ past);
 // return r / scaling;   and minstd_rand0 is x ← 16807·x mod (2^31 − 1). tests/test_gpu_parity.py compares it with the std:: calls.
 void Model::draw_reference_negatives(const int64_t* labels, int64_t B, int64_t* ids) {
+    // Data parallel: the ranks hold copies of ONE generator state (the trainer hands every rank the same stream), and rank r
+    // trains on instances [r·B, (r+1)·B) of the global batch. Every rank therefore replays the draws of the WHOLE global batch
+    // — world_size · B · k of them, in instance order — and keeps the ones of its own slice: each instance gets the negatives
+    // the single-GPU run would have given it, no two ranks share a negative set, and the generators stay in step across the
+    // ranks (they also shuffle the data source). Costs world_size x the draws per rank: this is the parity sampler.
+    const int64_t before = (cfg_.world_size > 1) ? static_cast<int64_t>(cfg_.rank) * B : 0;
+    const int64_t after = (cfg_.world_size > 1) ? static_cast<int64_t>(cfg_.world_size - 1 - cfg_.rank) * B : 0;
+    const int k = R_ - 1;
     const uint64_t n = static_cast<uint64_t>(cfg_.num_entities);
     constexpr uint64_t kMod = 2147483647ull, kRange = kMod - 2;          // max() − min() = 2147483646 − 1
     if (n > kRange) {                                                     // not the downscaling branch: leave it to libstdc++
+        auto draw = [&] { return std::uniform_int_distribution<long>(0, cfg_.num_entities - 1)(rng_); };
+        for (int64_t i = 0; i < before * k; ++i) (void)draw();
         for (int64_t i = 0; i < B; ++i) {
             ids[i * R_] = labels[i];
-            for (int r = 1; r < R_; ++r) ids[i * R_ + r] = std::uniform_int_distribution<long>(0, cfg_.num_entities - 1)(rng_);
+            for (int r = 1; r < R_; ++r) ids[i * R_ + r] = draw();
         }
+        for (int64_t i = 0; i < after * k; ++i) (void)draw();
         return;
     }
     std::stringstream ss; ss << rng_;
     uint64_t x = 0; ss >> x;
     const uint64_t scaling = kRange / n, past = n * scaling;
     const double inv = 1.0 / static_cast<double>(scaling);
+    auto draw = [&]() -> uint64_t {
+        uint64_t ret;
+        do {
+            const uint64_t p = x * 16807ull;                          // < 2^46
+            x = (p & kMod) + (p >> 31);                               // mod 2^31 − 1
+            if (x >= kMod) x -= kMod;
+            ret = x - 1;
+        } while (ret >= past);
+        return ret;
+    };
+    for (int64_t i = 0; i < before * k; ++i) (void)draw();              // (the quotient is not needed to advance the state)
     for (int64_t i = 0; i < B; ++i) {
         ids[i * R_] = labels[i];
         for (int r = 1; r < R_; ++r) {
-            uint64_t ret;
-            do {
-                const uint64_t p = x * 16807ull;                          // < 2^46
-                x = (p & kMod) + (p >> 31);                               // mod 2^31 − 1
-                if (x >= kMod) x -= kMod;
-                ret = x - 1;
-            } while (ret >= past);
+            const uint64_t ret = draw();
             uint64_t q = static_cast<uint64_t>(static_cast<double>(ret) * inv);      // ret / scaling, fixed up to be exact
             if ((q + 1) * scaling <= ret) ++q; else if (q * scaling > ret) --q;
             ids[i * R_ + r] = static_cast<int64_t>(q);
         }
     }
+    for (int64_t i = 0; i < after * k; ++i) (void)draw();
     rng_.seed(static_cast<std::minstd_rand0::result_type>(x));          // 1 ≤ x < 2^31 − 1: seed() stores it unchanged
 }
 
@@ -726,7 +743,10 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
                 static const bool use_pull = [] { const char* e = std::getenv("NVSM_HOST_PULL"); return !(e && e[0] == '0'); }();
                 void* dev_view = nullptr;
                 hipPointerAttribute_t at{};
-                if (use_pull && bytes % 4 == 0 && hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost &&
+                // (the pull kernel reads 16 bytes per lane: a source that is only element-aligned — a slice of a page-locked
+                //  batch at an odd instance offset — takes the copy engine instead)
+                if (use_pull && bytes % 4 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
+                    hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost &&
                     hipHostGetDevicePointer(&dev_view, const_cast<void*>(src), 0) == hipSuccess && dev_view) {
                     pull.dst[pull.count] = dst; pull.src[pull.count] = dev_view; pull.bytes[pull.count] = bytes; ++pull.count;
                 } else {
@@ -809,6 +829,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         // (the documents table has two sets of CSR arrays: its build does not wait for the previous documents update)
         if (se != aux_stream_ && E_pending_ && ents_.idx_sets < 2) NVSM_HIP_CHECK(hipStreamWaitEvent(se, ev_E_done_, 0));
         csr_joined_ents_ = csr_joined_words_ = false;
+        words_csr_stream_ = sw;
         auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, ids_.p, N, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
         auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, widx_.p, B * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
         if (layout == 1) { wrds(); ents(); } else { ents(); wrds(); }
@@ -1411,7 +1432,10 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     // with entries — disjoint rows — but behind the projection update on side stream 2, which built this CSR and is idle by
     // then; the next step's word gather joins that stream (LSE batch 4096: 14-17 us of a 0.2 ms step). NVSM_UNTOUCHED_ASIDE=0: off.
     static const bool untouched_aside = [] { const char* e = std::getenv("NVSM_UNTOUCHED_ASIDE"); return !(e && e[0] == '0'); }();
-    const bool words_aside = untouched_aside && !dp && !words_.lazy && row_pass_split(csr_of(words_, B_ * cfg_.window_size));
+    // (only when side stream 2 is the stream that built the words CSR: the untouched pass reads its row bounds, and the next
+    //  step's sort on that stream clears them — a pass queued on any other stream would have neither order)
+    const bool words_aside = untouched_aside && !dp && !words_.lazy && words_csr_stream_ == aux2_stream_ &&
+                             row_pass_split(csr_of(words_, B_ * cfg_.window_size));
     words_untouched_stream_ = words_aside ? aux2_stream_ : nullptr;
     update_words(lr, sl);
     words_untouched_stream_ = nullptr;

@@ -206,6 +206,7 @@ class Model {
     hipEvent_t ev_gathered_ = nullptr;
     hipEvent_t ev_loss_ = nullptr, ev_dx_ = nullptr, ev_bwdx_ = nullptr, ev_E_done_ = nullptr, ev_T_done_ = nullptr;
     hipEvent_t ev_csr_all_ = nullptr;           // both tables' CSR builds of this step are done (recorded on the words build's stream)
+    hipStream_t words_csr_stream_ = nullptr;            // the side stream that built this step's words CSR (NVSM_SORT_LAYOUT)
     hipStream_t words_untouched_stream_ = nullptr;      // set by step() around update_words (kernels.h launch_table_pass untouched_s)
     bool words_tail_pending_ = false;                   // side stream 2 still decays words rows: the next word gather joins it
     hipStream_t dx_follower_ = nullptr;                 // set by step(): the stream that waits for ev_dx_ (issued inside backward_dx)

@@ -30,6 +30,7 @@
 #include "hdf5_writer.hpp"
 #include "index_source.hpp"
 #include "indri_index.hpp"
+#include "rendezvous.hpp"
 #include "trectext_index.hpp"
 
 using namespace nvsm_host;
@@ -46,7 +47,7 @@ bool FLAGS_bias_negative_samples, FLAGS_l2_phrase_normalization, FLAGS_l2_entity
     FLAGS_include_oov, FLAGS_compute_initial_cost, FLAGS_check_gradients, FLAGS_no_shuffle, FLAGS_dump_initial_model,
     FLAGS_allow_ragged_batches, FLAGS_logtostderr, FLAGS_alsologtostderr;
 int64_t FLAGS_dump_every, FLAGS_v, FLAGS_device, FLAGS_minloglevel, FLAGS_gpus, FLAGS_world_size, FLAGS_rank;
-std::string FLAGS_comm_id_file;
+std::string FLAGS_comm_id_file, FLAGS_comm_nonce;
 
 void define_flags(Flags* f) {      // names, defaults and help strings of cpp/main.cu:15-76
     f->define_uint64("num_epochs", &FLAGS_num_epochs, 100000, "Number of training iterations.");
@@ -93,7 +94,9 @@ void define_flags(Flags* f) {      // names, defaults and help strings of cpp/ma
     f->define_int64("world_size", &FLAGS_world_size, 0, "Data-parallel ranks when an external launcher starts them (default: WORLD_SIZE, else 1).");
     f->define_int64("rank", &FLAGS_rank, -1, "This process's rank (default: RANK, else 0).");
     f->define_string("comm_id_file", &FLAGS_comm_id_file, "", "File through which rank 0 hands the RCCL unique id to the other ranks "
-                     "(default: /tmp/cunvsm_comm_<MASTER_PORT or parent pid>).");
+                     "(default: comm_<hash of the run's nonce> in $XDG_RUNTIME_DIR or /tmp/cunvsm-<uid>, a directory private to the user).");
+    f->define_string("comm_nonce", &FLAGS_comm_nonce, "", "What names this run to all of its ranks (default: the launcher's run id, else "
+                     "parent pid + MASTER_PORT; --gpus N hands its children a random one). A rendezvous file with another nonce is ignored.");
     f->define_string("sampler", &FLAGS_sampler, "host", "Negative sampler: host (minstd_rand0, draw-for-draw the reference) or device.");
     f->define_bool("allow_ragged_batches", &FLAGS_allow_ragged_batches, false, "Train on batches whose size is not a multiple of 1024 instead of skipping them as the reference does.");
     // glog's own options that the reference's scripts pass
@@ -389,8 +392,11 @@ int run(int argc, char** argv) {
         if (nvsm_device_count() < FLAGS_gpus) NVSM_LOG(FATAL) << "--gpus " << FLAGS_gpus << " but only " << nvsm_device_count() << " HIP device(s) are visible.";
         // re-execute this binary once per GPU with explicit --world_size / --rank / --device / --comm_id_file (the children
         // initialise HIP themselves; the parent only waits)
-        const std::string id_file = FLAGS_comm_id_file.empty() ? "/tmp/cunvsm_comm_" + std::to_string(getpid()) : FLAGS_comm_id_file;
-        std::remove(id_file.c_str());
+        // a nonce of this launch: a rendezvous file any earlier run left behind cannot carry it
+        const std::string nonce = FLAGS_comm_nonce.empty()
+            ? "gpus:" + std::to_string(static_cast<long long>(getpid())) + ":" + std::to_string(static_cast<long long>(wall_clock_ns())) : FLAGS_comm_nonce;
+        const std::string id_file = FLAGS_comm_id_file.empty() ? default_comm_id_path(nonce) : FLAGS_comm_id_file;
+        rendezvous_clear(id_file);
         std::vector<pid_t> kids;
         for (int64_t r = 0; r < FLAGS_gpus; ++r) {
             const pid_t pid = fork();
@@ -399,6 +405,7 @@ int run(int argc, char** argv) {
                 std::vector<std::string> av(argv, argv + argc);
                 av.push_back("--world_size=" + std::to_string(FLAGS_gpus)); av.push_back("--rank=" + std::to_string(r));
                 av.push_back("--device=" + std::to_string(r)); av.push_back("--comm_id_file=" + id_file);
+                av.push_back("--comm_nonce=" + nonce);
                 std::vector<char*> cav;
                 for (std::string& a : av) cav.push_back(&a[0]);
                 cav.push_back(nullptr);
@@ -417,6 +424,12 @@ int run(int argc, char** argv) {
     const int rank = static_cast<int>(FLAGS_rank >= 0 ? FLAGS_rank : env_int("RANK", 0));
     NVSM_CHECK(world_size >= 1 && rank >= 0 && rank < world_size) << "bad --world_size / --rank";
     if (FLAGS_device < 0) FLAGS_device = world_size > 1 ? env_int("LOCAL_RANK", rank) : 0;
+    // RCCL bootstrap file (rendezvous.hpp): rank 0 removes whatever an earlier run left under the name FIRST THING — before
+    // the minutes it spends indexing the collection, and long before any other rank of this run looks for the file
+    const int64_t process_start_ns = wall_clock_ns();
+    const std::string comm_nonce = world_size > 1 ? comm_run_nonce(FLAGS_comm_nonce) : std::string();
+    const std::string comm_id_file = world_size > 1 ? (FLAGS_comm_id_file.empty() ? default_comm_id_path(comm_nonce) : FLAGS_comm_id_file) : std::string();
+    if (world_size > 1 && rank == 0) rendezvous_clear(comm_id_file);
     if (world_size > 1) {
         NVSM_CHECK(FLAGS_batch_size % static_cast<uint64_t>(world_size) == 0) << "--batch_size must be a multiple of the number of ranks.";
         NVSM_CHECK(!FLAGS_check_gradients) << "--check_gradients is a single-GPU diagnostic.";
@@ -528,28 +541,28 @@ int run(int argc, char** argv) {
     nvsm_model* model = nullptr;
     NVSM_CALL(nvsm_create(&cfg, &model));
     if (world_size > 1) {
-        // RCCL bootstrap without a rendezvous service: rank 0 publishes the 128-byte ncclUniqueId through a file (written
-        // under a temporary name and renamed, so a reader never sees half of it); ncclCommInitRank is itself a barrier, so
-        // once it returns on rank 0 every rank has read the file and it can go.
-        std::string id_file = FLAGS_comm_id_file;
-        if (id_file.empty()) id_file = "/tmp/cunvsm_comm_" + std::to_string(env_int("MASTER_PORT", static_cast<int64_t>(getppid())));
-        char id[128];
+        // RCCL bootstrap without a rendezvous service: rank 0 publishes the 128-byte ncclUniqueId through a file (rendezvous.hpp:
+        // private directory, exclusive create, no links followed, written under a temporary name and renamed so that a reader
+        // never sees half of it); the readers only accept a file of their own user that carries this run's nonce and was
+        // created after they themselves started (minus the skew between the ranks' start-ups). ncclCommInitRank is itself a
+        // barrier, so once it returns on rank 0 every rank has read the file and it can go.
+        const std::string& id_file = comm_id_file;
+        char id[kCommIdBytes];
         if (rank == 0) {
             NVSM_CALL(nvsm_comm_unique_id(id));
-            const std::string tmp = id_file + ".tmp";
-            { std::ofstream f(tmp, std::ios::binary); f.write(id, 128); NVSM_CHECK(f.good()) << "cannot write " << tmp; }
-            NVSM_CHECK(std::rename(tmp.c_str(), id_file.c_str()) == 0) << "cannot publish " << id_file;
+            rendezvous_publish(id_file, comm_nonce, id);
         } else {
             bool got = false;
+            std::string why;
+            const int64_t not_before = process_start_ns - int64_t(120) * 1000000000;      // ranks of one launch start within two minutes
             for (int tries = 0; tries < 6000 && !got; ++tries) {       // up to 10 minutes: rank 0 may still be indexing the collection
-                std::ifstream f(id_file, std::ios::binary);
-                if (f.good() && f.read(id, 128) && f.gcount() == 128) got = true;
-                else std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                got = rendezvous_read(id_file, comm_nonce, not_before, id, &why);
+                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
             }
-            NVSM_CHECK(got) << "rank " << rank << ": no RCCL id appeared in " << id_file;
+            NVSM_CHECK(got) << "rank " << rank << ": no RCCL id for this run appeared in " << id_file << " (the file " << why << ")";
         }
         NVSM_CALL(nvsm_comm_init(model, id));
-        if (rank == 0) std::remove(id_file.c_str());
+        if (rank == 0) rendezvous_clear(id_file);
         int ranks = 0;
         NVSM_CALL(nvsm_comm_size(model, &ranks));
         NVSM_LOG(INFO) << "Data parallel: rank " << rank << " of " << world_size << " on device " << FLAGS_device << " (RCCL communicator of " << ranks

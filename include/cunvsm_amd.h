@@ -208,7 +208,13 @@ int nvsm_synchronize(nvsm_model* m);
  * end of every epoch and before every model dump, so that what rank 0 writes carries every rank's updates. A caller
  * that checkpoints one rank without it drops the other ranks' embedding updates.
  * nvsm_get_cost with world_size > 1 is a collective when called before nvsm_compute_gradients (it all-reduces a copy of
- * the loss word); every rank must make the same sequence of calls. */
+ * the loss word); every rank must make the same sequence of calls.
+ * NEGATIVES with world_size > 1: rank r is taken to hold instances [r·B, (r+1)·B) of a global batch of world_size·B.
+ * NVSM_SAMPLER_HOST_MINSTD: every rank replays the draws of the WHOLE global batch from its copy of the shared generator
+ * (nvsm_rng_set_state: the same state on every rank, as cuNVSMTrainModel hands it over) and keeps its own slice's — the
+ * negatives of an instance are those of the single-GPU run, ranks never share a negative set, and the generator states
+ * stay equal across ranks (world_size x the host draws per rank: this is the parity sampler). NVSM_SAMPLER_DEVICE: the
+ * counter-based sampler is keyed by (seed, rank, step, slot), so ranks draw independent streams. */
 int nvsm_comm_unique_id(char id[128]);
 int nvsm_comm_init(nvsm_model* m, const char id[128]);
 /* ncclCommCount of the handle's communicator (0 = none was built) */

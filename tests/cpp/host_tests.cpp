@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <functional>
 #include <set>
 #include <sstream>
@@ -13,6 +14,7 @@
 #include "../../cunvsm_amd/host/data.hpp"
 #include "../../cunvsm_amd/host/index_source.hpp"
 #include "../../cunvsm_amd/host/indri_index.hpp"
+#include "../../cunvsm_amd/host/rendezvous.hpp"
 #include "../../cunvsm_amd/host/trectext_index.hpp"
 
 using namespace nvsm_host;
@@ -526,6 +528,61 @@ static void test_IndriRepository_docno_lookups() {
     EXPECT_TRUE(by_docno == want_by_docno);
 }
 
+// ---- the RCCL id rendezvous of a data-parallel run (no reference counterpart: host/rendezvous.hpp) ----
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+static void test_Rendezvous() {
+    char dir_t[] = "/tmp/nvsm_rdv_XXXXXX";
+    const char* dir = mkdtemp(dir_t);
+    EXPECT_TRUE(dir != nullptr);
+    if (!dir) return;
+    const std::string path = std::string(dir) + "/comm", nonce = "run:abc";
+    char id[kCommIdBytes], got[kCommIdBytes];
+    for (int i = 0; i < kCommIdBytes; ++i) id[i] = static_cast<char>(i * 7 + 3);
+    std::string why;
+    const int64_t t0 = wall_clock_ns();
+    EXPECT_TRUE(!rendezvous_read(path, nonce, t0, got, &why));                    // nothing there yet
+    rendezvous_publish(path, nonce, id);
+    EXPECT_TRUE(rendezvous_read(path, nonce, t0, got, &why));
+    EXPECT_TRUE(std::memcmp(id, got, kCommIdBytes) == 0);
+    struct stat st;
+    EXPECT_TRUE(::stat(path.c_str(), &st) == 0 && (st.st_mode & 0777) == 0600);
+    // a leftover of an earlier run: older than this reader, or under another run's nonce
+    EXPECT_TRUE(!rendezvous_read(path, nonce, wall_clock_ns() + 1000000000, got, &why));
+    EXPECT_EQ(why, std::string("is older than this run"));
+    EXPECT_TRUE(!rendezvous_read(path, "run:other", t0, got, &why));
+    EXPECT_EQ(why, std::string("belongs to another run (nonce)"));
+    // what the old protocol wrote (the bare 128 bytes) is not taken for an id
+    rendezvous_clear(path);
+    { const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT, 0600); EXPECT_TRUE(fd >= 0 && ::write(fd, id, kCommIdBytes) == kCommIdBytes); ::close(fd); }
+    EXPECT_TRUE(!rendezvous_read(path, nonce, t0, got, &why));
+    // readable by others: somebody else could have written it
+    rendezvous_clear(path);
+    rendezvous_publish(path, nonce, id);
+    EXPECT_TRUE(::chmod(path.c_str(), 0644) == 0);
+    EXPECT_TRUE(!rendezvous_read(path, nonce, t0, got, &why));
+    EXPECT_EQ(why, std::string("is accessible to group / others"));
+    // a symbolic link in its place is not followed, by the reader or by the writer's temporary file
+    rendezvous_clear(path);
+    const std::string target = std::string(dir) + "/elsewhere";
+    rendezvous_publish(target, nonce, id);
+    EXPECT_TRUE(::symlink(target.c_str(), path.c_str()) == 0);
+    EXPECT_TRUE(!rendezvous_read(path, nonce, t0, got, &why));
+    EXPECT_EQ(why, std::string("is a symbolic link"));
+    rendezvous_publish(path, nonce, id);                                            // rename replaces the link itself
+    EXPECT_TRUE(::lstat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode));
+    EXPECT_TRUE(rendezvous_read(path, nonce, t0, got, &why));
+    // the default location is private to the user, and two runs (nonces) do not share a name
+    const std::string a = default_comm_id_path("ppid:1:port:29500"), b = default_comm_id_path("ppid:2:port:29500");
+    EXPECT_TRUE(a != b);
+    const std::string adir = a.substr(0, a.rfind('/'));
+    EXPECT_TRUE(::stat(adir.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & 077) == 0);
+    EXPECT_EQ(comm_run_nonce("given"), std::string("given"));
+    rendezvous_clear(path); rendezvous_clear(target);
+    ::rmdir(dir);
+}
+
 int main(int argc, char** argv) {
     log_to_stderr() = false;
     if (const char* e = std::getenv("NVSM_BROWN_INDEX")) g_brown_path = e;
@@ -550,6 +607,7 @@ int main(int argc, char** argv) {
         {"TrectextIndex.end_to_end", test_TrectextIndex},
         {"IndriSourceTest.Brown", test_IndriSource_Brown},
         {"IndriRepository.docno_lookups", test_IndriRepository_docno_lookups},
+        {"DataParallel.rendezvous_file", test_Rendezvous},
     };
     int failed_tests = 0;
     for (const auto& t : tests) {

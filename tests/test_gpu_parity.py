@@ -133,6 +133,56 @@ def test_host_sampler_replays_std_uniform_int_distribution(num_entities, seed):
         assert g.rng_state == rng.state
 
 
+@pytest.mark.parametrize("num_entities", [7, 100000])
+def test_host_sampler_data_parallel_slices_replay_the_global_batch(num_entities):
+    """world_size > 1 with the host sampler (include/cunvsm_amd.h, NEGATIVES): every rank starts from the SAME generator
+    state (the trainer hands it over) and holds instances [r·B, (r+1)·B) of the global batch. Rank r's negatives must be
+    those the single-GPU run draws for these instances — not the same set on every rank — and every rank's generator must
+    end where the single-GPU run's ends (it also shuffles the data source)."""
+    spec = dict(num_words=5, num_entities=num_entities, word_dim=1, entity_dim=1, window=1, num_random=6)
+    G, B = 3, 130
+    one = gpu_model(spec, G * B, sampler=ca.SAMPLER_HOST_MINSTD)
+    ranks = [gpu_model(spec, B, sampler=ca.SAMPLER_HOST_MINSTD, world_size=G, rank=r, sync_batch_norm=0) for r in range(G)]
+    rs = np.random.RandomState(5)
+    state = 12345
+    for _ in range(2):
+        words, ww, labels, iw, _ = random_batch(spec, rs, G * B)
+        one.rng_state = state
+        one.compute_cost(ca.Batch(words, labels, ww, iw))
+        want = one.get_tensor("entity_ids").astype(np.int64).reshape(G, B, -1)
+        for r, m in enumerate(ranks):
+            m.rng_state = state
+            sl = slice(r * B, (r + 1) * B)
+            m.compute_cost(ca.Batch(words[sl], labels[sl], ww[sl], iw[sl]))
+            np.testing.assert_array_equal(m.get_tensor("entity_ids").astype(np.int64).reshape(B, -1), want[r])
+            assert m.rng_state == one.rng_state
+        assert len({want[r][:, 1:].tobytes() for r in range(G)}) == G          # no two ranks share a negative set
+        state = one.rng_state
+
+
+def test_page_locked_source_at_an_odd_offset():
+    """A host batch that is a slice of a page-locked buffer starting 8 / 4 bytes into it (a data-parallel rank's share at an
+    odd instance offset): only 16-byte aligned sources go through the PCIe pull kernel, anything else through the copy
+    engine — same step either way."""
+    spec = dict(SPECS["nvsm"], update_method="sgd")
+    B = 257
+    rs = np.random.RandomState(3)
+    params = random_params(spec, rs)
+    a, b = gpu_model(spec, B), gpu_model(spec, B)
+    for m in (a, b):
+        load_params(m, params, True)
+    words, ww, labels, iw, ids = random_batch(spec, rs, B)
+    w = spec["window"]
+    pins = [ca.model.pinned_copy(np.concatenate([x[:1], x])) for x in (words, labels, ww, iw)]       # one element of padding in front
+    off = ca.Batch(pins[0].array[1:], pins[1].array[1:], pins[2].array[1:], pins[3].array[1:])
+    assert off.features.ctypes.data % 16 == 8 and off.feature_weights.ctypes.data % 16 == 4 and off.features.size == B * w
+    ca_cost = a.step(ca.Batch(words, labels, ww, iw), 1e-2, entity_ids=ids, want_cost=True)
+    cb_cost = b.step(off, 1e-2, entity_ids=ids, want_cost=True)
+    assert ca_cost == cb_cost
+    for n in PARAMS:
+        np.testing.assert_array_equal(a.get_param(n), b.get_param(n))
+
+
 # ---------------------------------------------------------------------------------------------
 # the reference's own end-to-end KAT (cpp/model_tests.cu:341-466) through the HIP path
 # ---------------------------------------------------------------------------------------------

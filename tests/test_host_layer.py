@@ -30,6 +30,7 @@ CASES = [
     "IndriSourceTest.StochasticIndriSource_SelfInformation",
     "MetaSourceTest.AsyncSource", "MetaSourceTest.RepeatingSource",
     "Base.utils", "Batch.swap", "Metadata.roundtrip", "TrectextIndex.end_to_end", "IndriSourceTest.Brown", "IndriRepository.docno_lookups",
+    "DataParallel.rendezvous_file",
 ]
 
 

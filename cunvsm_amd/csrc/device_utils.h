@@ -74,6 +74,96 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
     unsafeAtomicAdd(p, v);
 }
 
+// ---- hand-over of values between workgroups of ONE launch --------------------------------------------------------------
+// The XCDs' L2s are not coherent with each other inside a kernel. A value that another workgroup of the same launch will read
+// travels as agent-scope atomic stores / loads (write-through, cache-bypassing) — no release / acquire fence, which would
+// write back and invalidate whole caches under the step's bandwidth-bound kernels. The writer waits for its stores
+// (s_waitcnt vmcnt(0)) before it bumps the arrival counter that tells the others.
+__device__ __forceinline__ void st_agent1(float* p, float x) {
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent1(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent_f64(double* p, double x) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(__double_as_longlong(x)), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent_f64(const double* p) {
+    return __longlong_as_double(static_cast<long long>(
+        __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<double*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+}
+
+// Ordered grid-wide sum: `total` workgroups each contribute a vector of n floats (val(i)); out(i, Σ) receives the sums.
+// Replaces one fp64 atomicAdd per value and workgroup (column statistics of the batch-norm / bias gradient, the loss word):
+// atomics add in arrival order, so the last bits differed from run to run, and a thousand workgroups adding to the same
+// 513 addresses serialise in the L2's atomic units (a quarter of the loss kernel's time at batch 6 400). Here a workgroup
+// stores its vector, bumps the arrival counter of its group of `fan` workgroups, and whoever arrives LAST — nobody waits —
+// adds the group's vectors in member order (in double); the last group to finish adds the group sums in group order.
+// Which workgroup that is varies; what it computes does not: results are the same bits every run. Counters return to
+// zero for the next launch. part [total][n], part2 [ceil(total / fan)][n], arrive [ceil(total / fan) + 1] (zero before
+// the first launch). Every thread of the workgroup must call it; `flag` is one int of LDS; nothing block-wide may follow.
+template <int THREADS, class Val, class Out>
+__device__ __forceinline__ void grid_sum_ordered(float* part, double* part2, int* arrive, int fan, int n, int me, int total,
+                                                 Val val, Out out, int* flag) {
+    const int tid = threadIdx.x;
+    if (total == 1) {                  // a single workgroup: nothing to hand over
+        for (int i = tid; i < n; i += THREADS) out(i, static_cast<double>(val(i)));
+        return;
+    }
+    for (int i = tid; i < n; i += THREADS) st_agent1(part + static_cast<size_t>(me) * n + i, val(i));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int grp = me / fan, ngroups = (total + fan - 1) / fan;
+    const int members = min(fan, total - grp * fan);
+    if (tid == 0) {
+        int last = 0;
+        if (__hip_atomic_fetch_add(arrive + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(arrive + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = 1;
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const float* gp = part + static_cast<size_t>(grp) * fan * n;
+    for (int i = tid; i < n; i += THREADS) {
+        double s = 0.0;
+        for (int j0 = 0; j0 < members; j0 += 8) {        // eight members in flight, added in member order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld_agent1(gp + static_cast<size_t>(min(j0 + u, members - 1)) * n + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (j0 + u < members) ? static_cast<double>(v[u]) : 0.0;
+        }
+        if (ngroups == 1) out(i, s); else st_agent_f64(part2 + static_cast<size_t>(grp) * n + i, s);
+    }
+    if (ngroups == 1) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        int last = 0;
+        if (__hip_atomic_fetch_add(arrive + ngroups, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
+            __hip_atomic_store(arrive + ngroups, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = 1;
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    for (int i = tid; i < n; i += THREADS) {
+        double s = 0.0;
+        for (int g0 = 0; g0 < ngroups; g0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld_agent_f64(part2 + static_cast<size_t>(min(g0 + u, ngroups - 1)) * n + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (g0 + u < ngroups) ? v[u] : 0.0;
+        }
+        out(i, s);
+    }
+}
+
 inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
 
 // memory-bound launches: enough blocks to fill 256 CUs x 8, grid-stride the rest

@@ -1,4 +1,5 @@
 // gfx950 kernels: embedding gather-mean, fp32 MFMA GEMM, split-K reduce, small utilities.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include "kernels.h"
@@ -127,6 +128,7 @@ struct GemmArgs {
     float alpha;
     const float* bias_n;
     double* colstats;        // optional [2][N]: Σ_rows C, Σ_rows C² of the stored values (batch-norm statistics, F6)
+    GridSumWs sums;          // workspace of their ordered sum over the m tiles (one column group per n tile)
     float* rowsq;            // SWAP kernels, optional [ntiles][M]: rowsq_scale · Σ_{cols of the n tile} C² per row
     float rowsq_scale;
     int mtiles, ntiles, slabs, groups, members;   // see gemm_decode_block
@@ -399,16 +401,25 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
             }
         }
         __syncthreads();
-        if (tid < BN && n0 + tid < g.N) {
-            atomic_add_f64(g.colstats + n0 + tid, static_cast<double>(red[tid] + red[BN + tid]));
-            atomic_add_f64(g.colstats + g.N + n0 + tid, static_cast<double>(red[2 * BN + tid] + red[3 * BN + tid]));
-        }
+        // ordered sum over the m tiles of this n tile (device_utils.h grid_sum_ordered): the same bits every run
+        const GridSumWs& ws = g.sums;
+        auto val = [&](int i) -> float { return i < BN ? red[i] + red[BN + i] : red[2 * BN + (i - BN)] + red[3 * BN + (i - BN)]; };
+        double* cs = g.colstats;
+        const int N = g.N;
+        auto out = [&](int i, double v) {
+            const int st = i / BN, n = i - st * BN;
+            if (n0 + n < N) cs[static_cast<size_t>(st) * N + n0 + n] = v;
+        };
+        grid_sum_ordered<256>(ws.part + static_cast<size_t>(nt) * ws.contrib_cap * ws.width_cap,
+                              ws.part2 + static_cast<size_t>(nt) * ws.groups_cap * ws.width_cap,
+                              ws.arrive + nt * (ws.groups_cap + 1), ws.fan, 2 * BN, mt, g.mtiles, val, out,
+                              reinterpret_cast<int*>(red + 4 * BN));
     }
 }
 
 bool launch_gemm_panel(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                        int lda, int ldb, int ldc, float alpha, const float* bias_n, int slabs, int k_split_len,
-                       size_t c_split_stride, hipStream_t s, double* colstats);   // gemm_panel.hip
+                       size_t c_split_stride, hipStream_t s);   // gemm_panel.hip
 static bool g_gemm_panel_enabled = [] { const char* e = std::getenv("NVSM_GEMM_PANEL"); return !(e && e[0] == '0'); }();
 void gemm_set_panel_enabled(bool on) { g_gemm_panel_enabled = on; }
 
@@ -444,12 +455,13 @@ int gemm_split_k_slabs(int K, int want) {
 
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
-                 hipStream_t s, double* colstats, float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip) {
+                 hipStream_t s, double* colstats, float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip,
+                 const GridSumWs* sums) {
     if (M <= 0 || N <= 0) return;
     if (rowsq_parts) *rowsq_parts = rowsq ? tiled_rowsq_parts(N) : 0;
     // batch-sized products against the projection matrix: the matrix stationary in LDS (gemm_tstat.hip)
     if (split_k <= 1 && launch_gemm_tstat(a_layout, b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, s, colstats, rowsq,
-                                          rowsq_scale, rowsq_parts, busy_chip))
+                                          rowsq_scale, rowsq_parts, busy_chip, sums))
         return;
     GemmArgs g;
     g.colstats = (split_k > 1) ? nullptr : colstats;
@@ -470,13 +482,24 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
     //  file, and a CU that hosts one hosts nothing else for its ~100 us; the tiled kernel takes 273 instead of 184 us there
     //  but shares its CUs: NVSM shape 1.007 -> 1.000 ms, full_adam 0.913 -> 0.902, |D| = 2 M 1.915 -> 1.90, interleaved A/B)
     if (g_gemm_panel_enabled && !(busy_chip && split_k > 1) && launch_gemm_panel(a_layout, b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, slabs,
-                                                  g.k_split_len, c_split_stride, s, g.colstats))
+                                                  g.k_split_len, c_split_stride, s))
         return;
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(B) % 16 == 0);
     const int a_contig = a_layout == 0 ? K : M, b_contig = b_layout == 0 ? N : K;
     const bool fast = aligned && (a_contig % 4 == 0) && (b_contig % 4 == 0);
     g.mtiles = (M + BM - 1) / BM; g.ntiles = (N + BN - 1) / BN; g.slabs = slabs;
+    if (g.colstats) {
+        // (the caller sized the workspace for its largest batch; a launch it cannot hold is a programming error)
+        const int fan = grid_sum_fan(g.mtiles);
+        if (!sums || sums->colgroups < g.ntiles || sums->contrib_cap < g.mtiles || sums->width_cap < 2 * BN ||
+            sums->groups_cap < (g.mtiles + fan - 1) / fan) {
+            std::fprintf(stderr, "cunvsm_amd: launch_gemm with column statistics needs a GridSumWs of %d x %d x %d\n", g.ntiles, g.mtiles, 2 * BN);
+            std::abort();
+        }
+        g.sums = *sums;
+        g.sums.fan = fan;
+    }
     if (slabs > 1) { g.groups = slabs; g.members = g.mtiles * g.ntiles; }
     else { g.groups = g.mtiles; g.members = g.ntiles; }
     const int padded_groups = ((g.groups + 7) / 8) * 8;

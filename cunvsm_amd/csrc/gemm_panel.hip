@@ -27,7 +27,6 @@ struct PanelArgs {
     size_t c_split_stride;
     float alpha;
     const float* bias_n;
-    double* colstats;          // [2][N] or null
     int mpanels, npanels, slabs;
 #ifdef NVSM_GEMM_DBG
     int dbg;                   // experiments only: 1 = one global tile load only, 2 = no C stores, 4 = no LDS tile stores
@@ -169,13 +168,12 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(PanelArgs g) {
 
     // ---- epilogue: acc[i][j][r] = C[m0 + 16 i + li][n0 + 16 (wid TN + j) + 4 lg + r] ----
     const bool vec_ok = (g.ldc % 4 == 0) && (reinterpret_cast<uintptr_t>(C) % 16 == 0);
-    float cs[TN][4], cs2[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wid * TN + j) * 16 + 4 * lg;
         float bias[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { cs[j][r] = 0.f; cs2[j][r] = 0.f; bias[r] = (g.bias_n && col + r < g.N) ? g.bias_n[col + r] : 0.f; }
+        for (int r = 0; r < 4; ++r) { bias[r] = (g.bias_n && col + r < g.N) ? g.bias_n[col + r] : 0.f; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = m0 + i * 16 + li;
@@ -189,29 +187,12 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(PanelArgs g) {
             float* cp = C + static_cast<size_t>(row) * g.ldc + col;
             if (vec_ok && col + 3 < g.N) {
                 stv<4>(cp, v);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { cs[j][r] += v[r]; cs2[j][r] += v[r] * v[r]; }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (col + r < g.N) { cp[r] = v[r]; cs[j][r] += v[r]; cs2[j][r] += v[r] * v[r]; }
+                    if (col + r < g.N) cp[r] = v[r];
             }
         }
-    }
-    if (g.colstats) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = cs[j][r], b = cs2[j][r];
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-                const int col = n0 + (wid * TN + j) * 16 + 4 * lg + r;
-                if (li == 0 && col < g.N) {
-                    atomic_add_f64(g.colstats + col, static_cast<double>(a));
-                    atomic_add_f64(g.colstats + g.N + col, static_cast<double>(b));
-                }
-            }
     }
 }
 
@@ -224,26 +205,18 @@ static void launch_panel(const PanelArgs& g, hipStream_t s) {
 // Returns true when the panel kernel took the GEMM; false → the caller uses the tiled kernel.
 bool launch_gemm_panel(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                        int lda, int ldb, int ldc, float alpha, const float* bias_n, int slabs, int k_split_len,
-                       size_t c_split_stride, hipStream_t s, double* colstats) {
+                       size_t c_split_stride, hipStream_t s) {
     PanelArgs g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.alpha = alpha; g.bias_n = bias_n; g.colstats = slabs > 1 ? nullptr : colstats;
+    g.alpha = alpha; g.bias_n = bias_n;
     g.slabs = slabs; g.k_split_len = slabs > 1 ? k_split_len : K; g.c_split_stride = c_split_stride;
     const int a_contig = a_layout == 0 ? K : M, b_contig = b_layout == 0 ? N : K;
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (a_contig % 4 == 0) && (b_contig % 4 == 0);
     if (!aligned) return false;
-    // Measured at B = 51 200 (tools/exp/gemm_exp.hip), alone: forward 88 us (TM 7, two workgroups per CU) vs 102 us tiled;
-    // dT 90 us vs 114 us tiled; dx·T (N = 300) 107 vs 109 us. Inside the step only dT keeps its gain: the forward
-    // GEMM overlaps the side-stream sort, and a grid that needs every workgroup slot of the chip (458 of 512) gets a
-    // second scheduling round as soon as anything else is resident (136 us in-step) — it stays on the 800-tile kernel.
-    static const int panel_fwd = [] { const char* e = std::getenv("NVSM_PANEL_FWD"); return e ? std::atoi(e) : 0; }();
-    if (panel_fwd && a_layout == 0 && b_layout == 0 && slabs == 1 && N == 256 && M >= 16384) {
-        g.npanels = 1;
-        if (panel_fwd == 1) { g.mpanels = (M + 207) / 208; launch_panel<0, 0, 13, 4, 32>(g, s); }
-        else { g.mpanels = (M + 111) / 112; launch_panel<0, 0, 7, 4, 32>(g, s); }
-        return true;
-    }
+    // (A forward-product variant — TM 13 or 7, one or two workgroups per CU: 88 us alone against 102 us tiled at B = 51 200 —
+    //  lost inside the step: a grid that needs every workgroup slot of the chip gets a second scheduling round as soon as
+    //  anything else is resident, 136 us. Removed in round 3 together with its atomic column statistics.)
     if (a_layout == 1 && b_layout == 0 && slabs >= 64 && N <= 256 && N > 128 && M <= 320 && M > 160) {  // dT, split-K slabs
         g.mpanels = 2; g.npanels = 1;
         launch_panel<1, 0, 10, 4, 32>(g, s);                    // (2 row halves) x slabs workgroups, 160 accumulators

@@ -39,7 +39,8 @@ struct TstatArgs {
     int M, N, K, lda, ldb, ldc;
     float alpha;
     const float* bias_n;
-    double* colstats;        // [2][N] += Σ_rows C, Σ_rows C² (forward: batch-norm statistics) or null
+    double* colstats;        // [2][N] = Σ_rows C, Σ_rows C² (forward: batch-norm statistics) or null
+    GridSumWs sums;          // workspace of the ordered sum over the workgroups of a column part (one column group per part)
     float* rowsq;            // [ceil(N/16)][M] = rowsq_scale · Σ_{16 cols of the tile} C² per row, or null
     float rowsq_scale;
     int parts;
@@ -284,16 +285,25 @@ __global__ __launch_bounds__(kTstatThreads) void gemm_tstat_kernel(TstatArgs g) 
 
     if (EPI & kEpiStats) {
         __syncthreads();
-        // the eight waves' slots in wave order, then one fp64 atomic per column and statistic per workgroup
-        for (int i = tid; i < 2 * NH; i += kTstatThreads) {
-            const int st = i / NH, n = i - st * NH;
-            if (n < 16 * nt && n0 + n < g.N) {
-                float s = 0.f;
+        // the eight waves' slots in wave order, then the ordered sum over the part's workgroups (device_utils.h): the same
+        // bits every run, where one fp64 atomic per column and workgroup added in arrival order
+        int* sum_flag = reinterpret_cast<int*>(tstat_lds);      // (the image of B is dead behind the barrier; LDS is full)
+        const GridSumWs& ws = g.sums;
+        auto val = [&](int i) -> float {
+            float s = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < kTstatWaves; ++ww) s += stats[ww * 2 * NH + i];
-                atomic_add_f64(g.colstats + static_cast<size_t>(st) * g.N + n0 + n, static_cast<double>(s));
-            }
-        }
+            for (int ww = 0; ww < kTstatWaves; ++ww) s += stats[ww * 2 * NH + i];
+            return s;
+        };
+        double* cs = g.colstats;
+        const int N = g.N;
+        auto out = [&](int i, double v) {
+            const int st = i / NH, n = i - st * NH;
+            if (n < 16 * nt && n0 + n < N) cs[static_cast<size_t>(st) * N + n0 + n] = v;
+        };
+        grid_sum_ordered<kTstatThreads>(ws.part + static_cast<size_t>(part) * ws.contrib_cap * ws.width_cap,
+                                        ws.part2 + static_cast<size_t>(part) * ws.groups_cap * ws.width_cap,
+                                        ws.arrive + part * (ws.groups_cap + 1), ws.fan, 2 * NH, me, wgs, val, out, sum_flag);
     }
 }
 
@@ -343,7 +353,7 @@ void gemm_set_tstat_enabled(bool on) { g_gemm_tstat_enabled = on; }
 // *rowsq_parts = number of [M]-sized parts written to rowsq (one per 16-column tile)
 bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                        int lda, int ldb, int ldc, float alpha, const float* bias_n, hipStream_t s, double* colstats,
-                       float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip) {
+                       float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip, const GridSumWs* sums) {
     // NVSM_GEMM_TSTAT (A/B runs): bit 0 = the forward product (B as [K][N]), bit 1 = the backward one (B stored [N][K])
     static const int env_mask = [] { const char* e = std::getenv("NVSM_GEMM_TSTAT"); return e ? std::atoi(e) : 3; }();
     if (!g_gemm_tstat_enabled || !(env_mask & (b_layout ? 2 : 1)) || a_layout != 0 || M < 1024) return false;
@@ -408,6 +418,13 @@ bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* 
     }
     g.wg_begin[parts] = w0;
     wgs = w0;
+    if (colstats) {
+        // the ordered column sums need their workspace, large enough for this launch's split
+        if (!sums || sums->colgroups < parts || sums->contrib_cap < wgs || sums->width_cap < 2 * NT * 16) return false;
+        g.sums = *sums;
+        g.sums.fan = grid_sum_fan(wgs);
+        if ((wgs + g.sums.fan - 1) / g.sums.fan > sums->groups_cap) return false;
+    }
     const size_t lds = static_cast<size_t>(KG) * 4 * NT * 16 * 16 + (colstats ? static_cast<size_t>(kTstatWaves) * 2 * NT * 16 * 4 : 0);
     bool ok = false;
     const bool mixed = wide < parts;

@@ -37,6 +37,18 @@ struct LazyView {
     float decay[kLazyHistory];      // factor of update u + 1 on the table rows at [u % kLazyHistory]
 };
 
+// Workspace of the ordered grid-wide sums (device_utils.h grid_sum_ordered): the batch-norm column statistics out of the
+// projection GEMM's epilogue and [loss | Σdy | Σdy·x̂] out of the loss kernel are added up in a fixed order — same bits
+// every run, no atomics on data. `colgroups` independent sums (column parts / tiles of a GEMM; 1 for the loss kernel), each
+// of up to `contrib_cap` contributions of up to `width_cap` floats.
+struct GridSumWs {
+    float* part;        // [colgroups][contrib_cap][width_cap]
+    double* part2;      // [colgroups][groups_cap][width_cap]
+    int* arrive;        // [colgroups][groups_cap + 1], zero between launches
+    int colgroups, contrib_cap, groups_cap, width_cap, fan;
+};
+inline int grid_sum_fan(int contributions) { return contributions > 256 ? 32 : 16; }
+
 // ---- gather-mean (F3/F9; replaces average_repr_kernel, cpp/params.cu:75-95) ------------------
 void launch_gather_mean(const float* table, int dim, const int* idx, const float* wts, int window,
                         int64_t num_out, float* out, hipStream_t s, const LazyView* lazy = nullptr);
@@ -50,9 +62,10 @@ int window_unroll(int window);      // rows of a window in flight per lane in th
 // is lost: alpha applied per slab, bias must be null) and the caller reduces with launch_splitk_reduce.
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
-                 hipStream_t s, double* colstats = nullptr,     // colstats [2][N] (no split-K): += Σ_rows C, Σ_rows C²
+                 hipStream_t s, double* colstats = nullptr,     // colstats [2][N] (no split-K): = Σ_rows C, Σ_rows C² (needs `sums`)
                  float* rowsq = nullptr, float rowsq_scale = 0.f, int* rowsq_parts = nullptr,
-                 bool busy_chip = false);     // the launch lands next to long-running kernels of other streams (kernel choice)
+                 bool busy_chip = false,      // the launch lands next to long-running kernels of other streams (kernel choice)
+                 const GridSumWs* sums = nullptr);      // workspace of the ordered column sums (required with colstats)
 // rowsq [gemm_rowsq_parts(N)][M]: rowsq_scale · Σ_cols C² per row, split by column tile (128 columns in the tiled kernel,
 // 16 in the LDS-stationary one): *rowsq_parts = the number of parts this launch wrote; launch_sum_parts adds them in
 // order (a runtime-length loop over the parts inside the row passes' unrolled gather was measured: it halves their
@@ -61,7 +74,7 @@ int gemm_rowsq_parts(int N);             // upper bound of *rowsq_parts: sizes t
 // LDS-stationary kernel for the batch-sized projection products (gemm_tstat.hip); false = shape not covered
 bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                        int lda, int ldb, int ldc, float alpha, const float* bias_n, hipStream_t s, double* colstats,
-                       float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip = false);
+                       float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip = false, const GridSumWs* sums = nullptr);
 void gemm_set_tstat_enabled(bool on);    // experiments / tests: force the tiled kernel
 void launch_sum_parts(const float* parts, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
 void gemm_set_panel_enabled(bool on);    // experiments / tests: force the tiled kernel
@@ -113,8 +126,9 @@ struct LossArgs {
     float* coef;              // [B*R]   ±m_j  (signed multipliers)
     float* probs;             // [B*R]
     float* pp;                // [B]     mean_t(proj²)
-    double* loss_acc;         // [1]     Σ ω·log p
-    double* colstats;         // [2][de] Σdy, Σdy·x̂ (x̂ only when bn)
+    double* loss_acc;         // [1]     Σ ω·log p                           } written (not accumulated) by the ordered grid-wide sum;
+    double* colstats;         // [2][de] Σdy, Σdy·x̂ (x̂ only when bn)      } colstats == loss_acc + 1
+    GridSumWs sums;           // its workspace (kernels.h GridSumWs, one column group)
     int64_t B;
     int de, R, k;
     int bn, nonlinearity, rebalance;

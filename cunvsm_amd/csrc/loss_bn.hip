@@ -104,9 +104,25 @@ void launch_bn_dx(float* dy, const float* pre, const float* mean, const float* i
 constexpr int kExamplesPerWave = 8;
 constexpr int kRowGroup = 4;
 
+// The workgroup's share of [loss | Σdy | Σdy·x̂] (four waves' column sums in LDS) goes into the ordered grid-wide sum
+// (device_utils.h grid_sum_ordered) whose result lands in a.loss_acc[0 .. 2 de]: value 0 is the loss word, 1 .. de the
+// column sums of dy, de + 1 .. 2 de those of dy·x̂ (batch-norm only).
+__device__ __forceinline__ void loss_block_sums(const LossArgs& a, const float* s_dy, const float* s_dyx, const float* s_loss, int* flag) {
+    const int de = a.de;
+    const int n = 1 + (a.bn ? 2 : 1) * de;
+    auto val = [&](int i) -> float {
+        if (i == 0) return (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        const float* sp = (i <= de) ? s_dy + (i - 1) : s_dyx + (i - 1 - de);
+        return (sp[0] + sp[de]) + (sp[2 * de] + sp[3 * de]);
+    };
+    double* dst = a.loss_acc;
+    grid_sum_ordered<256>(a.sums.part, a.sums.part2, a.sums.arrive, a.sums.fan, n, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x),
+                          val, [&](int i, double v) { dst[i] = v; }, flag);
+}
+
 template <int V, int NITER, bool L2E = false>
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
-    extern __shared__ float lds[];          // [2][4][de] column stats + [4] loss
+    extern __shared__ float lds[];          // [2][4][de] column stats + [4] loss + the grid sum's flag
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int de = a.de, R = a.R;
     const int64_t e0 = (static_cast<int64_t>(blockIdx.x) * 4 + wid) * kExamplesPerWave;
@@ -286,16 +302,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     }
     if (lane == 0) s_loss[wid] = wave_loss;
     __syncthreads();
-    for (int c = threadIdx.x; c < de; c += blockDim.x) {
-        const float t0 = (s_dy[c] + s_dy[de + c]) + (s_dy[2 * de + c] + s_dy[3 * de + c]);
-        atomic_add_f64(a.colstats + c, static_cast<double>(t0));
-        if (a.bn) {
-            const float t1 = (s_dyx[c] + s_dyx[de + c]) + (s_dyx[2 * de + c] + s_dyx[3 * de + c]);
-            atomic_add_f64(a.colstats + de + c, static_cast<double>(t1));
-        }
-    }
-    if (threadIdx.x == 0)
-        atomic_add_f64(a.loss_acc, static_cast<double>((s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3])));
+    loss_block_sums(a, s_dy, s_dyx, s_loss, reinterpret_cast<int*>(s_loss + 4));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -469,27 +476,22 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
     }
     if (lane == 0) s_loss[wid] = wave_loss;
     __syncthreads();
-    for (int cc = threadIdx.x; cc < de; cc += blockDim.x) {
-        const float t0 = (s_dy[cc] + s_dy[de + cc]) + (s_dy[2 * de + cc] + s_dy[3 * de + cc]);
-        atomic_add_f64(a.colstats + cc, static_cast<double>(t0));
-        if (a.bn) {
-            const float t1 = (s_dyx[cc] + s_dyx[de + cc]) + (s_dyx[2 * de + cc] + s_dyx[3 * de + cc]);
-            atomic_add_f64(a.colstats + de + cc, static_cast<double>(t1));
-        }
-    }
-    if (threadIdx.x == 0) atomic_add_f64(a.loss_acc, static_cast<double>((s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3])));
+    loss_block_sums(a, s_dy, s_dyx, s_loss, reinterpret_cast<int*>(s_loss + 4));
 }
 
 template <int V, int NITER>
-static void launch_loss_t(const LossArgs& a, hipStream_t s) {
-    const int grid = ceil_div(a.B, 4 * kExamplesPerWave);
-    const size_t shmem = (8 * static_cast<size_t>(a.de) + 4) * sizeof(float);
+static void launch_loss_t(const LossArgs& a_in, hipStream_t s) {
+    const int grid = ceil_div(a_in.B, 4 * kExamplesPerWave);
+    LossArgs a = a_in;
+    a.sums.fan = grid_sum_fan(grid);
+    const size_t shmem = (8 * static_cast<size_t>(a.de) + 8) * sizeof(float);
     if (a.l2_entity) NVSM_LAUNCH((loss_kernel<V, NITER, true>), dim3(grid), dim3(256), shmem, s, a);
     else NVSM_LAUNCH((loss_kernel<V, NITER, false>), dim3(grid), dim3(256), shmem, s, a);
 }
 
 template <int RB>
-static void launch_loss_rows(const LossArgs& a, hipStream_t s) {
+static void launch_loss_rows(const LossArgs& a_in, hipStream_t s) {
+    LossArgs a = a_in;
     // ~5 blocks per CU; at most 16 examples per wave (column statistics: one fp64 atomic per column per block)
     int epw = static_cast<int>((a.B + 4 * 1280 - 1) / (4 * 1280));
     epw = epw < 1 ? 1 : (epw > 16 ? 16 : epw);
@@ -498,7 +500,8 @@ static void launch_loss_rows(const LossArgs& a, hipStream_t s) {
     static const int epw_env = [] { const char* e = std::getenv("NVSM_LOSS_EPW"); return e ? std::atoi(e) : 0; }();      // experiments
     if (epw_env > 0) epw = epw_env;
     const int grid = ceil_div(a.B, 4 * epw);
-    const size_t shmem = (8 * static_cast<size_t>(a.de) + 4) * sizeof(float);
+    a.sums.fan = grid_sum_fan(grid);
+    const size_t shmem = (8 * static_cast<size_t>(a.de) + 8) * sizeof(float);
     if (a.lazyE.stamp) NVSM_LAUNCH((loss_rows_kernel<RB, true>), dim3(grid), dim3(256), shmem, s, a, epw);
     else NVSM_LAUNCH((loss_rows_kernel<RB, false>), dim3(grid), dim3(256), shmem, s, a, epw);
 }

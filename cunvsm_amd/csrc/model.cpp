@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -344,6 +345,17 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
     t.sort_temp.alloc(t.sort_temp_bytes, true);      // zero once: the arrival counter only ever grows
 }
 
+void Model::alloc_sums(SumsBufs& b, int colgroups, int contrib_cap, int width_cap) {
+    GridSumWs& w = b.ws;
+    w.colgroups = colgroups; w.contrib_cap = contrib_cap; w.width_cap = width_cap;
+    w.groups_cap = contrib_cap / 16 + 1;      // (grid_sum_fan() is at least 16)
+    w.fan = 16;
+    b.part.alloc(static_cast<size_t>(colgroups) * contrib_cap * width_cap);
+    b.part2.alloc(static_cast<size_t>(colgroups) * w.groups_cap * width_cap);
+    b.arrive.alloc(static_cast<size_t>(colgroups) * (w.groups_cap + 1), true);      // zero once: the last arriver resets its counter
+    w.part = b.part.p; w.part2 = b.part2.p; w.arrive = b.arrive.p;
+}
+
 Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1), rng_(1) {
     auto bad = [](const std::string& m) { throw Error(NVSM_ERR_INVALID_ARGUMENT, m); };
     if (cfg.num_words <= 0 || cfg.num_entities <= 0) bad("num_words and num_entities must be positive");
@@ -406,6 +418,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&err_host_), sizeof(int), hipHostMallocDefault));
     *err_host_ = 0;
     { const char* d = std::getenv("NVSM_DEBUG"); debug_ = d && d[0] && d[0] != '0'; }
+    { const char* d = std::getenv("NVSM_DP_T_ON_MAIN"); dp_single_stream_ = d && d[0] && d[0] != '0'; }
 
     const int dw = cfg.word_repr_size, de = cfg.entity_repr_size, w = cfg.window_size;
     const int64_t N = B * R_;
@@ -429,6 +442,15 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     if (cfg.update_method == NVSM_ADAM && cfg.adam_mode <= NVSM_ADAM_SPARSE) U_.alloc(B * dw);
     if (cfg.update_method == NVSM_ADAGRAD) scale_w_.alloc(B);
     stats_.alloc(4 * de + 1, true); stats_fwd_ = stats_.p; stats_bwd_ = stats_.p + 2 * de;
+    {
+        // projection GEMM: one column group per column part (LDS-stationary kernel: <= 4, a workgroup per CU) or per 128-column
+        // tile (tiled kernel: a contribution per 128-row tile); loss kernel: one workgroup per 4 .. 64 examples
+        hipDeviceProp_t prop{};
+        NVSM_HIP_CHECK(hipGetDeviceProperties(&prop, cfg.device));
+        const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        alloc_sums(sums_fwd_, std::max(4, (de + 127) / 128), std::max<int>(cus, static_cast<int>((B + 127) / 128)), 2 * 160);
+        alloc_sums(sums_bwd_, 1, static_cast<int>((B + 3) / 4), 2 * de + 1);
+    }
     bn_mean_.alloc(de, true); bn_inv_std_.alloc(de, true); dbeta_.alloc(de, true); dgamma_.alloc(de, true);
     gT_.alloc(static_cast<size_t>(de) * dw, true); gb_.alloc(de, true);
     const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
@@ -559,6 +581,61 @@ void Model::comm_init(const char id[128]) {
     if (rc != 0) throw Error(NVSM_ERR_DEVICE, std::string("ncclCommInitRank: ") + (rccl_->GetErrorString ? rccl_->GetErrorString(rc) : "error"));
     comm_ranks_ = cfg_.world_size;
     if (rccl_->CommCount) { int n = 0; if (rccl_->CommCount(comm_, &n) == 0) comm_ranks_ = n; }
+    // The step issues its collectives on ONE communicator from two streams ordered by events (never two in flight). Before
+    // the first step relies on that, the same pattern runs once with known values; a communicator that does not deliver the
+    // right sums that way gets every collective on the main stream instead (and must pass the check there).
+    if (!dp_single_stream_ && !comm_order_check(true)) {
+        std::fprintf(stderr, "cunvsm_amd: rank %d: collectives on two event-ordered streams failed their check; using the main stream for all "
+                             "of them (NVSM_DP_T_ON_MAIN=1)\n", cfg_.rank);
+        dp_single_stream_ = true;
+    }
+    if (dp_single_stream_ && !comm_order_check(false))
+        throw Error(NVSM_ERR_DEVICE, "the RCCL communicator does not all-reduce correctly (checked with known values)");
+}
+
+// The step's collective pattern with known values: f64 on the main stream (batch-norm sums), f64 again (backward sums), f32 on
+// side stream 2 behind an event (projection gradient), f64 on the main stream behind an event (the next step's sums). Rank r
+// contributes r + 1, so every element must come back as G (G + 1) / 2 times its index weight. The verdict is itself summed
+// over the ranks (on the main stream, which both modes use), so that all ranks choose the same mode.
+bool Model::comm_order_check(bool two_streams) {
+    const int n = 2 * cfg_.entity_repr_size + 1, nf = 4096, G = cfg_.world_size;
+    DevBuf<double> d; DevBuf<float> f; DevBuf<double> verdict;
+    d.alloc(n); f.alloc(nf); verdict.alloc(1);
+    std::vector<double> hd(n); std::vector<float> hf(nf);
+    bool ok = true;
+    hipStream_t side = two_streams ? aux2_stream_ : stream_;
+    hipEvent_t e1 = nullptr, e2 = nullptr;
+    NVSM_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    NVSM_HIP_CHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    for (int round = 0; round < 3 && ok; ++round) {
+        for (int i = 0; i < n; ++i) hd[i] = (cfg_.rank + 1) * (1.0 + i);
+        for (int i = 0; i < nf; ++i) hf[i] = static_cast<float>((cfg_.rank + 1) * (1 + i % 7));
+        NVSM_HIP_CHECK(hipMemcpyAsync(d.p, hd.data(), n * sizeof(double), hipMemcpyHostToDevice, stream_));
+        NVSM_HIP_CHECK(hipMemcpyAsync(f.p, hf.data(), nf * sizeof(float), hipMemcpyHostToDevice, stream_));
+        int rc = rccl_->AllReduce(d.p, d.p, n, RcclApi::kFloat64, RcclApi::kSum, comm_, stream_);
+        NVSM_HIP_CHECK(hipEventRecord(e1, stream_));
+        NVSM_HIP_CHECK(hipStreamWaitEvent(side, e1, 0));
+        if (rc == 0) rc = rccl_->AllReduce(f.p, f.p, nf, RcclApi::kFloat32, RcclApi::kSum, comm_, side);
+        NVSM_HIP_CHECK(hipEventRecord(e2, side));
+        NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, e2, 0));
+        if (rc == 0) rc = rccl_->AllReduce(d.p, d.p, n, RcclApi::kFloat64, RcclApi::kSum, comm_, stream_);
+        NVSM_HIP_CHECK(hipMemcpyAsync(hd.data(), d.p, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        NVSM_HIP_CHECK(hipMemcpyAsync(hf.data(), f.p, nf * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        NVSM_HIP_CHECK(hipStreamSynchronize(side));
+        const double s1 = 0.5 * G * (G + 1);
+        ok = rc == 0;
+        for (int i = 0; i < n && ok; ++i) ok = hd[i] == s1 * G * (1.0 + i);             // summed twice: the second time G equal copies
+        for (int i = 0; i < nf && ok; ++i) ok = hf[i] == static_cast<float>(s1 * (1 + i % 7));
+    }
+    (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    // every rank must reach the same verdict: sum the failures (on the main stream, with the plainest possible call)
+    double bad = ok ? 0.0 : 1.0;
+    NVSM_HIP_CHECK(hipMemcpyAsync(verdict.p, &bad, sizeof(double), hipMemcpyHostToDevice, stream_));
+    const int rc = rccl_->AllReduce(verdict.p, verdict.p, 1, RcclApi::kFloat64, RcclApi::kSum, comm_, stream_);
+    NVSM_HIP_CHECK(hipMemcpyAsync(&bad, verdict.p, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+    return rc == 0 && bad == 0.0;
 }
 
 // Data parallel: the embedding tables are updated rank-locally (north_star "sparse embedding rows stay
@@ -875,7 +952,8 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         launch_gemm(0, 0, phrase_p_, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
                     cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_,
                     cfg_.batch_normalization ? stats_fwd_ : nullptr, nullptr, 0.f, nullptr,
-                    /*busy_chip=*/words_.lazy || ents_.lazy);      // long sorts and a long documents-update tail next to it
+                    /*busy_chip=*/words_.lazy || ents_.lazy,       // long sorts and a long documents-update tail next to it
+                    &sums_fwd_.ws);
     }
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
@@ -904,7 +982,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         a.bn_sums = stats_fwd_; a.bn_n = bn_n; a.bn_eps = 1e-4f;
         a.E = ents_.P.p; a.ids = ids_.p; a.inst_w = instw_;
         a.proj = proj_.p; a.dy = dy_.p; a.coef = coef_.p; a.probs = probs_.p; a.pp = pp_.p;
-        a.loss_acc = stats_bwd_; a.colstats = stats_bwd_ + 1;
+        a.loss_acc = stats_bwd_; a.colstats = stats_bwd_ + 1; a.sums = sums_bwd_.ws;
         a.B = B; a.de = de; a.R = R_; a.k = k;
         a.bn = cfg_.batch_normalization; a.nonlinearity = cfg_.nonlinearity;
         a.l2_entity = cfg_.l2_normalize_entity_reprs;
@@ -1383,8 +1461,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     // events below (BN forward sums → BN backward sums on the main stream → [ev_dx] gradient on side stream 2 →
     // [join_T] next step's BN forward sums), so one communicator serves both streams. NVSM_DP_T_ON_MAIN=1 keeps all
     // collectives on the main stream (dT GEMM + all-reduce + update no longer overlap the words update).
-    static const bool t_on_main = std::getenv("NVSM_DP_T_ON_MAIN") != nullptr;
-    const bool dp = cfg_.world_size > 1 && t_on_main;
+    const bool dp = cfg_.world_size > 1 && dp_single_stream_;
     RangeScope range_bu("ComputeGradients+UpdateParameters");      // cpp/main.cu:414,429 — one interleaved region here
     // ... but only once the dx GEMM is through at large batches: next to the MFMA-bound GEMM the row pass (100 k short-lived
     // waves) keeps the GEMM's workgroups from becoming resident — measured at B = 51 200: dx GEMM 132 → 203 us, dT GEMM

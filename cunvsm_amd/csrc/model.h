@@ -162,6 +162,7 @@ class Model {
     void comm_init(const char id[128]);
     void average_tables();                 // data parallel: mean of the replicas' embedding tables (nvsm_dp_average_tables)
     int comm_ranks() const { return comm_ranks_; }
+    bool dp_single_stream() const { return dp_single_stream_; }
     void set_allreduce_callback(nvsm_allreduce_fn fn, void* user) { ar_fn_ = fn; ar_user_ = user; }
 
     Profiler prof;
@@ -246,7 +247,11 @@ class Model {
     float* phrase_p_ = nullptr;           // the one the current forward result lives in
     bool E_pending_ = false, T_pending_ = false;      // side-stream tails of the last nvsm_step not yet joined
     DevBuf<float> phrase_, pre_, proj_, dy_, gphrase_, coef_, probs_, pp_, msq_w_, msq_parts_, U_, scale_w_, grad_entity_;
-    DevBuf<double> stats_;                   // [2 de | 1 + 2 de] = Σx Σx² | loss Σdy Σdy·x̂ — cleared by one memset per step
+    DevBuf<double> stats_;                   // [2 de | 1 + 2 de] = Σx Σx² | loss Σdy Σdy·x̂ — written by the ordered grid sums
+    // workspaces of those sums (kernels.h GridSumWs): projection GEMM epilogue / loss kernel
+    struct SumsBufs { DevBuf<float> part; DevBuf<double> part2; DevBuf<int> arrive; GridSumWs ws{}; };
+    SumsBufs sums_fwd_, sums_bwd_;
+    void alloc_sums(SumsBufs& b, int colgroups, int contrib_cap, int width_cap);
     bool csr_joined_words_ = true, csr_joined_ents_ = true;      // the main stream is behind the current CSR builds
     double* stats_fwd_ = nullptr;
     double* stats_bwd_ = nullptr;
@@ -267,6 +272,11 @@ class Model {
     RcclApi* rccl_ = nullptr;
     void* comm_ = nullptr;
     int comm_ranks_ = 0;              // ncclCommCount of the communicator (0 = none)
+    // the step's three collectives: on two event-ordered streams (dT all-reduce + projection update on side stream 2, next to
+    // the words update) or all on the main stream — NVSM_DP_T_ON_MAIN=1, or chosen by comm_init when the communicator does not
+    // return the right sums with the two-stream order
+    bool dp_single_stream_ = false;
+    bool comm_order_check(bool two_streams);      // all-reduces of known values in the step's order; every rank gets the same verdict
     DevBuf<double> loss_tmp_;         // data parallel get_cost before compute_gradients: all-reduced copy of the loss word
     nvsm_allreduce_fn ar_fn_ = nullptr;
     void* ar_user_ = nullptr;

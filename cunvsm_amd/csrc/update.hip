@@ -258,12 +258,6 @@ __device__ __forceinline__ void ld_agent(const float* p, float (&x)[V]) {
             x[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(const_cast<float*>(p)) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
 }
-__device__ __forceinline__ void st_agent1(float* p, float x) {
-    __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_agent1(const float* p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
 
 // sum_partials over partials written by other workgroups of the same launch: the same additions in the same order
 template <int V, bool VEC, int U>

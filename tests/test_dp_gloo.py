@@ -189,3 +189,142 @@ def test_dp_fused_step(tmp_path, method):
     assert np.linalg.norm(r[0]["T1"] - T1) <= (2e-2 if method.endswith("adam") else 1e-4) * step
     # ... and the embedding tables are rank-local ("sparse rows stay GPU-local"): they differ between the ranks
     assert not np.array_equal(r[0]["E"], r[1]["E"])
+
+
+# ---------------------------------------------------------------------------------------------
+# loss TRAJECTORY of a data-parallel run against the single-process run: the dense parameters follow the
+# all-reduced gradients, the embedding tables are rank-local and averaged at the end — not the single-GPU trajectory, but
+# one that stays next to it: the loss of step 0 is the global loss exactly, the curve falls on fresh batches, and it lags the
+# single-process curve by what rank-local tables cost (every replica's rows see only their own rank's share of the sparse
+# gradient — with 2 ranks the tables train as if at half the learning rate): at least 60 % of the single-process
+# improvement after 20 steps, never more than 15 % above its curve, never below it.
+# ---------------------------------------------------------------------------------------------
+TRAJ_SPEC = dict(num_words=300, num_entities=200, word_dim=16, entity_dim=12, window=4, num_random=5,
+                 nonlinearity="hard_tanh", batch_norm=True, update_method="sgd")
+TRAJ_SPEC["lambda"] = 0.01
+TRAJ_STEPS, TRAJ_B, TRAJ_LR = 20, 512, 5.0
+
+
+def _traj_batches(spec):
+    """Batches with something to learn: a document's words come from its own 12-word region of the vocabulary."""
+    from tests.helpers import random_params
+    rs = np.random.RandomState(31)
+    params = random_params(spec, rs)
+    params["word_entity_mapping-transform"] = (params["word_entity_mapping-transform"] * 3).astype(np.float32)
+    nV, nD, w, k, B = spec["num_words"], spec["num_entities"], spec["window"], spec["num_random"], TRAJ_B
+    batches = []
+    for _ in range(TRAJ_STEPS):
+        labels = rs.randint(0, nD, B).astype(np.int64)
+        words = ((labels[:, None] * 7 + rs.randint(0, 12, (B, w))) % nV).astype(np.int64).ravel()
+        ids = rs.randint(0, nD, (B, k + 1)).astype(np.int64)
+        ids[:, 0] = labels
+        batches.append((words, np.ones(B * w, np.float32), labels, np.ones(B, np.float32), ids.ravel()))
+    return params, batches
+
+
+def _worker_traj(rank, port, spec, out_dir, use_gpu):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from cunvsm_amd import dp
+    from tests.helpers import gpu_model, load_params, oracle_model
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
+    params, batches = _traj_batches(spec)
+    if use_gpu:
+        import cunvsm_amd as ca
+        m = gpu_model(spec, TRAJ_B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0)
+        load_params(m, params, True)
+        m.set_allreduce_callback(dp.torch_allreduce(dist))
+    else:
+        m = oracle_model(spec)
+        load_params(m, params, False)
+        m.set_allreduce(dp.torch_allreduce(dist), WORLD)
+    costs = []
+    for words, ww, labels, iw, ids in batches:
+        w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
+        if use_gpu:
+            costs.append(m.step(ca.Batch(w, wl, wwt, wi), TRAJ_LR, entity_ids=wid, want_cost=True))
+        else:
+            m.forward(w, wwt, wid, wi)
+            m.backward()
+            costs.append(m.get_cost())
+            m.update(TRAJ_LR)
+    if use_gpu:
+        m.dp_average_tables()
+        E, T = m.get_param("entity_representations-representations"), m.get_param("word_entity_mapping-transform")
+    else:
+        E, T = m.get("entity_representations-representations"), m.get("word_entity_mapping-transform")
+    np.savez(os.path.join(out_dir, "traj_rank%d.npz" % rank), cost=np.array(costs, np.float64), E=E, T=T)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_trajectory(r, single_costs, params, E_single, T_single, averaged):
+    single_costs = np.asarray(single_costs)
+    for k in range(WORLD):
+        c = r[k]["cost"]
+        assert abs(c[0] - single_costs[0]) <= 1e-5 * abs(single_costs[0])          # same parameters: the global loss, exactly
+        assert c[0] - c[-1] >= 0.6 * (single_costs[0] - single_costs[-1]), (c, single_costs)      # it trains
+        rel = (c - single_costs) / single_costs
+        assert rel.max() < 0.15 and rel.min() > -0.02, (c, single_costs)
+    np.testing.assert_array_equal(r[0]["cost"], r[1]["cost"])                       # every rank reports the global loss
+    np.testing.assert_array_equal(r[0]["T"], r[1]["T"])                             # dense replicas in lock-step for 20 steps
+    # the projection moved the way the single process's projection moved
+    T0 = params["word_entity_mapping-transform"].astype(np.float64)
+    dT, dT1 = r[0]["T"] - T0, T_single - T0
+    assert float(np.dot(dT, dT1) / (np.linalg.norm(dT) * np.linalg.norm(dT1))) > 0.8
+    if averaged:                                                                     # one table for all ranks after nvsm_dp_average_tables
+        np.testing.assert_array_equal(r[0]["E"], r[1]["E"])
+        E0 = params["entity_representations-representations"].astype(np.float64)
+        moved, moved_single = r[0]["E"] - E0, E_single - E0
+        # parameter averaging: every rank moved its own rows, the mean moves in the single-process direction
+        cos = float(np.dot(moved.ravel(), moved_single.ravel()) / (np.linalg.norm(moved) * np.linalg.norm(moved_single)))
+        assert cos > 0.9, cos
+
+
+def _single_oracle_trajectory(spec):
+    from tests.helpers import load_params, oracle_model
+    params, batches = _traj_batches(spec)
+    o = oracle_model(spec)
+    load_params(o, params, False)
+    costs = []
+    for words, ww, labels, iw, ids in batches:
+        o.forward(words, ww, ids, iw)
+        o.backward()
+        costs.append(o.get_cost())
+        o.update(TRAJ_LR)
+    return params, costs, o.get("entity_representations-representations"), o.get("word_entity_mapping-transform")
+
+
+def test_dp_loss_trajectory_oracle(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_traj, args=(port, TRAJ_SPEC, str(tmp_path), False), nprocs=WORLD, join=True)
+    params, costs, E1, T1 = _single_oracle_trajectory(TRAJ_SPEC)
+    r = [np.load(os.path.join(str(tmp_path), "traj_rank%d.npz" % k)) for k in range(WORLD)]
+    _check_trajectory(r, costs, params, E1, T1, averaged=False)
+    assert not np.array_equal(r[0]["E"], r[1]["E"])          # rank-local tables until somebody averages them
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("collectives", ["two_streams", "main_stream"])
+def test_dp_loss_trajectory_hip(tmp_path, collectives, monkeypatch):
+    """The same 20 steps through nvsm_step on two ranks sharing GPU 0, with the step's collectives in either order of issue:
+    side stream 2 for the projection gradient (default) or everything on the main stream (NVSM_DP_T_ON_MAIN=1, what
+    nvsm_comm_init falls back to when its check of the two-stream order fails)."""
+    import torch.multiprocessing as mp
+    if collectives == "main_stream":
+        monkeypatch.setenv("NVSM_DP_T_ON_MAIN", "1")
+    else:
+        monkeypatch.delenv("NVSM_DP_T_ON_MAIN", raising=False)
+    port = _free_port()
+    mp.spawn(_worker_traj, args=(port, TRAJ_SPEC, str(tmp_path), True), nprocs=WORLD, join=True)
+    params, costs, E1, T1 = _single_oracle_trajectory(TRAJ_SPEC)
+    r = [np.load(os.path.join(str(tmp_path), "traj_rank%d.npz" % k)) for k in range(WORLD)]
+    _check_trajectory(r, costs, params, E1, T1, averaged=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["sgd", "sparse_adam"])
+def test_dp_fused_step_collectives_on_the_main_stream(tmp_path, method, monkeypatch):
+    monkeypatch.setenv("NVSM_DP_T_ON_MAIN", "1")
+    test_dp_fused_step(tmp_path, method)

@@ -107,11 +107,12 @@ template <int THREADS, class Val, class Out>
 __device__ __forceinline__ void grid_sum_ordered(float* part, double* part2, int* arrive, int fan, int n, int me, int total,
                                                  Val val, Out out, int* flag) {
     const int tid = threadIdx.x;
+    const int T = THREADS > 0 ? THREADS : static_cast<int>(blockDim.x);      // (THREADS = 0: the block size is a run-time value)
     if (total == 1) {                  // a single workgroup: nothing to hand over
-        for (int i = tid; i < n; i += THREADS) out(i, static_cast<double>(val(i)));
+        for (int i = tid; i < n; i += T) out(i, static_cast<double>(val(i)));
         return;
     }
-    for (int i = tid; i < n; i += THREADS) st_agent1(part + static_cast<size_t>(me) * n + i, val(i));
+    for (int i = tid; i < n; i += T) st_agent1(part + static_cast<size_t>(me) * n + i, val(i));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int grp = me / fan, ngroups = (total + fan - 1) / fan;
@@ -127,7 +128,7 @@ __device__ __forceinline__ void grid_sum_ordered(float* part, double* part2, int
     __syncthreads();
     if (!*flag) return;
     const float* gp = part + static_cast<size_t>(grp) * fan * n;
-    for (int i = tid; i < n; i += THREADS) {
+    for (int i = tid; i < n; i += T) {
         double s = 0.0;
         for (int j0 = 0; j0 < members; j0 += 8) {        // eight members in flight, added in member order
             float v[8];
@@ -151,7 +152,7 @@ __device__ __forceinline__ void grid_sum_ordered(float* part, double* part2, int
     }
     __syncthreads();
     if (!*flag) return;
-    for (int i = tid; i < n; i += THREADS) {
+    for (int i = tid; i < n; i += T) {
         double s = 0.0;
         for (int g0 = 0; g0 < ngroups; g0 += 8) {
             double v[8];

@@ -75,6 +75,17 @@ int gemm_rowsq_parts(int N);             // upper bound of *rowsq_parts: sizes t
 bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                        int lda, int ldb, int ldc, float alpha, const float* bias_n, hipStream_t s, double* colstats,
                        float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip = false, const GridSumWs* sums = nullptr);
+// Row-panel kernel for per-rank batch sizes (gemm_rows.hip): a workgroup owns 32 rows and all N <= 320 columns.
+// A [M][K] row-major; b_layout as launch_gemm. colstats (+ sums): ordered column sums of the output; rowsq [M]: COMPLETE
+// rowsq_scale · Σ_cols C² per row (no parts); bn: the batch-norm backward of launch_bn_dx applied to the rows of A as they are
+// loaded, dx written back over dy (b_layout 1 only). false: shape not covered, nothing launched.
+struct BnDxFused { float* dy; const float* pre; const float* mean; const float* inv_std; const double* sums;
+                   float* dbeta; float* dgamma; float* grad_bias; double n_global; };
+bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
+                      float rowsq_scale, const BnDxFused* bn);
+bool gemm_rows_covers(int b_layout, int M, int N, int K, bool colstats, bool rowsq, bool bn);      // what launch_gemm_rows accepts
+int gemm_rows_max_m();                   // largest M launch_gemm sends to the row-panel kernel (NVSM_GEMM_ROWS_MAX, default 16384; 0 = never)
 void gemm_set_tstat_enabled(bool on);    // experiments / tests: force the tiled kernel
 void launch_sum_parts(const float* parts, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
 void gemm_set_panel_enabled(bool on);    // experiments / tests: force the tiled kernel

@@ -448,7 +448,8 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         hipDeviceProp_t prop{};
         NVSM_HIP_CHECK(hipGetDeviceProperties(&prop, cfg.device));
         const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        alloc_sums(sums_fwd_, std::max(4, (de + 127) / 128), std::max<int>(cus, static_cast<int>((B + 127) / 128)), 2 * 160);
+        // or per 32 rows and all columns at once (row-panel kernel, per-rank batch sizes)
+        alloc_sums(sums_fwd_, std::max(4, (de + 127) / 128), std::max<int>(cus, static_cast<int>((B + 31) / 32)), std::max(2 * 160, 2 * de));
         alloc_sums(sums_bwd_, 1, static_cast<int>((B + 3) / 4), 2 * de + 1);
     }
     bn_mean_.alloc(de, true); bn_inv_std_.alloc(de, true); dbeta_.alloc(de, true); dgamma_.alloc(de, true);
@@ -1058,6 +1059,39 @@ void Model::backward_dx() {
     const bool dp = cfg_.world_size > 1;
     const double B_global = static_cast<double>(B) * (dp ? cfg_.world_size : 1);
 
+    const bool need_msq = cfg_.update_method == NVSM_ADAGRAD ||
+                          (cfg_.update_method == NVSM_ADAM && cfg_.adam_mode != NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE);
+    const bool l2p = cfg_.l2_normalize_phrase_reprs != 0;
+    const float inv_w = static_cast<float>(std::exp(-std::log(static_cast<double>(w))));
+    const float inv_dw = static_cast<float>(std::exp(-std::log(static_cast<double>(dw))));
+    // Per-rank batch sizes (gemm_rows.hip): batch-norm backward, the dx·T product and the rows' mean of squares are ONE launch
+    // — the kernel owns whole rows of dy, applies dx = invσ·(dy − (dβ + x̂·dγ)/N) as it loads them (writing dx back for the
+    // dT product) and finishes each row's sum of squares itself. Three launches and two gaps less on the critical stream.
+    const bool sync_bn_order = !dp || cfg_.sync_batch_norm;       // (per-shard batch-norm under DP reduces AFTER bn_dx: separate launches)
+    if (cfg_.batch_normalization && sync_bn_order && !l2p && B >= 512 && B <= gemm_rows_max_m() &&
+        gemm_rows_covers(1, static_cast<int>(B), dw, de, false, need_msq, true)) {
+        if (dp) allreduce_f64(stats_bwd_, 1 + 2 * de);
+        BnDxFused bn{dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, stats_bwd_ + 1, dbeta_.p, dgamma_.p, gb_.p, dp ? B_global : static_cast<double>(B)};
+        bool launched = false;
+        {
+            PROF("gemm_bwd_x");
+            launch_and_record(ev_bwdx_, stream_, [&] {
+                launched = launch_gemm_rows(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
+                                            nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &bn);
+            });
+        }
+        if (launched) {
+            // dx is final when this kernel is through: the dT GEMM of the fused step follows it (a wait on a kernel-borne event
+            // must be issued right behind the launch, see below)
+            if (dx_follower_) NVSM_HIP_CHECK(hipStreamWaitEvent(dx_follower_, ev_bwdx_, 0));
+            if (dp) loss_reduced_ = true;
+            return;
+        }
+        // (shape not covered: the event was recorded on an empty launch; fall through to the separate kernels. The statistics
+        //  have been all-reduced already under DP, which the code below must not repeat.)
+        throw Error(NVSM_ERR_UNSUPPORTED, "row-panel GEMM refused a shape its caller had checked");
+    }
+
     // B5: bias gradient / BN backward (params.cu:509-521)
     {
         PROF("bn_backward");
@@ -1093,14 +1127,9 @@ void Model::backward_dx() {
     // B7 + B9: gphrase[B][dw] = dx[B][de] · T (stored [dw][de]) / w   (objective.cu:447-476)
     {
         PROF("gemm_bwd_x");
-        const float inv_w = static_cast<float>(std::exp(-std::log(static_cast<double>(w))));
         // the words update of Adam (sparse / dense_update) and Adagrad needs mean_t(gphrase[b][t]²) per window
-        // (cpp/updates_adam.cu:232-240, updates_adagrad.cu:136-143): emitted by the GEMM epilogue, per 128-column tile
-        const bool need_msq = cfg_.update_method == NVSM_ADAGRAD ||
-                              (cfg_.update_method == NVSM_ADAM && cfg_.adam_mode != NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE);
-        const float inv_dw = static_cast<float>(std::exp(-std::log(static_cast<double>(dw))));
+        // (cpp/updates_adam.cu:232-240, updates_adagrad.cu:136-143): emitted by the GEMM epilogue, per column tile
         // (A/B, interleaved: 1.235 ms per step with the epilogue fusion vs 1.262 ms with a separate row-mean-of-squares pass)
-        const bool l2p = cfg_.l2_normalize_phrase_reprs != 0;
         int msq_parts = 0;
         launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, l2p ? 1.f : inv_w, nullptr, 1, 0, stream_,
                     nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw, &msq_parts);

@@ -40,6 +40,15 @@ def test_gemm_layouts(M, N, K, layout):
     assert rel_err(Cout, ref) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(1031, 256, 300), (4099, 300, 256), (2048, 256, 128), (1500, 128, 256), (16390, 256, 300)])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_gemm_large_batch_kernels(M, N, K, layout, monkeypatch):
+    """The same batch-sized products with the row-panel kernel of the per-rank batch sizes (gemm_rows.hip, which takes
+    512 <= M <= 16 384 by default) switched off: the LDS-stationary / tiled kernels the 51 200-window batch runs on."""
+    monkeypatch.setenv("NVSM_GEMM_ROWS_MAX", "0")
+    test_gemm_layouts(M, N, K, layout)
+
+
 @pytest.mark.parametrize("split", [2, 7, 128])
 def test_gemm_split_k(split):
     rs = np.random.RandomState(split)

@@ -210,6 +210,47 @@ int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const 
     });
 }
 
+// average milliseconds of one launch_gemm of the batch-sized products on device-resident operands (A [M][K], B per b_layout):
+// extras bit 0 = ordered column statistics (the forward product), bit 1 = row sums of squares (the backward one)
+int nvsm_debug_gemm_time(int b_layout, int M, int N, int K, int extras, int repeats, float* avg_ms) {
+    NVSM_REQUIRE(avg_ms);
+    return guarded([&] {
+        cunvsm::DevBuf<float> A, B, C, rowsq, part;
+        cunvsm::DevBuf<double> stats, part2;
+        cunvsm::DevBuf<int> arrive;
+        A.alloc(static_cast<size_t>(M) * K, true); B.alloc(static_cast<size_t>(K) * N, true); C.alloc(static_cast<size_t>(M) * N);
+        cunvsm::GridSumWs ws{};
+        if (extras & 1) {
+            ws.colgroups = 8; ws.contrib_cap = M / 32 + 512; ws.width_cap = 2 * (N > 160 ? N : 160); ws.groups_cap = ws.contrib_cap / 16 + 1; ws.fan = 16;
+            part.alloc(static_cast<size_t>(ws.colgroups) * ws.contrib_cap * ws.width_cap);
+            part2.alloc(static_cast<size_t>(ws.colgroups) * ws.groups_cap * ws.width_cap);
+            arrive.alloc(static_cast<size_t>(ws.colgroups) * (ws.groups_cap + 1), true);
+            stats.alloc(2 * static_cast<size_t>(N), true);
+            ws.part = part.p; ws.part2 = part2.p; ws.arrive = arrive.p;
+        }
+        if (extras & 2) rowsq.alloc(static_cast<size_t>(M) * cunvsm::gemm_rowsq_parts(N));
+        hipStream_t s;
+        NVSM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        hipEvent_t e0, e1;
+        NVSM_HIP_CHECK(hipEventCreate(&e0)); NVSM_HIP_CHECK(hipEventCreate(&e1));
+        const int ldb = b_layout ? K : N;
+        int parts = 0;
+        auto go = [&] {
+            cunvsm::launch_gemm(0, b_layout, A.p, B.p, C.p, M, N, K, K, ldb, N, 1.f, nullptr, 1, 0, s, (extras & 1) ? stats.p : nullptr,
+                                (extras & 2) ? rowsq.p : nullptr, 1.f, &parts, false, (extras & 1) ? &ws : nullptr);
+        };
+        for (int i = 0; i < 3; ++i) go();
+        NVSM_HIP_CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < repeats; ++i) go();
+        NVSM_HIP_CHECK(hipEventRecord(e1, s));
+        NVSM_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        NVSM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = ms / static_cast<float>(repeats > 0 ? repeats : 1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    });
+}
+
 int nvsm_debug_sort(int64_t n, int bits, const int32_t* keys, int32_t* keys_out, int32_t* vals_out, int repeats, float* avg_ms) {
     NVSM_REQUIRE(keys); NVSM_REQUIRE(keys_out); NVSM_REQUIRE(vals_out);
     return guarded([&] {

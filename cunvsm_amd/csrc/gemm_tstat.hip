@@ -346,6 +346,21 @@ static bool tstat_launch(const TstatArgs& g, size_t lds, int wgs, hipStream_t s)
 #ifdef NVSM_TSTAT_DBG
 static int g_tstat_dbg = 0;
 #endif
+
+// 256 bytes per device that nobody reads: where lanes outside a matrix store, so that every store of a pipelined loop body
+// is unconditional (see tstat_block). Null: allocation failed.
+float* gemm_dump_buffer() {
+    static std::atomic<float*> dump[kTstatMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kTstatMaxDevices) return nullptr;
+    float* p = dump[dev].load(std::memory_order_acquire);
+    if (p) return p;
+    float* fresh = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&fresh), 256) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    float* expected = nullptr;
+    if (!dump[dev].compare_exchange_strong(expected, fresh, std::memory_order_acq_rel)) { (void)hipFree(fresh); return expected; }      // another thread was first
+    return fresh;
+}
 static bool g_gemm_tstat_enabled = true;
 void gemm_set_tstat_enabled(bool on) { g_gemm_tstat_enabled = on; }
 
@@ -379,9 +394,8 @@ bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* 
         if (need <= kTstatLdsBytes) { parts = p; NT = nt; break; }
     }
     if (!parts) return false;
-    // per device ordinal: the CU count that sizes the grid and the 16 bytes nobody reads
+    // per device ordinal: the CU count that sizes the grid
     static std::atomic<int> cus_of[kTstatMaxDevices];
-    static std::atomic<float*> dump[kTstatMaxDevices];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kTstatMaxDevices) return false;
     int num_cus = cus_of[dev].load(std::memory_order_acquire);
@@ -390,14 +404,10 @@ bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* 
         num_cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         cus_of[dev].store(num_cus, std::memory_order_release);
     }
-    if (!dump[dev].load(std::memory_order_acquire)) {
-        float* fresh = nullptr;
-        if (hipMalloc(reinterpret_cast<void**>(&fresh), 256) != hipSuccess) { (void)hipGetLastError(); return false; }
-        float* expected = nullptr;
-        if (!dump[dev].compare_exchange_strong(expected, fresh, std::memory_order_acq_rel)) (void)hipFree(fresh);      // another thread was first
-    }
+    float* dump = gemm_dump_buffer();
+    if (!dump) return false;
     TstatArgs g{};
-    g.dump = dump[dev].load(std::memory_order_acquire);
+    g.dump = dump;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = alpha; g.bias_n = bias_n; g.colstats = colstats; g.rowsq = rowsq; g.rowsq_scale = rowsq_scale;
     g.parts = parts; g.nblocks = (M + 15) / 16;

@@ -86,6 +86,7 @@ bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, in
                       float rowsq_scale, const BnDxFused* bn);
 bool gemm_rows_covers(int b_layout, int M, int N, int K, bool colstats, bool rowsq, bool bn);      // what launch_gemm_rows accepts
 int gemm_rows_max_m();                   // largest M launch_gemm sends to the row-panel kernel (NVSM_GEMM_ROWS_MAX, default 16384; 0 = never)
+float* gemm_dump_buffer();               // 256 B per device nobody reads (gemm_tstat.hip): the target of masked-out stores
 void gemm_set_tstat_enabled(bool on);    // experiments / tests: force the tiled kernel
 void launch_sum_parts(const float* parts, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
 void gemm_set_panel_enabled(bool on);    // experiments / tests: force the tiled kernel

@@ -328,13 +328,18 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
         const bool lazy_enabled = !(lazy_env && lazy_env[0] == '0');
         const bool sparse_adam = method == NVSM_ADAM && mode <= NVSM_ADAM_SPARSE;
         const bool decays = sparse_adam || (method != NVSM_ADAM && cfg_.regularization_lambda > 0.f);
-        // Lazy decay puts the batch's sort in front of the first gather (the rows to bring up to date are the CSR's touched
-        // list): ≈0.1 ms of latency. It pays when the dense passes it saves cost more than that, i.e. for tables of
-        // hundreds of MB (configs[4]); at the LSE shape (a 100 MB table, batch 4096) it made the step 0.28 → 0.34 ms.
-        const char* min_env = std::getenv("NVSM_LAZY_MIN_MB");          // (per handle, as NVSM_LAZY_DECAY: the tests use small tables)
-        const double lazy_min_mb = min_env ? std::atof(min_env) : 384.0;
+        // When lazy decay pays. The dense passes it saves must cost more than what it adds (a snapshot and a stamp launch per
+        // update on the table's stream, a stamp load per gathered row): tables of hundreds of MB (configs[4]) always; with
+        // sparse Adam — two dense arrays per table, P and m — from about a hundred MB of state, which is what makes the
+        // per-rank share of the 8-GPU metric (6 400 windows against 50 k / 100 k rows) lazy for both tables: 0.335 -> 0.292 ms
+        // per step (words alone 0.299, documents alone 0.322; interleaved A/B). Not the LSE shape (Adagrad, batch 4096, a
+        // 100 MB words table): 0.182 -> 0.193 ms with a lazy words table. NVSM_LAZY_MIN_MB overrides (tests use small tables).
+        const char* min_env = std::getenv("NVSM_LAZY_MIN_MB");          // (per handle, as NVSM_LAZY_DECAY)
+        const double lazy_min_mb = min_env ? std::atof(min_env) : (sparse_adam ? 96.0 : 384.0);
         const double state_mb = static_cast<double>(rows) * dim * sizeof(float) * (method == NVSM_ADAM ? 2.0 : 1.0) / 1048576.0;
-        t.lazy = lazy_enabled && decays && state_mb >= lazy_min_mb &&
+        const char* tab_env = std::getenv("NVSM_LAZY_TABLES");          // experiments: bit 0 = words, bit 1 = documents
+        const int tab_mask = tab_env ? std::atoi(tab_env) : 3;
+        t.lazy = lazy_enabled && decays && state_mb >= lazy_min_mb && ((tab_mask >> (&t == &ents_ ? 1 : 0)) & 1) &&
                  static_cast<double>(rows) * table_split_ratio() >= static_cast<double>(max_entries);
         t.lazy_scalar = sparse_adam || (method == NVSM_ADAGRAD && &t == &ents_);
         if (t.lazy) t.stamp.alloc(rows, true);
@@ -454,6 +459,14 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     }
     bn_mean_.alloc(de, true); bn_inv_std_.alloc(de, true); dbeta_.alloc(de, true); dgamma_.alloc(de, true);
     gT_.alloc(static_cast<size_t>(de) * dw, true); gb_.alloc(de, true);
+    // split-K slabs of the dT product: 128 at the 51 200-window batch (400 rows each); a per-rank batch of a few thousand
+    // windows cut 128 ways is 600 workgroups of two 32-deep K tiles each — all prologue, epilogue and 39 MB of partials
+    // (158 us next to the updates at batch 6 400: step 0.360 ms; 50 slabs 0.291, 25 slabs 0.295, 12 slabs 0.296, interleaved
+    // A/B). 128 rows per slab at least. NVSM_DT_SLABS overrides.
+    {
+        const char* e = std::getenv("NVSM_DT_SLABS");
+        gemm_slabs_want_ = e ? std::atoi(e) : static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, B / 128)));
+    }
     const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
     gT_partial_.alloc(static_cast<size_t>(slabs) * de * dw);
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));

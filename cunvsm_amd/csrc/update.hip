@@ -1085,8 +1085,9 @@ static bool entry_walk_enabled() {
     return on;
 }
 // NVSM_ENTRY_WALK_MIN (tests: 0 sends small batches through the entry walk too)
-static int64_t entry_walk_min_entries() {
+static int64_t entry_walk_min_entries(int table) {
     const char* e = std::getenv("NVSM_ENTRY_WALK_MIN");      // (read per launch: tests switch it)
+    if (const char* t = std::getenv(table == 0 ? "NVSM_ENTRY_WALK_MIN_WORDS" : "NVSM_ENTRY_WALK_MIN_DOCS")) e = t;      // experiments: per table
     return e ? std::atoll(e) : 64ll * 4096;
 }
 static bool entry_walk_kind(int kind) { return kind == ROW_SGD || kind == ROW_ADAGRAD_ENT || kind == ROW_ADAM_MV || kind == ROW_ADAM_SPARSE_ENT; }
@@ -1138,7 +1139,7 @@ int launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hipS
     }
     // (rows of up to two waves' width, held side by side in registers; batches of a few thousand windows are a chain of launch latencies, not of round trips per
     //  row, and keep the one-launch list walk: LSE batch 4096 0.234 vs 0.254 ms per step)
-    if (a.touched_only && nvec <= 128 && c.n >= entry_walk_min_entries() && entry_walk_enabled() && entry_walk_kind(a.kind)) {
+    if (a.touched_only && nvec <= 128 && c.n >= entry_walk_min_entries(a.table) && entry_walk_enabled() && entry_walk_kind(a.kind)) {
         // the rows with entries, by walking the sorted entries; the chunk tree (if the batch can have rows that long) in a
         // launch of its own, which also finishes those rows
         a.rows_elsewhere = 1;

@@ -256,6 +256,8 @@ int nvsm_debug_delay(nvsm_model* m, int microseconds);
  * forms are bit-identical (tests/test_gpu_parity.py); process-wide */
 int nvsm_debug_set_table_pass_form(int one_launch);
 /* the stable (row, entry) radix sort alone: keys of `bits` significant bits in, sorted keys + their original positions out */
+/* average ms per launch of a batch-sized projection product on device operands (extras: 1 = column statistics, 2 = row sums of squares) */
+int nvsm_debug_gemm_time(int b_layout, int M, int N, int K, int extras, int repeats, float* avg_ms);
 int nvsm_debug_sort(int64_t n, int bits, const int32_t* keys, int32_t* keys_out, int32_t* vals_out, int repeats, float* avg_ms);
 int nvsm_debug_gather_mean(int64_t num_rows, int dim, const float* table, const int64_t* idx, const float* wts,
                            int window, int64_t num_out, float* out);

@@ -479,6 +479,12 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
     loss_block_sums(a, s_dy, s_dyx, s_loss, reinterpret_cast<int*>(s_loss + 4));
 }
 
+// (Round 3 tried the document rows landing in LDS instead of registers — entity_dim = 256 makes a row exactly the 1 KB one
+//  global_load_lds_dwordx4 moves per wave; two 17 KB slots per wave, the next example's rows in flight by LDS-DMA under this
+//  example's arithmetic, bit-identical outputs. One workgroup of four waves then owns a CU's LDS: 68 rows in flight per CU
+//  where twelve register-landing waves hold up to 204, and the kernel took 222 instead of 180 us in-step at |D| = 100 k, 383
+//  instead of 279 us at |D| = 2 M. The register file (512 KB per CU) is the larger landing buffer; removed.)
+
 template <int V, int NITER>
 static void launch_loss_t(const LossArgs& a_in, hipStream_t s) {
     const int grid = ceil_div(a_in.B, 4 * kExamplesPerWave);

@@ -490,3 +490,4 @@ def test_mixed_host_and_device_batches_ragged_sizes_back_to_back():
     assert costs_b == costs_a[-8:]
     for n in PARAMS:
         np.testing.assert_array_equal(a.get_param(n), b.get_param(n))
+

@@ -26,7 +26,6 @@ namespace cunvsm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int RM = 32, RK = 32;
-constexpr int kRowsMaxWaves = 10;              // N <= 320 (ten waves of one 32-column tile, or five of two)
 constexpr size_t kRowsLdsBytes = 128 * 1024;   // two A + two B images; more than 64 KB needs the per-kernel, per-device opt-in
 constexpr int kRowsMaxDevices = 64;
 

@@ -90,6 +90,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_rows_kernel(RowsArgs g) {
             if (blockIdx.x == 0) { g.dbeta[k] = db; g.dgamma[k] = dg; g.grad_bias[k] = db; }      // ∂β is the bias gradient; ∂γ is dropped (:173)
         }
     }
+    if (!PRE && g.grad_bias && blockIdx.x == 0)      // no batch-norm: the bias gradient is Σdy (launch_colsum_finalize's job, riding here)
+        for (int k = tid; k < g.K; k += nthreads) g.grad_bias[k] = static_cast<float>(g.bn_sums[k]);
     // the B images' columns N .. NP are never written by store_tile: zero them once (they feed MFMAs whose results are dropped,
     // but NaN bit patterns left in LDS would poison the row sums of squares otherwise)
     for (int i = tid; i < 2 * BIMG; i += nthreads) Bs0[i] = 0.f;
@@ -315,7 +317,8 @@ bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, in
     if ((lda % 4) || (ldb % 4) || (ldc % 4)) return false;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) % 16) return false;
     int tpw = 0, waves = 0;
-    const size_t lds = rows_plan(b_layout, M, N, K, colstats != nullptr, rowsq != nullptr, bn != nullptr, &tpw, &waves);
+    const bool fused_bn = bn && bn->pre;
+    const size_t lds = rows_plan(b_layout, M, N, K, colstats != nullptr, rowsq != nullptr, fused_bn, &tpw, &waves);
     if (!lds) return false;
     const int grid = (M + RM - 1) / RM;
     RowsArgs g{};
@@ -326,7 +329,9 @@ bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, in
         if (!sums || sums->contrib_cap < grid || sums->width_cap < 2 * N || sums->groups_cap < (grid + fan - 1) / fan) return false;
         g.sums = *sums; g.sums.fan = fan;
     }
-    if (bn) {
+    if (bn && !bn->pre) {      // bias gradient only (no batch-norm)
+        g.bn_sums = bn->sums; g.grad_bias = bn->grad_bias;
+    } else if (bn) {
         g.A_rw = bn->dy; g.pre = bn->pre; g.mean = bn->mean; g.inv_std = bn->inv_std; g.bn_sums = bn->sums;
         g.dbeta = bn->dbeta; g.dgamma = bn->dgamma; g.grad_bias = bn->grad_bias; g.inv_n = static_cast<float>(1.0 / bn->n_global);
     }
@@ -338,7 +343,7 @@ bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, in
 #define NVSM_ROWS_CASE(T, W)                                                                          \
     if (tpw == T && waves == W) {                                                                     \
         if (b_layout == 0) { if constexpr (W == 4 || W == 8) return rows_launch<0, false, T, W>(g, grid, lds, s); else return false; } \
-        if (bn) return rows_launch<1, true, T, W>(g, grid, lds, s);                                   \
+        if (fused_bn) return rows_launch<1, true, T, W>(g, grid, lds, s);                                   \
         return rows_launch<1, false, T, W>(g, grid, lds, s);                                          \
     }
     NVSM_ROWS_CASE(1, 4) NVSM_ROWS_CASE(2, 4) NVSM_ROWS_CASE(2, 5) NVSM_ROWS_CASE(1, 8) NVSM_ROWS_CASE(1, 10)

@@ -78,7 +78,8 @@ bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* 
 // Row-panel kernel for per-rank batch sizes (gemm_rows.hip): a workgroup owns 32 rows and all N <= 320 columns.
 // A [M][K] row-major; b_layout as launch_gemm. colstats (+ sums): ordered column sums of the output; rowsq [M]: COMPLETE
 // rowsq_scale · Σ_cols C² per row (no parts); bn: the batch-norm backward of launch_bn_dx applied to the rows of A as they are
-// loaded, dx written back over dy (b_layout 1 only). false: shape not covered, nothing launched.
+// loaded, dx written back over dy (b_layout 1 only); bn with pre == null: only grad_bias = (float) sums[k] (no batch-norm: what
+// launch_colsum_finalize does). false: shape not covered, nothing launched.
 struct BnDxFused { float* dy; const float* pre; const float* mean; const float* inv_std; const double* sums;
                    float* dbeta; float* dgamma; float* grad_bias; double n_global; };
 bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,

@@ -416,7 +416,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, dev_flags));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, dev_flags));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, dev_flags));
-    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_step_begin_[0], &ev_step_begin_[1], &ev_gathered_, &ev_csr_all_})
+    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_step_begin_[0], &ev_step_begin_[1], &ev_gathered_})
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, dev_flags));
     for (hipEvent_t* e : {&ev_copied_, &ev_host_ids_[0], &ev_host_ids_[1]})
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -439,7 +439,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     if (cfg.sampler == NVSM_SAMPLER_HOST_MINSTD)
         for (int p = 0; p < 2; ++p) NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_ids_pin_[p]), N * sizeof(int64_t), hipHostMallocDefault));
     if (cfg.world_size > 1) loss_tmp_.alloc(1, true);
-    widx_.alloc(B * w); ids_.alloc(N);
+    widx_.alloc(B * w); ids_buf_[0].alloc(N); ids_buf_[1].alloc(N); ids_p_ = ids_buf_[0].p;
     phrase_.alloc(B * dw); phrase_alt_.alloc(B * dw); phrase_p_ = phrase_.p; pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
     if (cfg.l2_normalize_phrase_reprs) { phrase_raw_.alloc(B * dw); phrase_norms_.alloc(B); }
     if (cfg.l2_normalize_entity_reprs) { grad_entity_.alloc(N * de); ge_msq_.alloc(N); }
@@ -481,7 +481,7 @@ Model::~Model() {
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
     for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_, ev_copied_, ev_step_begin_[0], ev_step_begin_[1],
-                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_, ev_csr_all_}) if (e) (void)hipEventDestroy(e);
+                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_}) if (e) (void)hipEventDestroy(e);
     for (int p = 0; p < 2; ++p) if (host_ids_pin_[p]) (void)hipHostFree(host_ids_pin_[p]);
     if (err_host_) (void)hipHostFree(err_host_);
     // (copy_stream_ is side stream 3)
@@ -793,6 +793,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         csr_joined_ents_ = csr_joined_words_ = true;
     }
 
+    ids_p_ = (ids_p_ == ids_buf_[0].p) ? ids_buf_[1].p : ids_buf_[0].p;
     // device-sampler mode: zeroing the statistics, narrowing the word ids and drawing the document ids are one launch
     const bool fused_prologue = !entity_ids && cfg_.sampler != NVSM_SAMPLER_HOST_MINSTD;
     if (!fused_prologue)
@@ -866,7 +867,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         PROF("sample_entities");
         if (entity_ids) {
             NVSM_HIP_CHECK(hipMemcpyAsync(in_ids64_.p, entity_ids, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
-            launch_narrow_i64(in_ids64_.p, ids_.p, N, cfg_.num_entities, err_host_, NVSM_BAD_ENTITY_ID, stream_);
+            launch_narrow_i64(in_ids64_.p, ids_p_, N, cfg_.num_entities, err_host_, NVSM_BAD_ENTITY_ID, stream_);
         } else if (cfg_.sampler == NVSM_SAMPLER_HOST_MINSTD) {
             host_labels_.resize(B);
             if (batch.on_device) {
@@ -885,12 +886,12 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             NVSM_HIP_CHECK(hipMemcpyAsync(in_ids64_.p, host_ids_pin_[hp], N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
             NVSM_HIP_CHECK(hipEventRecord(ev_host_ids_[hp], stream_));
             host_ids_used_[hp] = true;
-            launch_narrow_i64(in_ids64_.p, ids_.p, N, cfg_.num_entities, err_host_, NVSM_BAD_ENTITY_ID, stream_);
+            launch_narrow_i64(in_ids64_.p, ids_p_, N, cfg_.num_entities, err_host_, NVSM_BAD_ENTITY_ID, stream_);
         } else {
             // (the prologue carries "inputs consumed, ids final" as its completion event: no packet between it and the gather)
             launch_and_record(ev_inputs_, stream_, [&] {
                 launch_step_prologue(words_dev, widx_.p, B * w, labels_dev_, B, R_, cfg_.num_words, cfg_.num_entities,
-                                     device_seed_ + 0x9E37u * cfg_.rank, step_count_, ids_.p, stats_.p, static_cast<int>(stats_.n),
+                                     device_seed_ + 0x9E37u * cfg_.rank, step_count_, ids_p_, stats_.p, static_cast<int>(stats_.n),
                                      err_host_, stream_);
             });
         }
@@ -921,13 +922,9 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         if (se != aux_stream_ && E_pending_ && ents_.idx_sets < 2) NVSM_HIP_CHECK(hipStreamWaitEvent(se, ev_E_done_, 0));
         csr_joined_ents_ = csr_joined_words_ = false;
         words_csr_stream_ = sw;
-        auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, ids_.p, N, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
+        auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, ids_p_, N, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
         auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, widx_.p, B * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
         if (layout == 1) { wrds(); ents(); } else { ents(); wrds(); }
-        // one event for "both builds done", made on a side stream (where a wait costs nothing that matters): the fused step's
-        // main stream then stops at one wait packet in front of the words update instead of two
-        if (se != sw) NVSM_HIP_CHECK(hipStreamWaitEvent(sw, ev_csr_ents_, 0));
-        NVSM_HIP_CHECK(hipEventRecord(ev_csr_all_, sw));
         if (se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
     };
     const bool any_lazy = words_.lazy || ents_.lazy;
@@ -994,7 +991,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         LossArgs a{};
         a.pre = pre_.p; a.bn_mean = bn_mean_.p; a.bn_inv_std = bn_inv_std_.p; a.bias = b_.p;
         a.bn_sums = stats_fwd_; a.bn_n = bn_n; a.bn_eps = 1e-4f;
-        a.E = ents_.P.p; a.ids = ids_.p; a.inst_w = instw_;
+        a.E = ents_.P.p; a.ids = ids_p_; a.inst_w = instw_;
         a.proj = proj_.p; a.dy = dy_.p; a.coef = coef_.p; a.probs = probs_.p; a.pp = pp_.p;
         a.loss_acc = stats_bwd_; a.colstats = stats_bwd_ + 1; a.sums = sums_bwd_.ws;
         a.B = B; a.de = de; a.R = R_; a.k = k;
@@ -1103,6 +1100,26 @@ void Model::backward_dx() {
         // (shape not covered: the event was recorded on an empty launch; fall through to the separate kernels. The statistics
         //  have been all-reduced already under DP, which the code below must not repeat.)
         throw Error(NVSM_ERR_UNSUPPORTED, "row-panel GEMM refused a shape its caller had checked");
+    }
+
+    // ... and without batch-norm (the LSE recipe) the same kernel finalises the bias gradient Σdy and the rows' mean of squares:
+    // colsum_finalize + GEMM + sum_parts as one launch
+    if (!cfg_.batch_normalization && !l2p && B >= 512 && B <= gemm_rows_max_m() &&
+        gemm_rows_covers(1, static_cast<int>(B), dw, de, false, need_msq, false)) {
+        if (dp) allreduce_f64(stats_bwd_, 1 + de);
+        BnDxFused bias_only{nullptr, nullptr, nullptr, nullptr, stats_bwd_ + 1, nullptr, nullptr, gb_.p, 1.0};
+        bool launched = false;
+        {
+            PROF("gemm_bwd_x");
+            launch_and_record(ev_bwdx_, stream_, [&] {
+                launched = launch_gemm_rows(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
+                                            nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &bias_only);
+            });
+        }
+        if (!launched) throw Error(NVSM_ERR_UNSUPPORTED, "row-panel GEMM refused a shape its caller had checked");
+        if (dx_follower_) NVSM_HIP_CHECK(hipStreamWaitEvent(dx_follower_, ev_bwdx_, 0));
+        if (dp) loss_reduced_ = true;
+        return;
     }
 
     // B5: bias gradient / BN backward (params.cu:509-521)
@@ -1361,7 +1378,7 @@ void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row
     if (cfg_.l2_normalize_entity_reprs) {
         // optional entity normaliser: the per-entry gradient rows are materialised (as the reference does) and scattered as
         // they are: source row = entry, coefficient 1, per-entry mean of squares
-        launch_materialize_grad_entity_l2(coef_.p, proj_.p, t.P.p, ids_.p, N, R_, de, grad_entity_.p, ge_msq_.p, strm);
+        launch_materialize_grad_entity_l2(coef_.p, proj_.p, t.P.p, ids_p_, N, R_, de, grad_entity_.p, ge_msq_.p, strm);
         a.X = grad_entity_.p; a.coefs = nullptr; a.div = 1; a.div_magic = (uint64_t(1) << 37) + 1;
         if (a.sq_src) a.sq_src = ge_msq_.p;
     }
@@ -1542,9 +1559,13 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         NVSM_HIP_CHECK(hipEventRecord(ev_T_done_, aux2_stream_));
         T_pending_ = true;
     }
-    // (the documents build too — finished long ago, its update is running —, so that the next step's prologue, which
-    //  rewrites the ids both builds read, does not have to stop for either: ev_csr_all_ stands for both)
-    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_all_, 0));
+    // The words update follows the words CSR build only. The documents build is not waited for on this stream at all: its
+    // ids live in the buffer this step's prologue wrote, the next prologue writes the other one, and the step after that is
+    // behind the next loss kernel, which joins this step's documents update, which followed its CSR build. (One event for
+    // both builds, made on side stream 2 behind a wait for the documents build, was the previous form: two cross-stream hops
+    // of 10 us each, and at batch 4096 the documents build — not the backward GEMM — then decided when the words update
+    // started: 24 us of idle main stream.)
+    NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
     csr_joined_ents_ = csr_joined_words_ = true;
     // A words table split into rows with and without entries (tables larger than the batch, not lazily decayed): the
     // streaming decay of the rows WITHOUT entries does not belong on the critical stream between the passes over the rows
@@ -1700,14 +1721,14 @@ void Model::get_tensor(const std::string& name, float* dst, int64_t count) {
     else if (name == "grad_entity") {
         if (grad_entity_.n < static_cast<size_t>(count)) grad_entity_.alloc(count);
         if (cfg_.l2_normalize_entity_reprs)
-            launch_materialize_grad_entity_l2(coef_.p, proj_.p, ents_.P.p, ids_.p, B_ * R_, R_, cfg_.entity_repr_size, grad_entity_.p, nullptr, stream_);
+            launch_materialize_grad_entity_l2(coef_.p, proj_.p, ents_.P.p, ids_p_, B_ * R_, R_, cfg_.entity_repr_size, grad_entity_.p, nullptr, stream_);
         else
             launch_materialize_grad_entity(coef_.p, proj_.p, B_ * R_, R_, cfg_.entity_repr_size, grad_entity_.p, stream_);
         src = grad_entity_.p;
     } else if (name == "entity_ids") {
         std::vector<int> h(count);
         synchronize();
-        NVSM_HIP_CHECK(hipMemcpy(h.data(), ids_.p, count * sizeof(int), hipMemcpyDeviceToHost));
+        NVSM_HIP_CHECK(hipMemcpy(h.data(), ids_p_, count * sizeof(int), hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < count; ++i) dst[i] = static_cast<float>(h[i]);
         return;
     }

@@ -206,7 +206,6 @@ class Model {
     // dx GEMM and the words update on the main stream
     hipEvent_t ev_gathered_ = nullptr;
     hipEvent_t ev_loss_ = nullptr, ev_dx_ = nullptr, ev_bwdx_ = nullptr, ev_E_done_ = nullptr, ev_T_done_ = nullptr;
-    hipEvent_t ev_csr_all_ = nullptr;           // both tables' CSR builds of this step are done (recorded on the words build's stream)
     hipStream_t words_csr_stream_ = nullptr;            // the side stream that built this step's words CSR (NVSM_SORT_LAYOUT)
     hipStream_t words_untouched_stream_ = nullptr;      // set by step() around update_words (kernels.h launch_table_pass untouched_s)
     bool words_tail_pending_ = false;                   // side stream 2 still decays words rows: the next word gather joins it
@@ -226,7 +225,9 @@ class Model {
     hipStream_t copy_stream_ = nullptr;   // alias of aux3_stream_
     hipEvent_t ev_copied_ = nullptr, ev_step_begin_[2] = {nullptr, nullptr};
     bool copied_recorded_ = false, last_batch_on_host_ = false;
-    DevBuf<int> widx_, ids_;
+    DevBuf<int> widx_, ids_buf_[2];
+    int* ids_p_ = nullptr;            // this step's document ids: the two buffers alternate, so that a step's prologue never
+                                      //   rewrites the ids the previous step's documents CSR build may still be reading
     const float* wwts_ = nullptr;     // device pointer or null
     const float* instw_ = nullptr;
     const int64_t* labels_dev_ = nullptr;

@@ -141,6 +141,7 @@ void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared) {
 template <int TABLE> struct SegUnrollDeep { static constexpr int value = TABLE == 0 ? NVSM_SEG_UNROLL_WORDS : NVSM_SEG_UNROLL_DOCS; };
 // rows of a table much larger than the batch hold one or two entries: two slots in flight per lane leave registers for
 // 2-3x as many rows in flight per CU, which is what bounds that regime (a dependent chain of four loads per row)
+constexpr int kSegUnrollScalar = 16;      // ROW_SCALAR_ACC gathers scalars only: sixteen entries in flight cost a handful of registers
 constexpr int kSegUnrollShallow = 4;      // (2 at first; A/B over 2-4: LSE batch 4096 0.197 -> 0.193 ms, |D| = 2 M unchanged)
 
 template <int V, int TABLE, bool VEC, int kSegUnroll = SegUnrollDeep<TABLE>::value>
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void chunk_pass_kernel(Csr c, RowPassArgs a, i
 #pragma unroll
             for (int i = 0; i < V; ++i) g[i] = 0.f;
             float q = 0.f;
-            accumulate_segment<V, TABLE, VEC>(a, c.sorted_entry, begin, end, col, g, q);
+            accumulate_segment<V, TABLE, VEC, VEC ? SegUnrollDeep<TABLE>::value : kSegUnrollScalar>(a, c.sorted_entry, begin, end, col, g, q);
             if (VEC) stv<V>(c.partial + static_cast<size_t>(ci) * a.dim + col, g);
             if (cv == 0) c.partial_q[ci] = q;
         }
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
                 if (nch > kFan) sum_partials<V, VEC, 4>(c.partial2, c.partial2_q, c.chunk2_base[row], (nch + kFan - 1) / kFan, dim, col, g, q);
                 else sum_partials<V, VEC, 4>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
             } else if (cnt > 0) {
-                accumulate_segment<V, TABLE, VEC, UNROLL>(a, c.sorted_entry, begin, end, col, g, q);
+                accumulate_segment<V, TABLE, VEC, VEC ? UNROLL : kSegUnrollScalar>(a, c.sorted_entry, begin, end, col, g, q);
             }
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, touch_p, g, q, p, m, v);
         }
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
 #pragma unroll
                 for (int i = 0; i < V; ++i) g[i] = 0.f;
                 float q = 0.f;
-                accumulate_segment<V, TABLE, VEC>(a, c.sorted_entry, begin, end, col, g, q);
+                accumulate_segment<V, TABLE, VEC, VEC ? SegUnrollDeep<TABLE>::value : kSegUnrollScalar>(a, c.sorted_entry, begin, end, col, g, q);
                 if (VEC) st_agent<V>(c.partial + static_cast<size_t>(ci) * dim + col, g);
                 if (cv == 0) st_agent1(c.partial_q + ci, q);
             }
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
 #pragma unroll
             for (int i = 0; i < V; ++i) g[i] = 0.f;
             float q = 0.f;
-            if (cnt > 0) accumulate_segment<V, TABLE, VEC, UNROLL>(a, c.sorted_entry, begin, end, col, g, q);
+            if (cnt > 0) accumulate_segment<V, TABLE, VEC, VEC ? UNROLL : kSegUnrollScalar>(a, c.sorted_entry, begin, end, col, g, q);
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, touch_p, g, q, p, m, v);
         }
     }
@@ -915,9 +916,12 @@ double table_split_ratio() {
 bool row_pass_split(const Csr& c) { return c.n > 0 && static_cast<double>(c.rows) * table_split_ratio() >= static_cast<double>(c.n); }
 static bool kind_is_row_local_when_untouched(int kind) { return kind != ROW_ADAM_DENSE && kind != ROW_ADAM_FULL; }
 
-static void group_geometry(int dim, int& V, int& nvec, int& G) {
-    V = (dim % 4 == 0) ? 4 : 1;
-    nvec = dim / V;
+static void group_geometry(const RowPassArgs& a, int& V, int& nvec, int& G) {
+    // (ROW_SCALAR_ACC, where only the row's scalar moves, was tried with one THREAD per row instead of a thread group as wide
+    //  as the row: 64 rows of different lengths per wave run as long as the longest — 36 instead of 27 us for the Adagrad
+    //  accumulator pass of the LSE recipe)
+    V = (a.dim % 4 == 0) ? 4 : 1;
+    nvec = a.dim / V;
     G = nvec < 256 ? nvec : 256;
 }
 
@@ -941,7 +945,7 @@ static void chunk_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
 void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s) {
     if (c.n <= 0 || c.max_chunks <= 0) return;
     int V, nvec, G;
-    group_geometry(a.dim, V, nvec, G);
+    group_geometry(a, V, nvec, G);
     if (V == 4) { if (a.table == 0) chunk_pass_dispatch<4, 0>(c, a, G, nvec, s); else chunk_pass_dispatch<4, 1>(c, a, G, nvec, s); }
     else        { if (a.table == 0) chunk_pass_dispatch<1, 0>(c, a, G, nvec, s); else chunk_pass_dispatch<1, 1>(c, a, G, nvec, s); }
 }
@@ -995,7 +999,7 @@ void launch_row_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hipSt
     if (!untouched_s) untouched_s = s;
     if (c.rows <= 0) return;
     int V, nvec, G;
-    group_geometry(a_in.dim, V, nvec, G);
+    group_geometry(a_in, V, nvec, G);
     RowPassArgs a = a_in;
     a.touched_only = 0; a.shallow = 0;
     Csr cc = c;
@@ -1127,7 +1131,7 @@ int launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hipS
     }
     if (c.rows <= 0) return TABLE_PASS_DENSE;
     int V, nvec, G;
-    group_geometry(a_in.dim, V, nvec, G);
+    group_geometry(a_in, V, nvec, G);
     RowPassArgs a = a_in;
     a.touched_only = 0; a.shallow = 0;
     int64_t row_items = c.rows;

@@ -23,7 +23,8 @@ N = 1: `value` = 51 200-window steps on one GPU. The line also carries
     this one GPU with an engine created for that batch size, and `strong_projection_8gpu` computed from it (compute only:
     no collective is in it);
   * `secondary` — the reference recipe's `full_adam` (scripts/functions.sh:395) and the uniform-word-id worst case;
-  * `value_readback_every_step` (the loss read back after every step, as cpp/main.cu:427-444 does) and
+  * `value_readback_every_step` (the loss read back after every step, as cpp/main.cu:427-444 does),
+    `value_readback_one_step_late` (every step's loss read back, one step behind: cuNVSMTrainModel's protocol) and
     `value_host_batches` (page-locked host batches handed over each step, PCIe inclusive) — never used for `value`.
 N > 1: the metric says batch = 51 200, so the headline `value` is the STRONG figure: the 51 200-window batch split
 51 200 / N per rank (dense gradients and batch-norm statistics all-reduced over RCCL each step); the weak figure
@@ -239,9 +240,21 @@ class Leg:
                                      torch.ones(B, dtype=torch.float32, device=dev)))
         return pool
 
-    def run_steps(self, n, batches=None, read_every=0):
+    def run_steps(self, n, batches=None, read_every=0, deferred=False):
         args, model, lr = self.env.args, self.model, self.wl["lr"]
         batches = batches or self.pool
+        if deferred:
+            # EVERY step's loss is read back, one step late: the loss of step s is fetched after step s + 1 has been queued
+            # (nvsm_step_deferred / nvsm_deferred_cost — what cuNVSMTrainModel does), so the GPU never waits for the host
+            ticket = None
+            for s in range(n):
+                t = model.step_deferred(batches[s % len(batches)], lr)
+                if ticket is not None:
+                    model.deferred_cost(ticket)
+                ticket = t
+            if ticket is not None:
+                model.deferred_cost(ticket)
+            return
         for s in range(n):
             want = read_every > 0 and (s + 1) % read_every == 0
             if args.gate_us:
@@ -255,13 +268,13 @@ class Leg:
             else:
                 model.step(batches[s % len(batches)], lr, want_cost=want)
 
-    def timed(self, n, batches=None, read_every=0):
+    def timed(self, n, batches=None, read_every=0, deferred=False):
         """EXACTLY n steps between barrier + synchronize on both sides; MAX over ranks. Seconds."""
         import torch
         env = self.env
         env.sync_all(self.model)
         t0 = time.perf_counter()
-        self.run_steps(n, batches, read_every)
+        self.run_steps(n, batches, read_every, deferred)
         self.model.synchronize()
         torch.cuda.synchronize()
         if env.dist is not None:
@@ -273,8 +286,8 @@ class Leg:
             dt = float(t.item())
         return dt
 
-    def timed_repeats(self, n, repeats, batches=None, read_every=0):
-        return [self.timed(n, batches, read_every) for _ in range(max(1, repeats))]
+    def timed_repeats(self, n, repeats, batches=None, read_every=0, deferred=False):
+        return [self.timed(n, batches, read_every, deferred) for _ in range(max(1, repeats))]
 
     def touched_rows(self):
         """Table rows one batch touches: words from the pool, documents from the ids the device sampler drew last."""
@@ -456,9 +469,9 @@ def main():
     model.profile_enable(False)
     touched = main_leg.touched_rows() if rank == 0 and not args.no_profile else None
 
-    def leg_value(leg, batches=None, read_every=0, repeats=None):
+    def leg_value(leg, batches=None, read_every=0, repeats=None, deferred=False):
         """windows/s and ms per step of a secondary leg: median of `repeats` regions of --steps steps, all ranks' batches"""
-        ts = leg.timed_repeats(args.steps, repeats or min(args.repeats, 3), batches, read_every)
+        ts = leg.timed_repeats(args.steps, repeats or min(args.repeats, 3), batches, read_every, deferred)
         med, st = ms_stats(ts, args.steps)
         return med, st
 
@@ -471,6 +484,9 @@ def main():
             main_leg.run_steps(2, None, 1)
             med, _ = leg_value(main_leg, None, 1)
             extra["value_readback_every_step"] = round(B * 1e3 / med, 1)
+            # (a') every step's loss read back ONE STEP LATE (the trainer's protocol: nothing stalls)
+            med, _ = leg_value(main_leg, None, 0, deferred=True)
+            extra["value_readback_one_step_late"] = round(B * 1e3 / med, 1)
             # (b) page-locked HOST batches handed over each step: PCIe-inclusive (never `value`)
             if not args.host_batches:
                 hpool = main_leg.make_pool(1234, True)

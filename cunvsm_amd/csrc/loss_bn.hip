@@ -498,9 +498,14 @@ static void launch_loss_t(const LossArgs& a_in, hipStream_t s) {
 template <int RB>
 static void launch_loss_rows(const LossArgs& a_in, hipStream_t s) {
     LossArgs a = a_in;
-    // ~5 blocks per CU; at most 16 examples per wave (column statistics: one fp64 atomic per column per block)
+    // ~5 blocks per CU; at most 16 examples per wave ...
     int epw = static_cast<int>((a.B + 4 * 1280 - 1) / (4 * 1280));
     epw = epw < 1 ? 1 : (epw > 16 ? 16 : epw);
+    // ... and twenty from 40 k examples: 640 workgroups, fewer than the 768 the chip holds at once (three per CU at 161
+    // registers). A workgroup ends by handing its column sums over (device_utils.h grid_sum_ordered: stores, a wait for them,
+    // a counter) — 3-4 us of idle waves that a second round of workgroups queues behind; in a single round only the last
+    // hand-over shows. 51 200 examples: 180 -> 176 us in-step (1 280 / 800 / 753 workgroups: 180 / 196 / 183 us).
+    if (a.B >= 40960) epw = 20;
     // (batch 4096: two examples per wave, 512 workgroups — half as many fp64 atomics per column: 44 -> 33 us)
     if (epw < 2 && a.B >= 2048) epw = 2;
     static const int epw_env = [] { const char* e = std::getenv("NVSM_LOSS_EPW"); return e ? std::atoi(e) : 0; }();      // experiments

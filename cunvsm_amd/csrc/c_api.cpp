@@ -1,6 +1,8 @@
 // extern "C" surface of libcunvsm_amd.so — see include/cunvsm_amd.h. No C++ exception and no abort
 // crosses this boundary: every entry point returns an nvsm_status and records nvsm_last_error().
+#include <algorithm>
 #include <cstring>
+#include <vector>
 #include <string>
 
 #include "model.h"
@@ -203,7 +205,12 @@ int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const 
             cunvsm::launch_gemm(al, bl, A.p, B.p, P.p, M, N, K, lda, ldb, N, 1.f, nullptr, split, static_cast<size_t>(M) * N, nullptr);
             cunvsm::launch_splitk_reduce(P.p, slabs, static_cast<size_t>(M) * N, C.p, static_cast<int64_t>(M) * N, nullptr);
         } else {
-            cunvsm::launch_gemm(al, bl, A.p, B.p, C.p, M, N, K, lda, ldb, N, 1.f, nullptr, 1, 0, nullptr);
+            cunvsm::DevBuf<char> planes;
+            planes.alloc(cunvsm::gemm_split_planes_bytes(N, K));
+            cunvsm::GemmSplitWs sws{planes.p, planes.n, false};
+            cunvsm::launch_gemm(al, bl, A.p, B.p, C.p, M, N, K, lda, ldb, N, 1.f, nullptr, 1, 0, nullptr, nullptr, nullptr, 0.f, nullptr, false,
+                                nullptr, &sws);
+            NVSM_HIP_CHECK(hipDeviceSynchronize());
         }
         NVSM_HIP_CHECK(hipDeviceSynchronize());
         NVSM_HIP_CHECK(hipMemcpy(hostC, C.p, C.n * sizeof(float), hipMemcpyDeviceToHost));
@@ -218,7 +225,16 @@ int nvsm_debug_gemm_time(int b_layout, int M, int N, int K, int extras, int repe
         cunvsm::DevBuf<float> A, B, C, rowsq, part;
         cunvsm::DevBuf<double> stats, part2;
         cunvsm::DevBuf<int> arrive;
-        A.alloc(static_cast<size_t>(M) * K, true); B.alloc(static_cast<size_t>(K) * N, true); C.alloc(static_cast<size_t>(M) * N);
+        A.alloc(static_cast<size_t>(M) * K); B.alloc(static_cast<size_t>(K) * N); C.alloc(static_cast<size_t>(M) * N);
+        {   // operands with all 24 significant bits in use (zeros would flatter a kernel: less switching, higher clocks)
+            std::vector<float> h(std::max(A.n, B.n));
+            uint32_t x = 12345u;
+            auto fill = [&](cunvsm::DevBuf<float>& d, float scale) {
+                for (size_t i = 0; i < d.n; ++i) { x = x * 1664525u + 1013904223u; h[i] = (static_cast<float>(x >> 8) * (1.f / 8388608.f) - 1.f) * scale; }
+                NVSM_HIP_CHECK(hipMemcpy(d.p, h.data(), d.n * sizeof(float), hipMemcpyHostToDevice));
+            };
+            fill(A, 0.5f); fill(B, 0.1f);
+        }
         cunvsm::GridSumWs ws{};
         if (extras & 1) {
             ws.colgroups = 8; ws.contrib_cap = M / 32 + 512; ws.width_cap = 2 * (N > 160 ? N : 160); ws.groups_cap = ws.contrib_cap / 16 + 1; ws.fan = 16;
@@ -235,9 +251,13 @@ int nvsm_debug_gemm_time(int b_layout, int M, int N, int K, int extras, int repe
         NVSM_HIP_CHECK(hipEventCreate(&e0)); NVSM_HIP_CHECK(hipEventCreate(&e1));
         const int ldb = b_layout ? K : N;
         int parts = 0;
+        cunvsm::DevBuf<char> planes;
+        planes.alloc(cunvsm::gemm_split_planes_bytes(N, K));
+        cunvsm::GemmSplitWs sws{planes.p, planes.n, false};
         auto go = [&] {
+            sws.ready = (extras & 4) != 0 && sws.ready;          // extras bit 2: the planes of B stay valid between launches
             cunvsm::launch_gemm(0, b_layout, A.p, B.p, C.p, M, N, K, K, ldb, N, 1.f, nullptr, 1, 0, s, (extras & 1) ? stats.p : nullptr,
-                                (extras & 2) ? rowsq.p : nullptr, 1.f, &parts, false, (extras & 1) ? &ws : nullptr);
+                                (extras & 2) ? rowsq.p : nullptr, 1.f, &parts, false, (extras & 1) ? &ws : nullptr, &sws);
         };
         for (int i = 0; i < 3; ++i) go();
         NVSM_HIP_CHECK(hipEventRecord(e0, s));

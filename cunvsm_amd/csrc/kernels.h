@@ -47,6 +47,8 @@ struct GridSumWs {
     int* arrive;        // [colgroups][groups_cap + 1], zero between launches
     int colgroups, contrib_cap, groups_cap, width_cap, fan;
 };
+// planes of the small operand for the split-bf16 GEMM (gemm_split.hip; see launch_gemm_split)
+struct GemmSplitWs { void* planes; size_t bytes; bool ready; };
 inline int grid_sum_fan(int contributions) { return contributions > 256 ? 32 : 16; }
 
 // ---- gather-mean (F3/F9; replaces average_repr_kernel, cpp/params.cu:75-95) ------------------
@@ -65,7 +67,8 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
                  hipStream_t s, double* colstats = nullptr,     // colstats [2][N] (no split-K): = Σ_rows C, Σ_rows C² (needs `sums`)
                  float* rowsq = nullptr, float rowsq_scale = 0.f, int* rowsq_parts = nullptr,
                  bool busy_chip = false,      // the launch lands next to long-running kernels of other streams (kernel choice)
-                 const GridSumWs* sums = nullptr);      // workspace of the ordered column sums (required with colstats)
+                 const GridSumWs* sums = nullptr,       // workspace of the ordered column sums (required with colstats)
+                 GemmSplitWs* split_ws = nullptr);      // planes of B for the split-bf16 kernel (null: exact-fp32 MFMA kernels)
 // rowsq [gemm_rowsq_parts(N)][M]: rowsq_scale · Σ_cols C² per row, split by column tile (128 columns in the tiled kernel,
 // 16 in the LDS-stationary one): *rowsq_parts = the number of parts this launch wrote; launch_sum_parts adds them in
 // order (a runtime-length loop over the parts inside the row passes' unrolled gather was measured: it halves their
@@ -86,6 +89,16 @@ bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, in
                       float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
                       float rowsq_scale, const BnDxFused* bn);
 bool gemm_rows_covers(int b_layout, int M, int N, int K, bool colstats, bool rowsq, bool bn);      // what launch_gemm_rows accepts
+// Split-bf16 kernel for large batches (gemm_split.hip): fp32 operands cut exactly into three bf16 planes, nine (or six) bf16
+// MFMAs per product with fp32 accumulation. rowsq [M]: COMPLETE rowsq_scale · Σ_cols C² per row. false: not covered / switched off.
+// B travels as its three bf16 planes (GemmSplitWs::planes, gemm_split_planes_bytes(N, K) bytes, owned by the caller): cut by a
+// small launch in front of the product unless `ready` says they are current — the caller clears `ready` whenever B changes.
+size_t gemm_split_planes_bytes(int N, int K);
+void launch_gemm_split_planes(int b_layout, const float* B, int N, int K, int ldb, void* planes, hipStream_t s);
+bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
+                       float rowsq_scale, GemmSplitWs* ws);
+int gemm_split_products();               // NVSM_GEMM_SPLIT: 9 (default), 6, or 0 = exact-fp32 MFMA kernels only
 int gemm_rows_max_m();                   // largest M launch_gemm sends to the row-panel kernel (NVSM_GEMM_ROWS_MAX, default 16384; 0 = never)
 float* gemm_dump_buffer();               // 256 B per device nobody reads (gemm_tstat.hip): the target of masked-out stores
 void gemm_set_tstat_enabled(bool on);    // experiments / tests: force the tiled kernel

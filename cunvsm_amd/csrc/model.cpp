@@ -458,6 +458,9 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         alloc_sums(sums_bwd_, 1, static_cast<int>((B + 3) / 4), 2 * de + 1);
     }
     bn_mean_.alloc(de, true); bn_inv_std_.alloc(de, true); dbeta_.alloc(de, true); dgamma_.alloc(de, true);
+    planes_fwd_.alloc(gemm_split_planes_bytes(de, dw), true); planes_bwd_.alloc(gemm_split_planes_bytes(dw, de), true);
+    split_fwd_ = GemmSplitWs{planes_fwd_.p, planes_fwd_.n, false};
+    split_bwd_ = GemmSplitWs{planes_bwd_.p, planes_bwd_.n, false};
     gT_.alloc(static_cast<size_t>(de) * dw, true); gb_.alloc(de, true);
     // split-K slabs of the dT product: 128 at the 51 200-window batch (400 rows each); a per-rank batch of a few thousand
     // windows cut 128 ways is 600 workgroups of two 32-deep K tiles each — all prologue, epilogue and 39 MB of partials
@@ -964,7 +967,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
                     cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_,
                     cfg_.batch_normalization ? stats_fwd_ : nullptr, nullptr, 0.f, nullptr,
                     /*busy_chip=*/words_.lazy || ents_.lazy,       // long sorts and a long documents-update tail next to it
-                    &sums_fwd_.ws);
+                    &sums_fwd_.ws, &split_fwd_);
     }
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
@@ -1162,7 +1165,7 @@ void Model::backward_dx() {
         // (A/B, interleaved: 1.235 ms per step with the epilogue fusion vs 1.262 ms with a separate row-mean-of-squares pass)
         int msq_parts = 0;
         launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, l2p ? 1.f : inv_w, nullptr, 1, 0, stream_,
-                    nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw, &msq_parts);
+                    nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw, &msq_parts, false, nullptr, &split_bwd_);
         // ev_bwdx_: the dx GEMM, the last reader of T before its update, is through (and gphrase / its row statistics final)
         if (l2p) {      // Normalizer::backward, then the division by the window (objective.cu:461-476); mean of squares of the result
             launch_l2_rows_backward(gphrase_.p, phrase_raw_.p, phrase_norms_.p, B, dw, inv_w, gphrase_.p,
@@ -1480,6 +1483,18 @@ void Model::update_transform(float lr, float sl, hipStream_t strm) {
     a.bc = adam_bc(t_transform_);
     if (cfg_.update_method == NVSM_ADAM) t_transform_ += 1;
     launch_transform_update(a, strm);
+    cut_transform_planes(strm);
+}
+
+// T changed: its bf16 planes for the next two projection products, behind the writer on the writer's stream (off the critical
+// path in the fused step: side stream 2, which the next projection GEMM joins anyway)
+void Model::cut_transform_planes(hipStream_t strm) {
+    split_fwd_.ready = split_bwd_.ready = false;
+    if (!gemm_split_products() || B_ <= gemm_rows_max_m()) return;       // (the exact-fp32 kernels are in use)
+    const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size;
+    launch_gemm_split_planes(0, T_.p, de, dw, de, split_fwd_.planes, strm);      // forward: B = T as [K = dw][N = de]
+    launch_gemm_split_planes(1, T_.p, dw, de, de, split_bwd_.planes, strm);      // backward: B stored [N = dw][K = de]
+    split_fwd_.ready = split_bwd_.ready = true;
 }
 
 void Model::update(float lr, float scaled_lambda) {
@@ -1674,6 +1689,7 @@ void Model::set_param(const std::string& name, const float* src, int64_t count) 
     synchronize();
     lazy_flush_all();
     NVSM_HIP_CHECK(hipMemcpy(r.p, src, count * sizeof(float), hipMemcpyHostToDevice));
+    split_fwd_.ready = split_bwd_.ready = false;
 }
 
 void Model::increment_param(const std::string& name, int64_t index, float delta) {
@@ -1686,6 +1702,7 @@ void Model::increment_param(const std::string& name, int64_t index, float delta)
     NVSM_HIP_CHECK(hipMemcpy(&v, r.p + index, sizeof(float), hipMemcpyDeviceToHost));
     v += delta;
     NVSM_HIP_CHECK(hipMemcpy(r.p + index, &v, sizeof(float), hipMemcpyHostToDevice));
+    split_fwd_.ready = split_bwd_.ready = false;
 }
 
 int64_t Model::tensor_size(const std::string& name) {

@@ -252,6 +252,11 @@ class Model {
     // workspaces of those sums (kernels.h GridSumWs): projection GEMM epilogue / loss kernel
     struct SumsBufs { DevBuf<float> part; DevBuf<double> part2; DevBuf<int> arrive; GridSumWs ws{}; };
     SumsBufs sums_fwd_, sums_bwd_;
+    // the projection matrix cut into bf16 planes for the split-bf16 GEMM (gemm_split.hip), in the forward and the backward
+    // product's layout; `ready` is cleared by everything that writes T
+    DevBuf<char> planes_fwd_, planes_bwd_;
+    GemmSplitWs split_fwd_{}, split_bwd_{};
+    void cut_transform_planes(hipStream_t strm);
     void alloc_sums(SumsBufs& b, int colgroups, int contrib_cap, int width_cap);
     bool csr_joined_words_ = true, csr_joined_ents_ = true;      // the main stream is behind the current CSR builds
     double* stats_fwd_ = nullptr;

@@ -1,28 +1,40 @@
 // The two batch-sized projection products of a step on the bf16 matrix pipe, at fp32 accuracy:
 //   forward   pre[B][d_e]     = phrase[B][d_w] · Tt[d_w][d_e]  (+ bias, + batch-norm column sums)   cpp/params.cu:417
-//   backward  gphrase[B][d_w] = alpha · dx[B][d_e] · T          (+ per-row sums of squares)          cpp/objective.cu:453
+//   backward  gphrase[B][d_w] = alpha · dx[B][d_e] · T          (+ per-row sums of squares,          cpp/objective.cu:453
+//                                                                + the batch-norm backward on the way in: cpp/cudnn_utils.cu:143-183)
 // gfx950 multiplies fp32 operands in its matrix cores at the fp32 VECTOR rate (v_mfma_f32_32x32x2_f32: 157 TFLOP/s, 1/16 of
 // the bf16 rate) and has no TF32-like mode. But an fp32 number is EXACTLY the sum of three bf16 numbers — x = h + m + l with
 // h = x cut to its upper 16 bits, m = (x − h) cut likewise, l = x − h − m: 8 + 8 + 8 significant bits — so a product a·b is
 // exactly the sum of the nine products of their pieces, each of which the bf16 MFMA forms exactly (8 x 8 bits) and adds into
-// an fp32 accumulator. Nine v_mfma_f32_16x16x32_bf16 do the work of sixteen fp32 MFMAs' worth of issue time in 9/16 of it,
-// with the same products and fp32 accumulation (only the order of the additions differs from the fp32 pipe's k-ordered chain;
-// tests/test_gpu_parity.py and tools/exp/gemm_accuracy.py compare both with an fp64 product). NVSM_GEMM_SPLIT=6 drops the three
-// products below 2^-24 of a·b (m·l, l·m, l·l), 0 switches this kernel off (exact-fp32 MFMA kernels: gemm_tstat / gemm_rows).
+// an fp32 accumulator: fp32 accumulation of exact products, as the fp32 pipe does, in a different order. Six products
+// (NVSM_GEMM_SPLIT=6, the default) leave out m·l, l·m and l·l, each below 2^-24 of a·b; NVSM_GEMM_SPLIT=9 keeps all nine;
+// 0 switches this kernel off (exact-fp32 MFMA kernels: gemm_tstat / gemm_rows). Measured against an fp64 product (tools/exp/
+// gemm_accuracy.py, M = 51 200, errors relative to Σ|a·b|, operands over 16 binades): exact-fp32 kernels max 1.31e-6 / rms
+// 9.9e-8, nine products 1.06e-6 / 8.2e-8, six products 1.11e-6 / 8.4e-8 — the bf16 pipe's wider internal sum makes both
+// forms slightly MORE accurate than the k-ordered fp32 chain. tests/test_gpu_parity.py asserts that relation.
 //
-// Shape of the work: M = batch is huge (51 200), N and K are a few hundred. One workgroup per CU owns up to 13 16-row blocks
-// (51 200 / 256 CUs = 200 rows = 12.5 blocks) and ALL columns; each of its waves owns a slice of the columns for all those
-// rows (forward: 16 column blocks = 4 per SIMD; backward: 19 = 5 + 5 + 5 + 4), so the SIMDs of a CU carry the same number of
-// MFMAs to within one column block whatever the batch size. K runs in tiles of 32:
+// Shape of the work: M = batch is huge (51 200), N and K are a few hundred. One workgroup (eight waves, two per SIMD, 256
+// registers each: the compiler keeps everything in arch VGPRs — a 512-register, one-wave-per-SIMD form of the same loop
+// compiled to a v_accvgpr move per MFMA) per CU owns the CU's share of the rows — 51 200 / 256 = 200 rows = 12.5 blocks of 16 —
+// and ALL columns; each wave owns a slice of the columns for all those rows (forward: 16 column blocks = 2 per wave; backward:
+// 19 = 3, 3, 3, 2 | 2, 2, 2, 2, waves w and w + 4 share a SIMD: 5, 5, 5, 4 per SIMD; a wave runs the loop compiled for its
+// own number of blocks), so the SIMDs carry the same number of MFMAs to within one column block. K runs in tiles of 32:
 //   * the rows' tile of A is loaded from global memory once (fp32, 16 B per lane, two tiles ahead), cut into its three bf16
-//     planes and stored to LDS in fragment order (row pitch 80 B: the 16 B fragment reads of a 16-lane group hit all banks once);
-//     two LDS images, one barrier per tile;
-//   * a wave fetches the K tile of ITS columns of B straight from global memory (L2-resident: the matrix is 307 KB) a tile
-//     ahead and cuts it in registers: B never goes through LDS and is cut once per CU;
+//     planes and stored to LDS in fragment order (row pitch 80 B: the 16 B fragment reads of a 16-lane group hit all banks
+//     once); two LDS images, one barrier per tile; the cutting rides between the MFMAs of the tile before;
+//   * B — the projection matrix, 77 k elements, the same for every workgroup — arrives already cut: gemm_split_planes_kernel
+//     writes its planes in fragment order (behind the projection update, off the critical path), a wave fetches the K tile of
+//     ITS columns a tile ahead with three 16 B loads per block, L2-resident;
 //   * operands are fed swapped (the tile is computed transposed), so a lane ends up with four consecutive columns of one
 //     output row: 16 B stores, row sums of squares by two cross-lane adds, column sums by a 16-lane DPP reduce;
 //   * column sums (batch-norm statistics) leave through the ordered grid-wide sum, row sums of squares are completed across
-//     the waves through LDS in wave order: one value per row, no launch_sum_parts behind the product.
+//     the waves through LDS in wave order: one value per row, no launch_sum_parts behind the product;
+//   * the backward product applies the batch-norm backward to the rows of dy as it stages them and writes dx back for the
+//     dT product (every element of A is staged by exactly one workgroup): launch_bn_dx + GEMM + launch_sum_parts in one launch.
+// Alone, idle GPU, M = 51 200 (tools/exp/gemm_time.py): forward 59 us / backward 60 us with six products (74 / 74 with nine)
+// against 90 / 95 us for the exact-fp32 kernels. The K loop runs within 7 % of what v_mfma_f32_16x16x32_bf16 delivers
+// (19.3 cycles per instruction and SIMD; tools/exp/split_times.py); what is left is prologue (3 us: the first tile of A comes
+// from HBM), epilogue (52 MB of stores at the end: 4 us) and the ordered column sums (4-10 us for the last workgroup).
 #include "kernels.h"
 #include "device_utils.h"
 
@@ -39,8 +51,8 @@ constexpr int kSplitPitch = 80;                                 // bytes per row
 constexpr int kSplitWaves = 8;                                  // two per SIMD: 256 registers each, no AGPR shuffling
 constexpr int kSplitMaxWaves = kSplitWaves;
 // RBP = 16-row blocks per workgroup and pass: plane = 16 RBP rows, an image = three planes, two images
-constexpr size_t split_lds_bytes(int rbp) {      // two images | column sums [2][np <= 320] | row sums of squares [waves][16 rbp]
-    return static_cast<size_t>(2) * 3 * rbp * 16 * kSplitPitch + 2 * 320 * 4 + static_cast<size_t>(kSplitWaves) * rbp * 16 * 4;
+constexpr size_t split_lds_bytes(int rbp) {      // two images | column sums [2][np <= 320] | row sums of squares [waves][16 rbp] | batch-norm constants
+    return static_cast<size_t>(2) * 3 * rbp * 16 * kSplitPitch + 2 * 320 * 4 + static_cast<size_t>(kSplitWaves) * rbp * 16 * 4 + 4 * 320 * 4;      // | PRE constants [4][K <= 320]
 }
 constexpr int kSplitMaxDevices = 64;
 
@@ -60,6 +72,10 @@ struct SplitArgs {
     const unsigned char* planes;   // B cut into its three bf16 planes: [3][ceil(K / 32)][np][32] (gemm_split_planes_kernel)
     float* dump;
     int nt_store;            // the output with non-temporal stores
+    // PRE: batch-norm backward on the rows of A (= dy, overwritten with dx) as they are staged (launch_bn_dx's job), or, with
+    // pre == null, only the bias gradient grad_bias = (float) bn_sums (launch_colsum_finalize's)
+    float* A_rw; const float* pre; const float* mean; const float* inv_std; const double* bn_sums;
+    float* dbeta; float* dgamma; float* grad_bias; float inv_n;
 };
 
 #ifdef NVSM_SPLIT_TIMING
@@ -127,7 +143,7 @@ __device__ __forceinline__ void split_gload_off(u32x4& dst, unsigned voff, const
 
 // The work of one wave: CBW column blocks (all of them multiplied), RBP row blocks per pass (the accumulators: 4 RBP CBW
 // registers); NPROD 9 or 6.
-template <int CBW, int RBP, int NPROD, int EPI>
+template <int CBW, int RBP, int NPROD, int EPI, bool PRE>
 __device__ __forceinline__ void split_body(const SplitArgs& g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char split_lds[];
     constexpr int WAVES = kSplitWaves;
@@ -153,10 +169,23 @@ __device__ __forceinline__ void split_body(const SplitArgs& g) {
     // LDS: two images of a tile of A (three planes each) | column sums [2][np <= 320] | row sums of squares [WAVES][kRows]
     float* st = reinterpret_cast<float*>(split_lds + 2 * kStage);
     float* rs_lds = st + 2 * 320;
+    float* consts = rs_lds + WAVES * kRows;                   // PRE: [4][K <= 320] μ, invσ, dβ, dγ
     int* sum_flag = reinterpret_cast<int*>(split_lds);
     if (EPI & kSplitEpiStats) {
         for (int k = tid; k < 2 * g.np; k += T) st[k] = 0.f;       // (the barriers of the K loop order this before the first add)
     }
+
+    if (PRE) {
+        for (int k = tid; k < g.K; k += T) {
+            consts[k] = g.mean[k]; consts[g.K + k] = g.inv_std[k];
+            const float db = static_cast<float>(g.bn_sums[k]), dg = static_cast<float>(g.bn_sums[g.K + k]);      // cudnn_utils.cu:158-173
+            consts[2 * g.K + k] = db; consts[3 * g.K + k] = dg;
+            if (blockIdx.x == 0) { g.dbeta[k] = db; g.dgamma[k] = dg; g.grad_bias[k] = db; }      // ∂β is the bias gradient; ∂γ is dropped (:173)
+        }
+        __syncthreads();
+    }
+    if (!PRE && g.grad_bias && blockIdx.x == 0)      // no batch-norm: the bias gradient is Σdy
+        for (int k = tid; k < g.K; k += T) g.grad_bias[k] = static_cast<float>(g.bn_sums[k]);
 
     // passes of at most RBP row blocks, as even as they go (13 blocks at RBP = 7: 7 + 6)
     const int npass = (nb + RBP - 1) / RBP;
@@ -177,16 +206,34 @@ __device__ __forceinline__ void split_body(const SplitArgs& g) {
         }
         // (tiles past the last one: the last one again; a tile may reach past K: those float4s are zeroed in store_a and the
         //  address stays inside the matrix)
-        auto load_a1 = [&](int kt, int u, u32x4& r) {
+        auto load_a1 = [&](int kt, int u, u32x4& r, u32x4& x) {
             const unsigned o = a_voff[u] + 128u * static_cast<unsigned>(kt < KT ? kt : KT - 1);
             split_gload(r, o < a_last ? o : a_last, g.A);
+            if (PRE) split_gload(x, o < a_last ? o : a_last, g.pre);
         };
-        auto store_a1 = [&](int kt, int stage, int u, const u32x4& r) {
+        auto store_a1 = [&](int kt, int stage, int u, const u32x4& r, const u32x4& x) {
             const int idx = tid + T * u;
             if (idx < kF4) {
                 const int row = idx >> 3, k4 = idx & 7;
                 const bool ok = (row < nrows) && (32 * kt + 4 * k4 < g.K);
-                const u32x4 v = ok ? r : u32x4{0u, 0u, 0u, 0u};
+                u32x4 v = ok ? r : u32x4{0u, 0u, 0u, 0u};
+                if (PRE) {
+                    // dx = invσ · (dy − (dβ + x̂·dγ) / N), x̂ = (x − μ)·invσ      (bn_dx_kernel, loss_bn.hip); written back over dy
+                    const int k = ok ? 32 * kt + 4 * k4 : 0;
+                    const float4 mu = *reinterpret_cast<const float4*>(consts + k), is = *reinterpret_cast<const float4*>(consts + g.K + k);
+                    const float4 db = *reinterpret_cast<const float4*>(consts + 2 * g.K + k), dg = *reinterpret_cast<const float4*>(consts + 3 * g.K + k);
+                    const float mu_[4] = {mu.x, mu.y, mu.z, mu.w}, is_[4] = {is.x, is.y, is.z, is.w};
+                    const float db_[4] = {db.x, db.y, db.z, db.w}, dg_[4] = {dg.x, dg.y, dg.z, dg.w};
+                    f32x4 d;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xhat = (__uint_as_float(x[e]) - mu_[e]) * is_[e];
+                        d[e] = is_[e] * (__uint_as_float(v[e]) - (db_[e] + xhat * dg_[e]) * g.inv_n);
+                    }
+                    *reinterpret_cast<f32x4*>(ok ? g.A_rw + (static_cast<size_t>(row0 + row) * g.lda + 32 * kt + 4 * k4) : g.dump) = d;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ok ? __float_as_uint(d[e]) : 0u;
+                }
                 unsigned h0, m0, l0, h1, m1, l1;
                 split_pair(__uint_as_float(v[0]), __uint_as_float(v[1]), h0, m0, l0);
                 split_pair(__uint_as_float(v[2]), __uint_as_float(v[3]), h1, m1, l1);
@@ -215,15 +262,15 @@ __device__ __forceinline__ void split_body(const SplitArgs& g) {
             for (int c = 0; c < CBW; ++c) acc[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // ---- prologue: tile 0 of A into image 0 and of B into registers; tile 1 of A in flight ----
-        u32x4 ar[NLD];
+        u32x4 ar[NLD], xr[NLD];
         SplitFrag bf[CBW], bfn[CBW];
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) load_a1(0, u, ar[u]);
+        for (int u = 0; u < NLD; ++u) load_a1(0, u, ar[u], xr[u]);
         load_bf(0, bf);
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) store_a1(0, 0, u, ar[u]);
+        for (int u = 0; u < NLD; ++u) store_a1(0, 0, u, ar[u], xr[u]);
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) load_a1(1, u, ar[u]);
+        for (int u = 0; u < NLD; ++u) load_a1(1, u, ar[u], xr[u]);
         __syncthreads();
         if (ps == 0) SPLIT_STAMP(1);
 
@@ -254,8 +301,8 @@ __device__ __forceinline__ void split_body(const SplitArgs& g) {
                 // the chunk's load sit the later chunks of its tile, the planes of B and the earlier chunks of tile kt + 2.
                 if ((rb - 1) % STEP == 0 && (rb - 1) / STEP < NLD && rb >= 1) {
                     const int u = (rb - 1) / STEP;
-                    store_a1(kt + 1, cur ^ 1, u, ar[u]);
-                    load_a1(kt + 2, u, ar[u]);
+                    store_a1(kt + 1, cur ^ 1, u, ar[u], xr[u]);
+                    load_a1(kt + 2, u, ar[u], xr[u]);
                 }
                 if (rb < nbb) {
                     // smallest products first; consecutive MFMAs go to different accumulators. (Column blocks the wave does
@@ -389,25 +436,25 @@ __device__ __forceinline__ void split_body(const SplitArgs& g) {
 
 // Eight waves; a wave owns CBW or (MIXED) CBW - 1 column blocks and runs the body compiled for that number — the same K loop
 // and the same barriers either way.
-template <int CBW, int RBP, int NPROD, int EPI, bool MIXED>
+template <int CBW, int RBP, int NPROD, int EPI, bool MIXED, bool PRE>
 __global__ __launch_bounds__(kSplitWaves * 64) void gemm_split_kernel(SplitArgs g) {
     if constexpr (MIXED) {
         const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
-        if (g.ncb[w] == CBW) split_body<CBW, RBP, NPROD, EPI>(g);
-        else split_body<CBW - 1, RBP, NPROD, EPI>(g);
+        if (g.ncb[w] == CBW) split_body<CBW, RBP, NPROD, EPI, PRE>(g);
+        else split_body<CBW - 1, RBP, NPROD, EPI, PRE>(g);
     } else {
-        split_body<CBW, RBP, NPROD, EPI>(g);
+        split_body<CBW, RBP, NPROD, EPI, PRE>(g);
     }
 }
 
-template <int CBW, int RBP, int NPROD, int EPI, bool MIXED>
+template <int CBW, int RBP, int NPROD, int EPI, bool MIXED, bool PRE = false>
 static bool split_launch_epi(const SplitArgs& g, int wgs, hipStream_t s) {
     constexpr size_t kSplitLdsBytes = split_lds_bytes(RBP);
     static std::atomic<bool> attr_set[kSplitMaxDevices];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kSplitMaxDevices) return false;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<CBW, RBP, NPROD, EPI, MIXED>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<CBW, RBP, NPROD, EPI, MIXED, PRE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSplitLdsBytes)) != hipSuccess) {
             (void)hipGetLastError();
             return false;
@@ -415,7 +462,7 @@ static bool split_launch_epi(const SplitArgs& g, int wgs, hipStream_t s) {
         attr_set[dev].store(true, std::memory_order_release);
     }
     (void)hipGetLastError();
-    NVSM_LAUNCH((gemm_split_kernel<CBW, RBP, NPROD, EPI, MIXED>), dim3(wgs), dim3(kSplitWaves * 64), kSplitLdsBytes, s, g);
+    NVSM_LAUNCH((gemm_split_kernel<CBW, RBP, NPROD, EPI, MIXED, PRE>), dim3(wgs), dim3(kSplitWaves * 64), kSplitLdsBytes, s, g);
     return hipGetLastError() == hipSuccess;
 }
 
@@ -428,6 +475,10 @@ static bool split_launch(const SplitArgs& g, int wgs, hipStream_t s) {
         if (epi == kSplitEpiBias) return split_launch_epi<CBW, RBP, NPROD, kSplitEpiBias, false>(g, wgs, s);
         if (epi == 0) return split_launch_epi<CBW, RBP, NPROD, 0, false>(g, wgs, s);
     } else {
+        if (g.pre) {
+            if (epi == kSplitEpiRowsq) return split_launch_epi<CBW, RBP, NPROD, kSplitEpiRowsq, true, true>(g, wgs, s);
+            if (epi == 0) return split_launch_epi<CBW, RBP, NPROD, 0, true, true>(g, wgs, s);
+        }
         if (epi == kSplitEpiRowsq) return split_launch_epi<CBW, RBP, NPROD, kSplitEpiRowsq, true>(g, wgs, s);
         if (epi == 0) return split_launch_epi<CBW, RBP, NPROD, 0, true>(g, wgs, s);
     }
@@ -478,19 +529,28 @@ void launch_gemm_split_planes(int b_layout, const float* B, int N, int K, int ld
     else NVSM_LAUNCH((gemm_split_planes_kernel<1>), dim3(grid), dim3(256), 0, s, B, N, K, ldb, np, static_cast<unsigned char*>(planes));
 }
 
-// NVSM_GEMM_SPLIT: 0 = never, 9 (default) / 6 = number of partial products. Read per call (tests switch it within a process).
+// NVSM_GEMM_SPLIT: 0 = never, 6 (default) / 9 = number of partial products. Read per call (tests switch it within a process).
 int gemm_split_products() {
     const char* e = std::getenv("NVSM_GEMM_SPLIT");
-    const int v = e ? std::atoi(e) : 9;
+    const int v = e ? std::atoi(e) : 6;
     return (v == 6 || v == 9) ? v : 0;
+}
+
+// what launch_gemm_split accepts (given 16 B aligned operands and leading dimensions that are multiples of 4)
+bool gemm_split_covers(int b_layout, int M, int N, int K, bool bn) {
+    if (!gemm_split_products() || M < 1024 || (K % 4) || (N % 4) || K < 8) return false;
+    const int cbs = (N + 15) / 16;
+    if (bn && (b_layout != 1 || K > 320)) return false;
+    return b_layout == 0 ? cbs == 2 * kSplitWaves : (cbs > 2 * kSplitWaves && cbs <= 3 * kSplitWaves);
 }
 
 // returns false when the shape is not one this kernel covers (nothing launched). rowsq: ONE complete value per row.
 // ws: the planes of B (cut here, on `s`, unless ws->ready says they are current).
 bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                        float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
-                       float rowsq_scale, GemmSplitWs* ws) {
+                       float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn) {
     const int nprod = gemm_split_products();
+    if (bn && (b_layout != 1 || K > 320 || (bn->pre && (bn->dy != A || reinterpret_cast<uintptr_t>(bn->pre) % 16)))) return false;
     if (!nprod || M < 1024 || !ws || !ws->planes || ws->bytes < gemm_split_planes_bytes(N, K)) return false;
     if ((K % 4) || (N % 4) || (lda % 4) || (ldb % 4) || (ldc % 4) || K < 8) return false;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) % 16) return false;
@@ -510,6 +570,10 @@ bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, i
     SplitArgs g{};
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = alpha; g.bias_n = bias_n; g.colstats = colstats; g.rowsq = rowsq; g.rowsq_scale = rowsq_scale;
+    if (bn) {
+        g.A_rw = bn->dy; g.pre = bn->pre; g.mean = bn->mean; g.inv_std = bn->inv_std; g.bn_sums = bn->sums;
+        g.dbeta = bn->dbeta; g.dgamma = bn->dgamma; g.grad_bias = bn->grad_bias; g.inv_n = static_cast<float>(1.0 / bn->n_global);
+    }
     { const char* e = std::getenv("NVSM_SPLIT_NT"); g.nt_store = e ? std::atoi(e) : 0; }
     g.nblocks = (M + 15) / 16; g.np = 16 * cbs; g.dump = dump; g.planes = static_cast<const unsigned char*>(ws->planes);
     int wgs = num_cus < g.nblocks ? num_cus : g.nblocks;

@@ -47,6 +47,9 @@ struct GridSumWs {
     int* arrive;        // [colgroups][groups_cap + 1], zero between launches
     int colgroups, contrib_cap, groups_cap, width_cap, fan;
 };
+// batch-norm backward (or, pre == null, the bias gradient alone) riding on the backward projection product: see launch_gemm_rows
+struct BnDxFused { float* dy; const float* pre; const float* mean; const float* inv_std; const double* sums;
+                   float* dbeta; float* dgamma; float* grad_bias; double n_global; };
 // planes of the small operand for the split-bf16 GEMM (gemm_split.hip; see launch_gemm_split)
 struct GemmSplitWs { void* planes; size_t bytes; bool ready; };
 inline int grid_sum_fan(int contributions) { return contributions > 256 ? 32 : 16; }
@@ -83,8 +86,6 @@ bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* 
 // rowsq_scale · Σ_cols C² per row (no parts); bn: the batch-norm backward of launch_bn_dx applied to the rows of A as they are
 // loaded, dx written back over dy (b_layout 1 only); bn with pre == null: only grad_bias = (float) sums[k] (no batch-norm: what
 // launch_colsum_finalize does). false: shape not covered, nothing launched.
-struct BnDxFused { float* dy; const float* pre; const float* mean; const float* inv_std; const double* sums;
-                   float* dbeta; float* dgamma; float* grad_bias; double n_global; };
 bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                       float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
                       float rowsq_scale, const BnDxFused* bn);
@@ -97,8 +98,9 @@ size_t gemm_split_planes_bytes(int N, int K);
 void launch_gemm_split_planes(int b_layout, const float* B, int N, int K, int ldb, void* planes, hipStream_t s);
 bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                        float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
-                       float rowsq_scale, GemmSplitWs* ws);
-int gemm_split_products();               // NVSM_GEMM_SPLIT: 9 (default), 6, or 0 = exact-fp32 MFMA kernels only
+                       float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn = nullptr);      // bn: as launch_gemm_rows (b_layout 1 only)
+bool gemm_split_covers(int b_layout, int M, int N, int K, bool bn);      // shapes launch_gemm_split accepts
+int gemm_split_products();               // NVSM_GEMM_SPLIT: 6 (default), 9, or 0 = exact-fp32 MFMA kernels only
 int gemm_rows_max_m();                   // largest M launch_gemm sends to the row-panel kernel (NVSM_GEMM_ROWS_MAX, default 16384; 0 = never)
 float* gemm_dump_buffer();               // 256 B per device nobody reads (gemm_tstat.hip): the target of masked-out stores
 void gemm_set_tstat_enabled(bool on);    // experiments / tests: force the tiled kernel

@@ -396,7 +396,8 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
         own_stream_ = true;
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, lo));
-        NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux2_stream_, hipStreamNonBlocking, lo));
+        static const int aux2_prio = [] { const char* e = std::getenv("NVSM_AUX2_PRIO"); return e ? std::atoi(e) : 0; }();   // (experiments) 0 lowest, 1 middle, 2 highest
+        NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux2_stream_, hipStreamNonBlocking, aux2_prio == 0 ? lo : (aux2_prio == 2 ? hi : (lo + hi) / 2)));
         // Four streams, not five: the runtime multiplexes streams onto four hardware queues, and with a fifth stream the
         // host-batch copies shared a queue with compute and stopped overlapping it (1.22 -> 1.7 ms per step with host
         // batches). The inputs' copies therefore ride on side stream 3 in front of the documents sort that needs them.
@@ -465,10 +466,13 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     // split-K slabs of the dT product: 128 at the 51 200-window batch (400 rows each); a per-rank batch of a few thousand
     // windows cut 128 ways is 600 workgroups of two 32-deep K tiles each — all prologue, epilogue and 39 MB of partials
     // (158 us next to the updates at batch 6 400: step 0.360 ms; 50 slabs 0.291, 25 slabs 0.295, 12 slabs 0.296, interleaved
-    // A/B). 128 rows per slab at least. NVSM_DT_SLABS overrides.
+    // A/B). 128 rows per slab at least. Large batches: 16 slabs — since round 3 the dT product starts behind the fused
+    // batch-norm-backward / dx product instead of next to it and must still be through before the next projection product:
+    // 16 slabs of 3 200 rows write 5 MB of partials instead of 39 (NVSM shape 0.976 ms with 128 slabs, 0.938 with 64, 0.929
+    // with 32-48, 0.926 with 16, 1.000 with 8, interleaved A/B). NVSM_DT_SLABS overrides.
     {
         const char* e = std::getenv("NVSM_DT_SLABS");
-        gemm_slabs_want_ = e ? std::atoi(e) : static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, B / 128)));
+        gemm_slabs_want_ = e ? std::atoi(e) : (B > 16384 ? 16 : static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, B / 128))));
     }
     const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
     gT_partial_.alloc(static_cast<size_t>(slabs) * de * dw);
@@ -1081,17 +1085,31 @@ void Model::backward_dx() {
     // — the kernel owns whole rows of dy, applies dx = invσ·(dy − (dβ + x̂·dγ)/N) as it loads them (writing dx back for the
     // dT product) and finishes each row's sum of squares itself. Three launches and two gaps less on the critical stream.
     const bool sync_bn_order = !dp || cfg_.sync_batch_norm;       // (per-shard batch-norm under DP reduces AFTER bn_dx: separate launches)
-    if (cfg_.batch_normalization && sync_bn_order && !l2p && B >= 512 && B <= gemm_rows_max_m() &&
-        gemm_rows_covers(1, static_cast<int>(B), dw, de, false, need_msq, true)) {
+    // Large batches: the same fusion in the split-bf16 kernel (gemm_split.hip). Its launch carries ev_bwdx_, so the planes of T
+    // must not be cut by a launch of their own between the two: cut here if they are stale.
+    static const bool split_fuse = [] { const char* e = std::getenv("NVSM_SPLIT_FUSE"); return !(e && e[0] == '0'); }();      // A/B runs
+    const bool big = B > gemm_rows_max_m();
+    auto split_ready = [&] {
+        if (!split_bwd_.ready) { launch_gemm_split_planes(1, T_.p, dw, de, de, split_bwd_.planes, stream_); split_bwd_.ready = true; }
+    };
+    auto dx_product = [&](const BnDxFused* fused) {
+        if (big) return launch_gemm_split(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
+                                          nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &split_bwd_, fused);
+        return launch_gemm_rows(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
+                                nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, fused);
+    };
+    auto fused_covers = [&](bool bn) {
+        if (B < 512 || (big && !split_fuse)) return false;
+        return big ? gemm_split_covers(1, static_cast<int>(B), dw, de, bn) : gemm_rows_covers(1, static_cast<int>(B), dw, de, false, need_msq, bn);
+    };
+    if (cfg_.batch_normalization && sync_bn_order && !l2p && fused_covers(true)) {
         if (dp) allreduce_f64(stats_bwd_, 1 + 2 * de);
+        if (big) split_ready();
         BnDxFused bn{dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, stats_bwd_ + 1, dbeta_.p, dgamma_.p, gb_.p, dp ? B_global : static_cast<double>(B)};
         bool launched = false;
         {
             PROF("gemm_bwd_x");
-            launch_and_record(ev_bwdx_, stream_, [&] {
-                launched = launch_gemm_rows(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
-                                            nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &bn);
-            });
+            launch_and_record(ev_bwdx_, stream_, [&] { launched = dx_product(&bn); });
         }
         if (launched) {
             // dx is final when this kernel is through: the dT GEMM of the fused step follows it (a wait on a kernel-borne event
@@ -1102,24 +1120,21 @@ void Model::backward_dx() {
         }
         // (shape not covered: the event was recorded on an empty launch; fall through to the separate kernels. The statistics
         //  have been all-reduced already under DP, which the code below must not repeat.)
-        throw Error(NVSM_ERR_UNSUPPORTED, "row-panel GEMM refused a shape its caller had checked");
+        throw Error(NVSM_ERR_UNSUPPORTED, "fused backward GEMM refused a shape its caller had checked");
     }
 
     // ... and without batch-norm (the LSE recipe) the same kernel finalises the bias gradient Σdy and the rows' mean of squares:
     // colsum_finalize + GEMM + sum_parts as one launch
-    if (!cfg_.batch_normalization && !l2p && B >= 512 && B <= gemm_rows_max_m() &&
-        gemm_rows_covers(1, static_cast<int>(B), dw, de, false, need_msq, false)) {
+    if (!cfg_.batch_normalization && !l2p && fused_covers(false)) {
         if (dp) allreduce_f64(stats_bwd_, 1 + de);
+        if (big) split_ready();
         BnDxFused bias_only{nullptr, nullptr, nullptr, nullptr, stats_bwd_ + 1, nullptr, nullptr, gb_.p, 1.0};
         bool launched = false;
         {
             PROF("gemm_bwd_x");
-            launch_and_record(ev_bwdx_, stream_, [&] {
-                launched = launch_gemm_rows(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
-                                            nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &bias_only);
-            });
+            launch_and_record(ev_bwdx_, stream_, [&] { launched = dx_product(&bias_only); });
         }
-        if (!launched) throw Error(NVSM_ERR_UNSUPPORTED, "row-panel GEMM refused a shape its caller had checked");
+        if (!launched) throw Error(NVSM_ERR_UNSUPPORTED, "fused backward GEMM refused a shape its caller had checked");
         if (dx_follower_) NVSM_HIP_CHECK(hipStreamWaitEvent(dx_follower_, ev_bwdx_, 0));
         if (dp) loss_reduced_ = true;
         return;

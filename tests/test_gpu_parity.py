@@ -49,6 +49,33 @@ def test_gemm_large_batch_kernels(M, N, K, layout, monkeypatch):
     test_gemm_layouts(M, N, K, layout)
 
 
+@pytest.mark.parametrize("M", [1024, 3333, 16390])
+@pytest.mark.parametrize("layout,N,K", [(0, 256, 300), (1, 300, 256), (1, 272, 64)])
+def test_gemm_split_bf16_is_fp32_accurate(M, layout, N, K, monkeypatch):
+    """gemm_split.hip: fp32 operands cut exactly into three bf16 planes, nine or six bf16 MFMAs per product, fp32 accumulation.
+    Against an fp64 product, on operands spread over many binades (as gradients are), its error must not exceed the exact-fp32
+    MFMA kernels' by more than rounding noise — and the 9- and 6-product forms must agree to fp32 roundoff."""
+    monkeypatch.setenv("NVSM_GEMM_ROWS_MAX", "0")
+    rs = np.random.RandomState(M + N + K)
+    A = (rs.standard_normal((M, K)) * np.exp2(rs.randint(-12, 4, (M, K)))).astype(np.float32)
+    Bm = (rs.standard_normal((K, N)) * 0.1 * np.exp2(rs.randint(-6, 3, (K, N))) + np.arange(N)[None, :] * 1e-3).astype(np.float32)
+    Bh = np.ascontiguousarray(Bm.T if layout else Bm)
+    ref = A.astype(np.float64) @ Bm.astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64)
+    out, err = {}, {}
+    for mode in ("0", "9", "6"):
+        monkeypatch.setenv("NVSM_GEMM_SPLIT", mode)
+        out[mode] = np.empty((M, N), np.float32)
+        ca._lib.check(ca.lib().nvsm_debug_gemm(layout, M, N, K, A.ctypes.data, Bh.ctypes.data, out[mode].ctypes.data))
+        e = (out[mode].astype(np.float64) - ref) / scale
+        err[mode] = (np.abs(e).max(), np.sqrt((e ** 2).mean()))
+    assert not np.array_equal(out["0"], out["9"])                      # (the split kernel did run)
+    for mode in ("9", "6"):
+        assert err[mode][0] < 1.5 * err["0"][0] + 1e-8, err            # largest error, relative to Σ|a b|
+        assert err[mode][1] < 1.1 * err["0"][1] + 1e-9, err            # root mean square
+    assert rel_err(out["6"], out["9"].astype(np.float64)) < 3e-7
+
+
 @pytest.mark.parametrize("split", [2, 7, 128])
 def test_gemm_split_k(split):
     rs = np.random.RandomState(split)

@@ -199,7 +199,14 @@ int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const 
         NVSM_HIP_CHECK(hipMemcpy(A.p, hostA, A.n * sizeof(float), hipMemcpyHostToDevice));
         NVSM_HIP_CHECK(hipMemcpy(B.p, hostB, B.n * sizeof(float), hipMemcpyHostToDevice));
         const int lda = al ? M : K, ldb = bl ? K : N;
-        if (split > 1) {
+        const char* dt_env = std::getenv("NVSM_DT_SPLIT");
+        if (split > 1 && al == 1 && bl == 0 && !(dt_env && dt_env[0] == '0') && cunvsm::gemm_dt_covers(M, N, K)) {
+            // the projection-gradient shape: the split-bf16 split-K kernel the model uses for it (gemm_dt.hip)
+            const int slabs = cunvsm::gemm_dt_slabs(K, split);
+            P.alloc(static_cast<size_t>(slabs) * M * N);
+            if (!cunvsm::launch_gemm_dt(A.p, B.p, P.p, M, N, K, lda, ldb, split, nullptr)) throw Error(NVSM_ERR_UNSUPPORTED, "gemm_dt refused a covered shape");
+            cunvsm::launch_splitk_reduce(P.p, slabs, static_cast<size_t>(M) * N, C.p, static_cast<int64_t>(M) * N, nullptr);
+        } else if (split > 1) {
             const int slabs = cunvsm::gemm_split_k_slabs(K, split);
             P.alloc(static_cast<size_t>(slabs) * M * N);
             cunvsm::launch_gemm(al, bl, A.p, B.p, P.p, M, N, K, lda, ldb, N, 1.f, nullptr, split, static_cast<size_t>(M) * N, nullptr);

@@ -1,0 +1,257 @@
+// dT[d_w][d_e] = phraseᵀ[d_w x B] · dx[B x d_e], the projection gradient (cpp/params.cu:526-531), on the bf16 matrix pipe at
+// fp32 accuracy — the split-bf16 arithmetic of gemm_split.hip (every fp32 operand cut exactly into three bf16 pieces, six or
+// nine bf16 MFMAs per product, fp32 accumulation) for the product whose LONG dimension is the reduction: split-K over the batch.
+// The step runs it on a side stream next to the HBM-bound updates of the two tables; the 128 x 128-tiled fp32 kernel took
+// 0.42 ms there, and the step was 70 us shorter without it (NVSM shape, a timing run with the product left out): what it
+// costs is CU time. Here a workgroup (eight waves) owns a slab of the batch and one half of the d_e columns:
+//   * K runs in tiles of 32 batch rows. 428 of the 512 threads each fetch an 8-row x 4-column piece of the tile (phrase:
+//     75 column groups x 4 row octets; dx half: 32 x 4) a tile ahead, cut it, and store — per column and plane — the eight
+//     consecutive-row bf16 values as ONE 16 B LDS word: exactly the fragment of a 16x16x32 MFMA whose K runs along the batch
+//     (the transposition is free: it happens in registers). Column pitch 80 B: fragment reads and staging writes are
+//     conflict-free. One LDS image (104 KB), two barriers per tile with only the twelve LDS stores between them (the cutting
+//     happens in front of the first, next to the other waves' MFMAs);
+//   * wave (cp, rh) multiplies column blocks 2 cp, 2 cp + 1 of the half against row blocks 10 rh ... (19 blocks of d_w = 300:
+//     10 + 9), waves w and w + 4 share a SIMD: 38 blocks per SIMD; 80 accumulator registers;
+//   * the slab's partial product goes to partial[slab] and launch_splitk_reduce adds the slabs in order, as before.
+// Slabs are few and long by default (the grid covers a quarter of the chip): the product is off the critical path, and the
+// updates next to it are better off with CUs of their own than with a product that finishes early.
+#include "kernels.h"
+#include "device_utils.h"
+
+#include <atomic>
+#include <cstdlib>
+
+namespace cunvsm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kDtWaves = 8, kDtThreads = kDtWaves * 64;
+constexpr int kDtPitch = 80;                                   // bytes per column of a plane: 32 bf16 + 16 B
+constexpr int kDtMaxM = 320, kDtHalfN = 128;
+constexpr int kDtRB = 10;                                      // row blocks per wave (two waves cover up to 20)
+constexpr int kDtMaxDevices = 64;
+
+struct DtArgs {
+    const float* A; const float* B; float* P;
+    int rows, M, N, lda, ldb, ldc;       // rows = batch (the reduction); A [rows][M] (lda), B [rows][N] (ldb), P [slabs][M][N] (ldc)
+    int slab_rows;                       // batch rows per slab, a multiple of 32
+    size_t p_stride;
+    int mpad;                            // 16 · row blocks
+};
+
+__device__ __forceinline__ void dt_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+    h = (b0 >> 16) | (b1 & 0xffff0000u);
+    const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
+    const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+    m = (c0 >> 16) | (c1 & 0xffff0000u);
+    const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
+    l = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+}
+__device__ __forceinline__ f32x4 dt_mfma(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(kDtThreads) void gemm_dt_kernel(DtArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dt_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cp = w & 3, rh = w >> 2;
+    const int half = blockIdx.x & 1, slab = blockIdx.x >> 1;
+    const int n0 = half * kDtHalfN;
+    const int row_begin = slab * g.slab_rows;
+    const int row_end = (row_begin + g.slab_rows) < g.rows ? (row_begin + g.slab_rows) : g.rows;
+    const int KT = (row_end - row_begin + 31) / 32;
+    const int rblocks = g.mpad / 16;
+    const int rb0 = rh * kDtRB;
+    const int nrb = (rblocks - rb0) < kDtRB ? (rblocks - rb0 > 0 ? rblocks - rb0 : 0) : kDtRB;
+    const int a_plane = g.mpad * kDtPitch;                                  // bytes of one plane of the phrase part
+    constexpr int b_plane = kDtHalfN * kDtPitch;
+    unsigned char* a_img = dt_lds;                                          // [3][mpad][80]
+    unsigned char* b_img = dt_lds + 3 * a_plane;                            // [3][128][80]
+
+    // ---- this thread's staging task: 8 rows (octet o of the tile) x 4 columns (group cg) of A, or of this half of B ----
+    const int a_groups = g.mpad / 4;                                        // column groups of A incl. the padding (zeros)
+    const int a_tasks = 4 * a_groups;
+    const bool is_a = tid < a_tasks;
+    const bool is_b = !is_a && tid < a_tasks + 4 * (kDtHalfN / 4);
+    const int tt = is_a ? tid : tid - a_tasks;
+    const int o = tt & 3, cg = tt >> 2;
+    const bool col_ok = is_a ? (4 * cg < g.M) : (is_b && n0 + 4 * cg < g.N);       // M % 4 == 0, N % 4 == 0
+    // (threads without a piece, and pieces in the padding columns, load column 0 of A: never stored / stored as zeros)
+    const float* src = (is_b ? g.B : g.A) + (col_ok ? (is_a ? 4 * cg : n0 + 4 * cg) : 0);
+    const int ld = is_b ? g.ldb : g.lda;
+    unsigned char* dst = (is_a ? a_img : b_img) + (4 * cg) * kDtPitch + o * 16;
+    const int dplane = is_a ? a_plane : b_plane;
+
+    u32x4 raw[8];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            int row = row_begin + 32 * kt + 8 * o + r;
+            row = row < row_end ? row : row_end - 1;                        // (clamped: zeroed in store_tile)
+            raw[r] = *reinterpret_cast<const u32x4*>(src + static_cast<size_t>(row) * ld);
+        }
+    };
+    // the piece of tile kt in `raw` cut into fragment words (column e: its eight rows, one 16 B word per plane) — register work,
+    // done while the other waves still multiply — and, behind the barrier, the twelve LDS stores
+    u32x4 ch[4], cm[4], cl[4];
+    auto cut_tile = [&](int kt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ra = row_begin + 32 * kt + 8 * o + 2 * j;
+                const float x0 = (col_ok && ra < row_end) ? __uint_as_float(raw[2 * j][e]) : 0.f;
+                const float x1 = (col_ok && ra + 1 < row_end) ? __uint_as_float(raw[2 * j + 1][e]) : 0.f;
+                unsigned hh, mm, ll;
+                dt_split_pair(x0, x1, hh, mm, ll);
+                ch[e][j] = hh; cm[e][j] = mm; cl[e][j] = ll;
+            }
+        }
+    };
+    auto write_tile = [&] {
+        if (!(is_a || is_b)) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned char* p = dst + e * kDtPitch;
+            *reinterpret_cast<u32x4*>(p) = ch[e];
+            *reinterpret_cast<u32x4*>(p + dplane) = cm[e];
+            *reinterpret_cast<u32x4*>(p + 2 * dplane) = cl[e];
+        }
+    };
+
+    f32x4 acc[kDtRB][2];
+#pragma unroll
+    for (int rb = 0; rb < kDtRB; ++rb) { acc[rb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    if (KT > 0) {
+        load_tile(0);
+        cut_tile(0);
+        write_tile();
+        load_tile(KT > 1 ? 1 : 0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        // this wave's two column blocks of dx ...
+        const unsigned char* bp = b_img + (32 * cp + i) * kDtPitch + q * 16;
+        u32x4 bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bh[c] = *reinterpret_cast<const u32x4*>(bp + c * 16 * kDtPitch);
+            bm[c] = *reinterpret_cast<const u32x4*>(bp + c * 16 * kDtPitch + b_plane);
+            bl[c] = *reinterpret_cast<const u32x4*>(bp + c * 16 * kDtPitch + 2 * b_plane);
+        }
+        // ... against its row blocks of phrase (the fragments of block rb + 1 are read while block rb is multiplied)
+        const unsigned char* ap = a_img + (16 * rb0 + i) * kDtPitch + q * 16;
+        u32x4 ah = *reinterpret_cast<const u32x4*>(ap);
+        u32x4 am = *reinterpret_cast<const u32x4*>(ap + a_plane);
+        u32x4 al = *reinterpret_cast<const u32x4*>(ap + 2 * a_plane);
+#pragma unroll
+        for (int rb = 0; rb < kDtRB; ++rb) {
+            u32x4 nh = ah, nm = am, nl = al;
+            if (rb + 1 < kDtRB) {
+                // (a wave with nine blocks reads one block past its own: inside the image, or the other image's start — never used)
+                const unsigned char* np = ap + (rb + 1 < nrb ? rb + 1 : 0) * 16 * kDtPitch;
+                nh = *reinterpret_cast<const u32x4*>(np);
+                nm = *reinterpret_cast<const u32x4*>(np + a_plane);
+                nl = *reinterpret_cast<const u32x4*>(np + 2 * a_plane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (rb < nrb) {
+                if (NPROD == 9) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) acc[rb][c] = dt_mfma(bl[c], al, acc[rb][c]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) acc[rb][c] = dt_mfma(bl[c], am, acc[rb][c]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) acc[rb][c] = dt_mfma(bm[c], al, acc[rb][c]);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[rb][c] = dt_mfma(bl[c], ah, acc[rb][c]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[rb][c] = dt_mfma(bh[c], al, acc[rb][c]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[rb][c] = dt_mfma(bm[c], am, acc[rb][c]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[rb][c] = dt_mfma(bm[c], ah, acc[rb][c]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[rb][c] = dt_mfma(bh[c], am, acc[rb][c]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[rb][c] = dt_mfma(bh[c], ah, acc[rb][c]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ah = nh; am = nm; al = nl;
+        }
+        cut_tile(kt + 1);                                  // (past the last tile: zeros, written to an image nobody reads)
+        load_tile(kt + 2 < KT ? kt + 2 : KT - 1);          // (past the last tile: a harmless repeat, the same loads every turn)
+        __syncthreads();                                   // everybody has read tile kt
+        write_tile();
+        __syncthreads();
+    }
+
+    // ---- this slab's partial: acc[rb][c][r] = P[slab][16 (rb0 + rb) + i][n0 + 16 (2 cp + c) + 4 q + r] ----
+    float* P = g.P + static_cast<size_t>(slab) * g.p_stride;
+#pragma unroll
+    for (int rb = 0; rb < kDtRB; ++rb) {
+        if (rb < nrb) {
+            const int m = 16 * (rb0 + rb) + i;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int n = n0 + 16 * (2 * cp + c) + 4 * q;
+                if (m < g.M && n < g.N) *reinterpret_cast<f32x4*>(P + static_cast<size_t>(m) * g.ldc + n) = acc[rb][c];
+            }
+        }
+    }
+}
+
+size_t gemm_dt_lds_bytes(int M) { return static_cast<size_t>(3) * (16 * ((M + 15) / 16) + kDtHalfN) * kDtPitch; }
+
+bool gemm_dt_covers(int M, int N, int rows) {
+    return gemm_split_products() != 0 && M % 4 == 0 && N % 4 == 0 && M >= 16 && M <= kDtMaxM && N > kDtHalfN && N <= 2 * kDtHalfN && rows >= 64;
+}
+
+// slabs the product will use for `want` (slab lengths are multiples of 32 rows)
+int gemm_dt_slabs(int rows, int want) {
+    if (want < 1) want = 1;
+    int len = (rows + want - 1) / want;
+    len = ((len + 31) / 32) * 32;
+    return (rows + len - 1) / len;
+}
+
+// partial [slabs][M][N] (ldc = N); the caller adds the slabs (launch_splitk_reduce). false: shape not covered, nothing launched.
+bool launch_gemm_dt(const float* A, const float* B, float* partial, int M, int N, int rows, int lda, int ldb, int want_slabs,
+                    hipStream_t s) {
+    if (!gemm_dt_covers(M, N, rows) || (lda % 4) || (ldb % 4)) return false;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(partial)) % 16) return false;
+    const int nprod = gemm_split_products();
+    DtArgs g{};
+    g.A = A; g.B = B; g.P = partial; g.rows = rows; g.M = M; g.N = N; g.lda = lda; g.ldb = ldb; g.ldc = N;
+    const int slabs = gemm_dt_slabs(rows, want_slabs);
+    int len = (rows + (want_slabs < 1 ? 1 : want_slabs) - 1) / (want_slabs < 1 ? 1 : want_slabs);
+    g.slab_rows = ((len + 31) / 32) * 32;
+    g.p_stride = static_cast<size_t>(M) * N;
+    g.mpad = 16 * ((M + 15) / 16);
+    const size_t lds = gemm_dt_lds_bytes(M);
+    static std::atomic<bool> attr_set[kDtMaxDevices][2];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDtMaxDevices) return false;
+    const int which = nprod == 9 ? 1 : 0;
+    if (!attr_set[dev][which].load(std::memory_order_acquire)) {
+        const void* fn = which ? reinterpret_cast<const void*>(&gemm_dt_kernel<9>) : reinterpret_cast<const void*>(&gemm_dt_kernel<6>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (kDtMaxM + kDtHalfN) * kDtPitch) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set[dev][which].store(true, std::memory_order_release);
+    }
+    (void)hipGetLastError();
+    if (which) NVSM_LAUNCH((gemm_dt_kernel<9>), dim3(2 * slabs), dim3(kDtThreads), lds, s, g);
+    else NVSM_LAUNCH((gemm_dt_kernel<6>), dim3(2 * slabs), dim3(kDtThreads), lds, s, g);
+    return hipGetLastError() == hipSuccess;
+}
+
+}  // namespace cunvsm

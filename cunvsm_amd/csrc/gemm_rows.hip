@@ -353,7 +353,7 @@ bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, in
 
 int gemm_rows_max_m() {
     const char* e = std::getenv("NVSM_GEMM_ROWS_MAX");      // (read per call: tests and A/B runs switch it)
-    return e ? std::atoi(e) : 16384;
+    return e ? std::atoi(e) : 8192;
 }
 
 }  // namespace cunvsm

@@ -100,8 +100,14 @@ bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, i
                        float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
                        float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn = nullptr);      // bn: as launch_gemm_rows (b_layout 1 only)
 bool gemm_split_covers(int b_layout, int M, int N, int K, bool bn);      // shapes launch_gemm_split accepts
+// dT = Aᵀ[M x rows] · B[rows x N] split-K over the rows (the batch), split-bf16 arithmetic (gemm_dt.hip): A [rows][M], B [rows][N],
+// partial [gemm_dt_slabs(rows, want)][M][N]; the caller adds the slabs with launch_splitk_reduce. false: not covered.
+bool gemm_dt_covers(int M, int N, int rows);
+int gemm_dt_slabs(int rows, int want);
+bool launch_gemm_dt(const float* A, const float* B, float* partial, int M, int N, int rows, int lda, int ldb, int want_slabs,
+                    hipStream_t s);
 int gemm_split_products();               // NVSM_GEMM_SPLIT: 6 (default), 9, or 0 = exact-fp32 MFMA kernels only
-int gemm_rows_max_m();                   // largest M launch_gemm sends to the row-panel kernel (NVSM_GEMM_ROWS_MAX, default 16384; 0 = never)
+int gemm_rows_max_m();                   // largest M launch_gemm sends to the row-panel kernel (NVSM_GEMM_ROWS_MAX, default 8192; 0 = never): above it the split-bf16 kernel
 float* gemm_dump_buffer();               // 256 B per device nobody reads (gemm_tstat.hip): the target of masked-out stores
 void gemm_set_tstat_enabled(bool on);    // experiments / tests: force the tiled kernel
 void launch_sum_parts(const float* parts, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);

@@ -469,12 +469,17 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     // A/B). 128 rows per slab at least. Large batches: 16 slabs — since round 3 the dT product starts behind the fused
     // batch-norm-backward / dx product instead of next to it and must still be through before the next projection product:
     // 16 slabs of 3 200 rows write 5 MB of partials instead of 39 (NVSM shape 0.976 ms with 128 slabs, 0.938 with 64, 0.929
-    // with 32-48, 0.926 with 16, 1.000 with 8, interleaved A/B). NVSM_DT_SLABS overrides.
+    // with 32-48, 0.926 with 16, 1.000 with 8; batch 12 800: 0.442 with 100 slabs, 0.417 with 50, 0.405 with 8-24; interleaved
+    // A/B). NVSM_DT_SLABS overrides.
     {
         const char* e = std::getenv("NVSM_DT_SLABS");
-        gemm_slabs_want_ = e ? std::atoi(e) : (B > 16384 ? 16 : static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, B / 128))));
+        gemm_slabs_want_ = e ? std::atoi(e) : (B > gemm_rows_max_m() ? 16 : static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, B / 128))));
     }
-    const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
+    {
+        const char* e = std::getenv("NVSM_DT_SPLIT_SLABS");
+        dt_slabs_want_ = e ? std::atoi(e) : 64;
+    }
+    const int slabs = std::max(gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_), gemm_dt_slabs(static_cast<int>(B), dt_slabs_want_));
     gT_partial_.alloc(static_cast<size_t>(slabs) * de * dw);
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -1059,6 +1064,8 @@ void Model::compute_gradients() {
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
     RangeScope range_cg("ComputeGradients");            // cpp/main.cu:414
     backward_dx();
+    // (alone on its stream the split-bf16 dT kernel is the faster one from a few thousand rows on)
+    dt_split_now_ = B_ >= 4096 && gemm_dt_covers(cfg_.word_repr_size, cfg_.entity_repr_size, static_cast<int>(B_));
     backward_T(stream_);
     NVSM_HIP_CHECK(hipGetLastError());
     have_grads_ = true;
@@ -1204,7 +1211,17 @@ void Model::backward_T(hipStream_t strm) {
         PROF_ON("gemm_bwd_T", strm);
         const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
         const size_t stride = static_cast<size_t>(de) * dw;
-        if (slabs == 1) {
+        static const bool skip_dt = [] { const char* e = std::getenv("NVSM_EXP_SKIP_DT"); return e && e[0] == '1'; }();      // timing experiment only: WRONG results
+        static const int dt_split_env = [] { const char* e = std::getenv("NVSM_DT_SPLIT"); return e ? std::atoi(e) : -1; }();      // A/B runs: 0 never, 1 always
+        const bool dt_split = dt_split_env >= 0 ? dt_split_env != 0 : dt_split_now_;
+        if (skip_dt) {
+        } else if (dt_split && gemm_dt_covers(dw, de, static_cast<int>(B))) {
+            // the split-bf16 product (gemm_dt.hip): few, long slabs on a quarter of the chip, next to the updates
+            const int dslabs = gemm_dt_slabs(static_cast<int>(B), dt_slabs_want_);
+            if (!launch_gemm_dt(phrase_p_, dy_.p, dslabs == 1 ? gT_.p : gT_partial_.p, dw, de, static_cast<int>(B), dw, de, dt_slabs_want_, strm))
+                throw Error(NVSM_ERR_UNSUPPORTED, "dT product refused a shape its caller had checked");
+            if (dslabs > 1) launch_splitk_reduce(gT_partial_.p, dslabs, stride, gT_.p, static_cast<int64_t>(stride), strm);
+        } else if (slabs == 1) {
             launch_gemm(1, 0, phrase_p_, dy_.p, gT_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr, 1, 0, strm);
         } else {
             launch_gemm(1, 0, phrase_p_, dy_.p, gT_partial_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr,
@@ -1577,13 +1594,31 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     if (!docs_after_dx && !docs_on_main) backward_dx();
     dx_follower_ = nullptr;
     if (dp) {
+        dt_split_now_ = B_ >= 4096 && gemm_dt_covers(cfg_.word_repr_size, cfg_.entity_repr_size, static_cast<int>(B_));
         backward_T(stream_);
     } else {
         // side stream 2 (behind the words CSR build): the MFMA-bound dT GEMM next to the HBM-bound words update, then the
         // projection update; the next projection GEMM joins it
         // (started as soon as dx is final rather than after the dx GEMM: 1.084 vs 1.100 ms per step, interleaved A/B)
         // (the wait for ev_dx_ was issued by backward_dx, right behind the kernel that carries the event)
-        backward_T(aux2_stream_);
+        // Large batches of the eager tables: the dT product (split-bf16, gemm_dt.hip: workgroups of a whole CU's LDS and most
+        // of its registers) on the MAIN stream in front of the words update. On side stream 2 such workgroups trickle in
+        // behind the thousands of small workgroups of the two table passes (0.55 ms next to them, 0.05 ms alone) and the
+        // projection update behind them came too late for the next step; the 128 x 128-tiled fp32 kernel fits into the gaps
+        // but costs the passes 70 us of the step (a timing run without the product). In front of the passes it has the chip
+        // for 45-70 us while the documents pass starts up, and the projection update still runs on side stream 2.
+        // Interleaved A/B: NVSM shape 0.931 -> 0.921 ms, full_adam 0.850 -> 0.787; batch 25 600 0.588 -> 0.597 and
+        // |D| = 2 M 1.71 -> 1.72 the other way (the main stream is their longer chain): hence the rule. NVSM_DT_ON_MAIN=0 / 1.
+        static const int dt_main_env = [] { const char* e = std::getenv("NVSM_DT_ON_MAIN"); return e ? std::atoi(e) : -1; }();
+        dt_split_now_ = (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy)) &&
+                        gemm_dt_covers(cfg_.word_repr_size, cfg_.entity_repr_size, static_cast<int>(B_));
+        if (dt_split_now_) {
+            backward_T(stream_);
+            NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_));
+            NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_gathered_, 0));
+        } else {
+            backward_T(aux2_stream_);
+        }
         NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_bwdx_, 0));      // the dx GEMM is the last reader of T
         update_transform(lr, sl, aux2_stream_);
         NVSM_HIP_CHECK(hipEventRecord(ev_T_done_, aux2_stream_));

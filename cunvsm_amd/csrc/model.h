@@ -264,6 +264,8 @@ class Model {
     DevBuf<float> bn_mean_, bn_inv_std_, dbeta_, dgamma_;
     DevBuf<float> gT_, gb_, gT_partial_;
     int gemm_slabs_want_ = 128;
+    int dt_slabs_want_ = 64;           // ... of the split-bf16 dT kernel (gemm_dt.hip; NVSM_DT_SPLIT_SLABS)
+    bool dt_split_now_ = false;        // this step's dT product: that kernel, on the main stream (set by step())
 
     bool have_forward_ = false, have_grads_ = false;
     struct DeferredCost { double* host = nullptr; hipEvent_t ev = nullptr; double batch = 1.0; int64_t ticket = -1; };

@@ -77,7 +77,11 @@ def test_gemm_split_bf16_is_fp32_accurate(M, layout, N, K, monkeypatch):
 
 
 @pytest.mark.parametrize("split", [2, 7, 128])
-def test_gemm_split_k(split):
+@pytest.mark.parametrize("dt_split", ["1", "0"])
+def test_gemm_split_k(split, dt_split, monkeypatch):
+    """The projection gradient's shape: dT = Aᵀ·B split-K over the batch — the split-bf16 kernel (gemm_dt.hip) and the tiled
+    exact-fp32 one (NVSM_DT_SPLIT=0)."""
+    monkeypatch.setenv("NVSM_DT_SPLIT", dt_split)
     rs = np.random.RandomState(split)
     M, N, K = 300, 256, 4096
     A = rs.uniform(-1, 1, (K, M)).astype(np.float32)       # stored [K][M] like phrase
@@ -85,6 +89,22 @@ def test_gemm_split_k(split):
     Cout = np.empty((M, N), np.float32)
     ca._lib.check(ca.lib().nvsm_debug_gemm((split << 2) | 2, M, N, K, A.ctypes.data, Bm.ctypes.data, Cout.ctypes.data))
     assert rel_err(Cout, A.T.astype(np.float64) @ Bm.astype(np.float64)) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,split", [(300, 256, 51200, 32), (300, 256, 6400 + 17, 50), (64, 200, 1000, 3), (320, 132, 77, 1), (16, 256, 64, 4)])
+@pytest.mark.parametrize("products", ["6", "9"])
+def test_gemm_dt_split_bf16(M, N, K, split, products, monkeypatch):
+    """gemm_dt.hip on ragged slabs (a last tile of 17 rows, a batch shorter than a slab, padding columns), an asymmetric
+    operand, values over many binades; against an fp64 product, relative to Σ|a b|."""
+    monkeypatch.setenv("NVSM_GEMM_SPLIT", products)
+    rs = np.random.RandomState(M + N + K)
+    A = (rs.standard_normal((K, M)) * np.exp2(rs.randint(-10, 3, (K, M)))).astype(np.float32)
+    Bm = (rs.standard_normal((K, N)) * np.exp2(rs.randint(-10, 3, (K, N))) + np.arange(N)[None, :] * 1e-3).astype(np.float32)
+    Cout = np.empty((M, N), np.float32)
+    ca._lib.check(ca.lib().nvsm_debug_gemm((split << 2) | 2, M, N, K, A.ctypes.data, Bm.ctypes.data, Cout.ctypes.data))
+    ref = A.T.astype(np.float64) @ Bm.astype(np.float64)
+    scale = np.abs(A.T).astype(np.float64) @ np.abs(Bm).astype(np.float64)
+    assert np.abs((Cout - ref) / scale).max() < 1.5e-6
 
 
 def test_gemm_identity_asymmetric():

@@ -50,6 +50,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 F32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0        # dense (MI355X_MICROARCH.md)
+
+
+def gemm_split_products(B):
+    """Partial products of the split-bf16 projection kernels at batch B (0: the exact-fp32 MFMA kernels) — mirrors
+    gemm_split_products() / gemm_rows_max_m() of the engine (NVSM_GEMM_SPLIT, NVSM_GEMM_ROWS_MAX)."""
+    v = int(os.environ.get("NVSM_GEMM_SPLIT", "6"))
+    return v if v in (6, 9) and B > int(os.environ.get("NVSM_GEMM_ROWS_MAX", "8192")) else 0
 
 
 def zipf_ids(rs, n, size):
@@ -569,8 +577,26 @@ def main():
                     # are served by L2 / the Infinity Cache (the PMC summaries under profiles/ show the HBM bytes)
                     ent["served_from_cache"] = True
             if k.startswith("gemm_"):
+                # useful (fp32) flops per second. Large batches run the split-bf16 kernels (gemm_split.hip / gemm_dt.hip): every
+                # fp32 operand cut exactly into three bf16 pieces, 6 (or 9) bf16 MFMAs per product, fp32 accumulation — the
+                # matrix pipe then issues `products` times the useful flops at the bf16 rate
                 ent["TFLOPs"] = round(gemm_flops(wl, B) / (avg * 1e-3) / 1e12, 1)
-                ent["mfma_frac"] = round(ent["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 3)      # of the 157.3 TF/s fp32 MFMA peak
+                ent["over_f32_mfma_peak"] = round(ent["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 3)      # 157.3 TF/s: what exact-fp32 MFMAs could do at best
+                nprod = gemm_split_products(B)
+                # (the dT product runs the split kernel, on the main stream, for large batches of eagerly decayed tables only:
+                #  model.cpp step(); a table decays lazily from 96 MB of sparse-Adam state — 384 MB otherwise — when it has
+                #  at least half as many rows as a batch has entries)
+                def lazy(rows_, dim_, entries_):
+                    state_mb = rows_ * dim_ * 4 * (2 if "adam" in method else 1) / 2 ** 20
+                    return state_mb >= (96 if method == "sparse_adam" else 384) and rows_ * 2 >= entries_
+                if k == "gemm_bwd_T" and not (B >= 40960 and not lazy(wl["num_words"], wl["word_dim"], B * wl["window"])
+                                              and not lazy(wl["num_entities"], wl["entity_dim"], B * (wl["num_random"] + 1))):
+                    nprod = 0
+                if nprod:
+                    ent["arithmetic"] = "f32 as 3 bf16 planes, %d of 9 partial products, f32 accumulation" % nprod
+                    ent["bf16_mfma_frac"] = round(ent["TFLOPs"] * nprod / BF16_MFMA_PEAK_TFLOPS, 3)
+                else:
+                    ent["mfma_frac"] = ent["over_f32_mfma_peak"]
             breakdown[k] = ent
         # Roofline kernel: the document-embedding gather + loss kernel — the HBM gather the north star names, and the
         # largest kernel of the step that runs with nothing else next to it but the (tiny) side-stream sorts. In the fused

@@ -55,24 +55,28 @@ def mfma(path, json_path=None, cu_num=256, xcds=8):
         e[cname] = e.get(cname, 0.0) + val
     rows = []
     for k, e in agg.items():
-        busy, mops, gui = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), e.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0), e.get("GRBM_GUI_ACTIVE", 0.0)
+        busy, gui = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), e.get("GRBM_GUI_ACTIVE", 0.0)
+        # (the split-bf16 GEMMs issue bf16 MFMAs: six or nine per fp32 product; one MOP = 512 flops for either type)
+        mops_f32, mops_bf16 = e.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0), e.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
+        mops = mops_f32 + mops_bf16
         if mops <= 0:
             continue
+        e["mfma_type"] = "bf16" if mops_bf16 > mops_f32 else "f32"
         e["mfma_util_pct"] = 100.0 * busy / ((gui / xcds) * cu_num * 4) if gui else None
         e["mfma_util_pct_uncorrected_formula"] = 100.0 * busy / (gui * cu_num * 4) if gui else None
         e["mfma_flops"] = mops * 512
         e["TFLOPs_under_pmc"] = mops * 512 / (e["avg_us"] * 1e-6) / 1e12 if e["avg_us"] else None
         rows.append((k, e))
-    print("%-70s %7s %10s %14s %14s %12s" % ("kernel", "calls", "avg_us", "MFMA GFLOP", "MfmaUtil %", "TF/s (pmc run)"))
+    print("%-70s %7s %10s %5s %14s %14s %12s" % ("kernel", "calls", "avg_us", "type", "MFMA GFLOP", "MfmaUtil %", "TF/s (pmc run)"))
     for k, e in sorted(rows, key=lambda kv: -kv[1]["mfma_flops"]):
-        print("%-70s %7d %10.2f %14.3f %14.1f %12.1f" % (k[:70], e["launches"], e["avg_us"], e["mfma_flops"] / 1e9,
-                                                         e["mfma_util_pct"] or 0.0, e["TFLOPs_under_pmc"] or 0.0))
+        print("%-70s %7d %10.2f %5s %14.3f %14.1f %12.1f" % (k[:70], e["launches"], e["avg_us"], e["mfma_type"], e["mfma_flops"] / 1e9,
+                                                             e["mfma_util_pct"] or 0.0, e["TFLOPs_under_pmc"] or 0.0))
     if json_path:
         import json
         with open(json_path, "w") as f:
-            json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE; "
+            json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE; "
                                "MfmaUtil = 100*BUSY/((GUI_ACTIVE/8 XCDs)*256 CUs*4 SIMDs) — GRBM_GUI_ACTIVE is reported summed over the 8 XCDs; "
-                               "the fp32 MFMA peak is 157.3 TF/s",
+                               "the fp32 MFMA peak is 157.3 TF/s; kernels of type bf16 are the split-bf16 GEMMs (issued bf16 MFMA flops: 6 or 9 per fp32 flop, bf16 peak 2.5 PF/s)",
                        "kernels": {k: e for k, e in rows}}, f, indent=1, sort_keys=True)
 
 

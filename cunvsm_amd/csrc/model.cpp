@@ -417,7 +417,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, dev_flags));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, dev_flags));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, dev_flags));
-    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_step_begin_[0], &ev_step_begin_[1], &ev_gathered_})
+    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_step_begin_[0], &ev_step_begin_[1], &ev_gathered_, &ev_words_late_})
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, dev_flags));
     for (hipEvent_t* e : {&ev_copied_, &ev_host_ids_[0], &ev_host_ids_[1]})
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -493,7 +493,7 @@ Model::~Model() {
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
     for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_, ev_copied_, ev_step_begin_[0], ev_step_begin_[1],
-                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_}) if (e) (void)hipEventDestroy(e);
+                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_, ev_words_late_}) if (e) (void)hipEventDestroy(e);
     for (int p = 0; p < 2; ++p) if (host_ids_pin_[p]) (void)hipHostFree(host_ids_pin_[p]);
     if (err_host_) (void)hipHostFree(err_host_);
     // (copy_stream_ is side stream 3)
@@ -831,10 +831,9 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             // already: this copy is queued behind the previous step's documents sort, which waited for that step's prologue,
             // i.e. for everything the step before it had on the main stream — no event, and no record packet in front of
             // the prologue on the critical stream.
-            static const bool copies_behind_sort = [] {
-                const char* a = std::getenv("NVSM_CSR_AFTER"); const char* l = std::getenv("NVSM_SORT_LAYOUT");
-                return (!a || std::atoi(a) == 0) && (!l || std::atoi(l) == 4);
-            }();
+            static const bool csr_at_start = [] { const char* a = std::getenv("NVSM_CSR_AFTER"); return !a || std::atoi(a) == 0; }();
+            // (the layout follows the batch size: the argument needs the previous step's documents sort on the copy stream)
+            const bool copies_behind_sort = csr_at_start && csr_stream_layout() == 4 && last_csr_layout_ == 4;
             if (!(copies_behind_sort && copy_stream_ == aux3_stream_ && aux3_stream_)) {
                 NVSM_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_step_begin_[p ^ 1], 0));
                 NVSM_HIP_CHECK(hipEventRecord(ev_step_begin_[p], stream_));
@@ -923,26 +922,37 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // The documents CSR arrays are still being read by the previous step's documents update, so a build on another stream
     // would have to wait for it (ev_E_done_) all the same; hence the second set of CSR arrays (TableState::CsrIndex).
     // 4 = documents on side stream 3, words on 2: neither queues behind the previous step's tails (default).
-    static const int sort_layout = [] { const char* e = std::getenv("NVSM_SORT_LAYOUT"); return e ? std::atoi(e) : 4; }();
-    auto launch_csr_builds = [&](hipEvent_t after) {
+    // Where the dT product runs on the main stream (dt_on_main(): large batches of eager tables) side stream 2 is idle for the
+    // whole step, and both builds go there one behind the other, documents first (2): the loss kernel then runs next to
+    // one sort at a time instead of two, and the words CSR is still early (NVSM shape 0.933 -> 0.911 ms, loss kernel
+    // 185 -> 176 us in-step; everywhere else 2 is 4-25 % slower than 4: interleaved A/B).
+    const int sort_layout = csr_stream_layout();
+    last_csr_layout_ = sort_layout;
+    // which: 1 = the documents table, 2 = the words table, 3 = both
+    auto launch_csr_builds = [&](hipEvent_t after, int which = 3) {
         const int layout = aux3_stream_ ? sort_layout : (sort_layout == 4 ? 0 : sort_layout);
         hipStream_t se = (layout == 0) ? aux_stream_ : (layout == 4 ? aux3_stream_ : aux2_stream_);
         hipStream_t sw = (layout == 3) ? aux_stream_ : aux2_stream_;
-        NVSM_HIP_CHECK(hipStreamWaitEvent(se, after, 0));
-        NVSM_HIP_CHECK(hipStreamWaitEvent(sw, after, 0));
+        if (which & 1) NVSM_HIP_CHECK(hipStreamWaitEvent(se, after, 0));
+        if (which & 2) NVSM_HIP_CHECK(hipStreamWaitEvent(sw, after, 0));
         // (the documents table has two sets of CSR arrays: its build does not wait for the previous documents update)
-        if (se != aux_stream_ && E_pending_ && ents_.idx_sets < 2) NVSM_HIP_CHECK(hipStreamWaitEvent(se, ev_E_done_, 0));
-        csr_joined_ents_ = csr_joined_words_ = false;
-        words_csr_stream_ = sw;
+        if ((which & 1) && se != aux_stream_ && E_pending_ && ents_.idx_sets < 2) NVSM_HIP_CHECK(hipStreamWaitEvent(se, ev_E_done_, 0));
+        if (which & 1) csr_joined_ents_ = false;
+        if (which & 2) { csr_joined_words_ = false; words_csr_stream_ = sw; }
         auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, ids_p_, N, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
         auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, widx_.p, B * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
-        if (layout == 1) { wrds(); ents(); } else { ents(); wrds(); }
-        if (se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
+        if (layout == 1) { if (which & 2) wrds(); if (which & 1) ents(); } else { if (which & 1) ents(); if (which & 2) wrds(); }
+        if ((which & 1) && se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
     };
     const bool any_lazy = words_.lazy || ents_.lazy;
     // (a lazily decayed documents table read by the generic loss kernel is refreshed by list first: that needs the CSR now)
     const bool csr_first = csr_after == 0 || (ents_.lazy && !loss_reads_lazily(de, static_cast<int>(R_), cfg_.l2_normalize_entity_reprs != 0));
-    if (csr_first) launch_csr_builds(ev_inputs_);
+    // NVSM_WORDS_CSR_LATE=1 (experiment): the words table's build behind the loss kernel instead of at the step's start — it is
+    // needed only behind the dx and dT products, whose MFMA-bound 0.18 ms it then runs next to, instead of next to the
+    // HBM-bound loss kernel
+    static const bool words_csr_late_env = [] { const char* e = std::getenv("NVSM_WORDS_CSR_LATE"); return e && e[0] == '1'; }();
+    const bool words_csr_late = words_csr_late_env && csr_after == 0 && !any_lazy;
+    if (csr_first) launch_csr_builds(ev_inputs_, words_csr_late ? 1 : 3);
     // (lazy dense decay: the gathers below bring the rows they read up to date on the fly — LazyView — and the row passes of
     //  the update do it for real; nothing waits for the sorts here)
 
@@ -1044,6 +1054,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         if (!prof_bound) prof.end(stream_);
     }
     if (csr_after == 3 && !csr_first) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
+    if (words_csr_late) { NVSM_HIP_CHECK(hipEventRecord(ev_words_late_, stream_)); launch_csr_builds(ev_words_late_, 2); }
     NVSM_HIP_CHECK(hipGetLastError());      // a failed launch of any kernel above surfaces here, not at the next sync
     have_forward_ = true;
     if (debug_) {
@@ -1518,6 +1529,19 @@ void Model::update_transform(float lr, float sl, hipStream_t strm) {
     cut_transform_planes(strm);
 }
 
+// which side streams build the two tables' CSRs this step (compute_cost: NVSM_SORT_LAYOUT)
+int Model::csr_stream_layout() const {
+    static const int sort_layout_env = [] { const char* e = std::getenv("NVSM_SORT_LAYOUT"); return e ? std::atoi(e) : -1; }();
+    return sort_layout_env >= 0 ? sort_layout_env : (dt_on_main() ? 2 : 4);
+}
+
+// the fused step's dT product on the main stream with the split-bf16 kernel (see step()): large batches of eager tables
+bool Model::dt_on_main() const {
+    static const int dt_main_env = [] { const char* e = std::getenv("NVSM_DT_ON_MAIN"); return e ? std::atoi(e) : -1; }();
+    return (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy)) && cfg_.world_size <= 1 &&
+           gemm_dt_covers(cfg_.word_repr_size, cfg_.entity_repr_size, static_cast<int>(B_));
+}
+
 // T changed: its bf16 planes for the next two projection products, behind the writer on the writer's stream (off the critical
 // path in the fused step: side stream 2, which the next projection GEMM joins anyway)
 void Model::cut_transform_planes(hipStream_t strm) {
@@ -1609,9 +1633,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         // for 45-70 us while the documents pass starts up, and the projection update still runs on side stream 2.
         // Interleaved A/B: NVSM shape 0.931 -> 0.921 ms, full_adam 0.850 -> 0.787; batch 25 600 0.588 -> 0.597 and
         // |D| = 2 M 1.71 -> 1.72 the other way (the main stream is their longer chain): hence the rule. NVSM_DT_ON_MAIN=0 / 1.
-        static const int dt_main_env = [] { const char* e = std::getenv("NVSM_DT_ON_MAIN"); return e ? std::atoi(e) : -1; }();
-        dt_split_now_ = (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy)) &&
-                        gemm_dt_covers(cfg_.word_repr_size, cfg_.entity_repr_size, static_cast<int>(B_));
+        dt_split_now_ = dt_on_main();
         if (dt_split_now_) {
             backward_T(stream_);
             NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_));

@@ -205,7 +205,7 @@ class Model {
     // fused step(): the documents update (HBM bound) and the dT GEMM (MFMA bound) run on the side stream next to the
     // dx GEMM and the words update on the main stream
     hipEvent_t ev_gathered_ = nullptr;
-    hipEvent_t ev_loss_ = nullptr, ev_dx_ = nullptr, ev_bwdx_ = nullptr, ev_E_done_ = nullptr, ev_T_done_ = nullptr;
+    hipEvent_t ev_loss_ = nullptr, ev_dx_ = nullptr, ev_bwdx_ = nullptr, ev_E_done_ = nullptr, ev_T_done_ = nullptr, ev_words_late_ = nullptr;
     hipStream_t words_csr_stream_ = nullptr;            // the side stream that built this step's words CSR (NVSM_SORT_LAYOUT)
     hipStream_t words_untouched_stream_ = nullptr;      // set by step() around update_words (kernels.h launch_table_pass untouched_s)
     bool words_tail_pending_ = false;                   // side stream 2 still decays words rows: the next word gather joins it
@@ -257,6 +257,9 @@ class Model {
     DevBuf<char> planes_fwd_, planes_bwd_;
     GemmSplitWs split_fwd_{}, split_bwd_{};
     void cut_transform_planes(hipStream_t strm);
+    bool dt_on_main() const;
+    int csr_stream_layout() const;
+    int last_csr_layout_ = -1;          // the layout of the previous step's builds (host-batch copies lean on it)
     void alloc_sums(SumsBufs& b, int colgroups, int contrib_cap, int width_cap);
     bool csr_joined_words_ = true, csr_joined_ents_ = true;      // the main stream is behind the current CSR builds
     double* stats_fwd_ = nullptr;

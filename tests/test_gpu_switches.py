@@ -26,6 +26,11 @@ if shape == "split":      # tables larger than the batch: touched-row list + str
     spec = dict(num_words=20000, num_entities=30000, word_dim=64, entity_dim=96, window=5, num_random=4, nonlinearity="tanh",
                 batch_norm=False, bias_negative_samples=True, update_method="adagrad", **{"lambda": 0.01})
     B = 512
+elif shape == "large":    # the headline shape's kernels and stream layout: batch >= 40 960, d_w = 300, d_e = 256 — split-bf16
+    # products with the batch-norm backward inside, the dT product on the main stream, both CSR builds on side stream 2
+    spec = dict(num_words=3000, num_entities=5000, word_dim=300, entity_dim=256, window=4, num_random=3, nonlinearity="hard_tanh",
+                batch_norm=True, bias_negative_samples=False, update_method="sparse_adam", **{"lambda": 0.01})
+    B = 40960
 else:                      # batch larger than the tables: dense passes, chunk tree, batch-norm, sparse Adam (NVSM-like)
     spec = dict(num_words=3000, num_entities=5000, word_dim=60, entity_dim=64, window=6, num_random=5, nonlinearity="hard_tanh",
                 batch_norm=True, bias_negative_samples=False, update_method="sparse_adam", **{"lambda": 0.01})
@@ -70,10 +75,24 @@ def _run(shape, env_extra):
     return json.loads(lines[-1][len("RESULT "):])
 
 
-@pytest.mark.parametrize("shape", ["split", "dense"])
+# the large shape: where the CSR builds run, host batches copied or pulled, the words build behind the loss kernel
+LARGE_VARIANTS = [
+    {},
+    {"NVSM_SORT_LAYOUT": "4"},
+    {"NVSM_SORT_LAYOUT": "2"},
+    {"NVSM_SORT_LAYOUT": "1"},
+    {"NVSM_STOP_EVENTS": "0", "NVSM_HOST_PULL": "0"},
+    {"NVSM_WORDS_CSR_LATE": "1"},
+    {"NVSM_AUX2_PRIO": "2", "NVSM_SPLIT_NT": "1"},
+    {"NVSM_SPLIT_FUSE": "0"},
+]
+
+
+@pytest.mark.parametrize("shape", ["split", "dense", "large"])
 def test_orchestration_switches_do_not_change_results(shape):
-    base = _run(shape, VARIANTS[0])
+    variants = LARGE_VARIANTS if shape == "large" else VARIANTS
+    base = _run(shape, variants[0])
     assert len(base["costs"]) == 3 and all(c == c for c in base["costs"])
-    for v in VARIANTS[1:]:
+    for v in variants[1:]:
         got = _run(shape, v)
         assert got == base, (shape, v, got, base)

@@ -545,6 +545,7 @@ int gemm_split_products() {
 // what launch_gemm_split accepts (given 16 B aligned operands and leading dimensions that are multiples of 4)
 bool gemm_split_covers(int b_layout, int M, int N, int K, bool bn) {
     if (!gemm_split_products() || M < 1024 || (K % 4) || (N % 4) || K < 8) return false;
+    if (static_cast<uint64_t>(M) * static_cast<uint64_t>(K) * 4 >= (1ull << 32)) return false;      // 32-bit byte offsets into A (lda = K)
     const int cbs = (N + 15) / 16;
     if (bn && (b_layout != 1 || K > 320)) return false;
     return b_layout == 0 ? cbs == 2 * kSplitWaves : (cbs > 2 * kSplitWaves && cbs <= 3 * kSplitWaves);
@@ -558,6 +559,8 @@ bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, i
     const int nprod = gemm_split_products();
     if (bn && (b_layout != 1 || K > 320 || (bn->pre && (bn->dy != A || reinterpret_cast<uintptr_t>(bn->pre) % 16)))) return false;
     if (!nprod || M < 1024 || !ws || !ws->planes || ws->bytes < gemm_split_planes_bytes(N, K)) return false;
+    // (the kernel addresses A — and pre — by 32-bit byte offsets from the base)
+    if (static_cast<uint64_t>(M) * static_cast<uint64_t>(lda) * 4 >= (1ull << 32) || lda < K) return false;
     if ((K % 4) || (N % 4) || (lda % 4) || (ldb % 4) || (ldc % 4) || K < 8) return false;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) % 16) return false;
     if (bias_n && reinterpret_cast<uintptr_t>(bias_n) % 16) return false;

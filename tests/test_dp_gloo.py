@@ -37,6 +37,9 @@ SPEC = dict(num_words=60, num_entities=40, word_dim=12, entity_dim=8, window=3, 
             nonlinearity="hard_tanh", batch_norm=True, update_method="sgd")
 SPEC["lambda"] = 0.01
 SPEC_NOBN = dict(SPEC, batch_norm=False, nonlinearity="tanh", bias_negative_samples=True)
+# the metric's dimensions at a per-rank batch above 8 192 rows: the split-bf16 projection kernels with the (synchronised)
+# batch-norm backward inside the backward product, under data parallelism
+SPEC_WIDE = dict(SPEC, num_words=2000, num_entities=3000, word_dim=300, entity_dim=256, window=4, num_random=3)
 
 
 def _worker_oracle(rank, port, spec, B, out_dir):
@@ -114,12 +117,11 @@ def _worker_gpu(rank, port, spec, B, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spec", [SPEC, SPEC_NOBN], ids=["bn", "nobn"])
-def test_dp_hip_equals_single_gpu(spec, tmp_path):
+@pytest.mark.parametrize("spec,B", [(SPEC, 256), (SPEC_NOBN, 256), (SPEC_WIDE, 2 * 8704)], ids=["bn", "nobn", "wide"])
+def test_dp_hip_equals_single_gpu(spec, B, tmp_path):
     import torch.multiprocessing as mp
     import cunvsm_amd as ca
     from tests.helpers import gpu_model, load_params, rel_err
-    B = 256
     port = _free_port()
     mp.spawn(_worker_gpu, args=(port, spec, B, str(tmp_path)), nprocs=WORLD, join=True)
     params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
@@ -159,8 +161,8 @@ def _worker_gpu_step(rank, port, spec, B, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method", ["sgd", "sparse_adam"])
-def test_dp_fused_step(tmp_path, method):
+@pytest.mark.parametrize("method,wide", [("sgd", False), ("sparse_adam", False), ("sparse_adam", True)], ids=["sgd", "sparse_adam", "sparse_adam_wide"])
+def test_dp_fused_step(tmp_path, method, wide):
     """nvsm_step under data parallelism (documents update on side stream 1; dT GEMM, the all-reduce of the projection
     gradient and the projection update on side stream 2, joined by the next step): after the first step the replicated
     projection is identical on both ranks and equal to the single-GPU step on the whole batch; the loss of the first
@@ -168,8 +170,9 @@ def test_dp_fused_step(tmp_path, method):
     import torch.multiprocessing as mp
     import cunvsm_amd as ca
     from tests.helpers import gpu_model, load_params, rel_err
-    spec = dict(SPEC, update_method=method)
-    B = 256
+    # (wide: the metric's dimensions at a per-rank batch above 8 192 rows — the split-bf16 kernels under the fused step)
+    spec = dict(SPEC_WIDE if wide else SPEC, update_method=method)
+    B = 2 * 8704 if wide else 256
     port = _free_port()
     mp.spawn(_worker_gpu_step, args=(port, spec, B, str(tmp_path)), nprocs=WORLD, join=True)
     params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
@@ -324,7 +327,7 @@ def test_dp_loss_trajectory_hip(tmp_path, collectives, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method", ["sgd", "sparse_adam"])
-def test_dp_fused_step_collectives_on_the_main_stream(tmp_path, method, monkeypatch):
+@pytest.mark.parametrize("method,wide", [("sgd", False), ("sparse_adam", False), ("sparse_adam", True)], ids=["sgd", "sparse_adam", "sparse_adam_wide"])
+def test_dp_fused_step_collectives_on_the_main_stream(tmp_path, method, wide, monkeypatch):
     monkeypatch.setenv("NVSM_DP_T_ON_MAIN", "1")
-    test_dp_fused_step(tmp_path, method)
+    test_dp_fused_step(tmp_path, method, wide)

@@ -195,8 +195,11 @@ void launch_materialize_grad_entity_l2(const float* coef, const float* proj, con
 // null (= 0, 1, 2, …). err_flag: the engine's error word (a grid-wide wait that never completes stores NVSM_SORT_TIMEOUT).
 // zero_buf (optional, 16 B aligned, zero_count % 4 == 0): ints the first pass clears on the way (the CSR's per-step counters).
 size_t sort_pairs_temp_bytes(int64_t n, int bits);
+// gate (optional, device): the launches return at once when *gate == 0 — the outputs are then left as they were (the chunk
+// order of a table none of whose rows has chunks this step).
 void sort_pairs(void* temp, size_t temp_bytes, uint64_t* epoch, const int* keys_in, int* keys_out, const int* vals_in,
-                int* vals_out, int64_t n, int bits, int* err_flag, hipStream_t s, int* zero_buf = nullptr, int64_t zero_count = 0);
+                int* vals_out, int64_t n, int bits, int* err_flag, hipStream_t s, int* zero_buf = nullptr, int64_t zero_count = 0,
+                const int* gate = nullptr);
 struct Csr {
     int* sorted_key;      // [n]
     int* sorted_entry;    // [n]  entry ids ordered by row (stable)

@@ -71,8 +71,9 @@ __device__ __forceinline__ void count_digits(const int* __restrict__ keys_in, ui
 // the CSR's row bounds — instead of a memset launch of their own.)
 __global__ __launch_bounds__(kSortThreads) void radix_count_kernel(
         const int* __restrict__ keys_in, uint32_t n, int shift, int D, uint32_t per_wave, int* __restrict__ counts,
-        int4* __restrict__ zero_buf, uint32_t zero_n4) {
+        int4* __restrict__ zero_buf, uint32_t zero_n4, const int* __restrict__ gate) {
     __shared__ int cnt[kSortWaves][kSortMaxBuckets];
+    if (gate && *gate == 0) return;      // (nothing to sort this time: see sort_pairs)
     for (uint32_t i = blockIdx.x * kSortThreads + threadIdx.x; i < zero_n4; i += gridDim.x * kSortThreads)
         zero_buf[i] = make_int4(0, 0, 0, 0);
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -99,9 +100,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_count_kernel(
 // then rank and scatter.
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         const int* __restrict__ keys_in, const int* __restrict__ vals_in, int* __restrict__ keys_out, int* __restrict__ vals_out,
-        uint32_t n, int shift, int D, uint32_t per_wave, const int* __restrict__ counts) {
+        uint32_t n, int shift, int D, uint32_t per_wave, const int* __restrict__ counts, const int* __restrict__ gate) {
     __shared__ int cnt[kSortWaves][kSortMaxBuckets];
     __shared__ int wave_tot[kSortWaves];
+    if (gate && *gate == 0) return;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int NB = 1 << D;
     const uint32_t mask = static_cast<uint32_t>(NB - 1);
@@ -211,7 +213,7 @@ size_t sort_pairs_temp_bytes(int64_t n, int /*bits*/) {
 }
 
 void sort_pairs(void* temp, size_t temp_bytes, uint64_t* epoch, const int* keys_in, int* keys_out, const int* vals_in,
-                int* vals_out, int64_t n, int bits, int* err_flag, hipStream_t s, int* zero_buf, int64_t zero_count) {
+                int* vals_out, int64_t n, int bits, int* err_flag, hipStream_t s, int* zero_buf, int64_t zero_count, const int* gate) {
     if (n <= 0) return;
     if (zero_count % 4 || reinterpret_cast<uintptr_t>(zero_buf) % 16) throw std::runtime_error("sort_pairs: zero_buf must be 16 B aligned, a multiple of 4 ints");
     if (n >= (int64_t(1) << 31)) throw std::runtime_error("sort_pairs: more than 2^31 entries");
@@ -232,9 +234,9 @@ void sort_pairs(void* temp, size_t temp_bytes, uint64_t* epoch, const int* keys_
         int* dst_v = to_out ? vals_out : tmp_v;
         hipLaunchKernelGGL(radix_count_kernel, dim3(p.blocks), dim3(kSortThreads), 0, s, src_k, static_cast<uint32_t>(n), shift,
                            p.digit_bits[i], p.per_wave, counts, reinterpret_cast<int4*>(i == 0 ? zero_buf : nullptr),
-                           static_cast<uint32_t>(i == 0 && zero_buf ? zero_count / 4 : 0));
+                           static_cast<uint32_t>(i == 0 && zero_buf ? zero_count / 4 : 0), gate);
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(p.blocks), dim3(kSortThreads), 0, s, src_k, src_v, dst_k, dst_v,
-                           static_cast<uint32_t>(n), shift, p.digit_bits[i], p.per_wave, counts);
+                           static_cast<uint32_t>(n), shift, p.digit_bits[i], p.per_wave, counts, gate);
         shift += p.digit_bits[i];
         src_k = dst_k; src_v = dst_v;
     }

@@ -67,7 +67,10 @@ __global__ void csr_chunks_kernel(const int* __restrict__ row_begin, const int* 
 __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, const int* __restrict__ row_begin,
                                       const int* __restrict__ row_end, const int* __restrict__ chunk_base,
                                       const int* __restrict__ chunk2_base, int* __restrict__ chunk_desc,
-                                      int* __restrict__ chunk2_desc, int max_chunks, int max_chunks2) {
+                                      int* __restrict__ chunk2_desc, int max_chunks, int max_chunks2, const int* __restrict__ num_chunks) {
+    // no row of more than kChunk entries this step (the documents table, most steps): nothing to describe — the kernel would
+    // otherwise read three words per entry to find that out (27 us next to the loss kernel for 870 k entries)
+    if (num_chunks[0] == 0) return;
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int r = key[i];
@@ -117,7 +120,7 @@ void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared) {
                        c.chunk_base, c.chunk2_base, c.num_chunks);
     if (c.n > 0)
         hipLaunchKernelGGL(csr_chunk_fill_kernel, dim3(csr_grid(c.n, sparse)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin,
-                           c.row_end, c.chunk_base, c.chunk2_base, c.chunk_desc, c.chunk2_desc, c.max_chunks, c.max_chunks2);
+                           c.row_end, c.chunk_base, c.chunk2_base, c.chunk_desc, c.chunk2_desc, c.max_chunks, c.max_chunks2, c.num_chunks);
 }
 
 // =============================================================================================
@@ -1068,6 +1071,7 @@ static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
 // microseconds of each other. Same chunks, same sums: results do not change.
 __global__ void chunk_order_key_kernel(Csr c, int* __restrict__ key) {
     const int nchunks = min(c.num_chunks[0], c.max_chunks);
+    if (nchunks == 0) return;      // (no chunks: their order is not looked at, and the sort behind this kernel returns at once too)
     for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < c.max_chunks; ci += gridDim.x * blockDim.x) {
         int k = 511;                                                           // unused slots sort behind the chunks (stable)
         if (ci < nchunks) {
@@ -1080,7 +1084,7 @@ __global__ void chunk_order_key_kernel(Csr c, int* __restrict__ key) {
 void launch_chunk_order(const Csr& c, int* key_in, int* key_out, void* sort_temp, size_t sort_temp_bytes, hipStream_t s) {
     if (!c.chunk_order || c.n <= 0 || c.max_chunks <= 0) return;
     hipLaunchKernelGGL(chunk_order_key_kernel, dim3(stream_grid(c.max_chunks, 256)), dim3(256), 0, s, c, key_in);
-    sort_pairs(sort_temp, sort_temp_bytes, nullptr, key_in, key_out, nullptr, c.chunk_order, c.max_chunks, 9, nullptr, s, nullptr, 0);
+    sort_pairs(sort_temp, sort_temp_bytes, nullptr, key_in, key_out, nullptr, c.chunk_order, c.max_chunks, 9, nullptr, s, nullptr, 0, c.num_chunks);
 }
 
 // NVSM_ENTRY_WALK=0 (A/B runs, tests): the list walk for the rows of tables much larger than the batch

@@ -417,9 +417,10 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, dev_flags));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, dev_flags));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, dev_flags));
-    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_step_begin_[0], &ev_step_begin_[1], &ev_gathered_, &ev_words_late_})
+    NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&cost_host_), sizeof(double), hipHostMallocDefault));
+    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_step_begin_[0], &ev_step_begin_[1], &ev_gathered_, &ev_words_late_, &ev_cost_ready_})
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, dev_flags));
-    for (hipEvent_t* e : {&ev_copied_, &ev_host_ids_[0], &ev_host_ids_[1]})
+    for (hipEvent_t* e : {&ev_copied_, &ev_host_ids_[0], &ev_host_ids_[1], &ev_cost_copied_})      // (the host waits on these)
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&err_host_), sizeof(int), hipHostMallocDefault));
     *err_host_ = 0;
@@ -493,7 +494,8 @@ Model::~Model() {
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
     for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_, ev_copied_, ev_step_begin_[0], ev_step_begin_[1],
-                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_, ev_words_late_}) if (e) (void)hipEventDestroy(e);
+                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_, ev_words_late_, ev_cost_ready_, ev_cost_copied_}) if (e) (void)hipEventDestroy(e);
+    if (cost_host_) (void)hipHostFree(cost_host_);
     for (int p = 0; p < 2; ++p) if (host_ids_pin_[p]) (void)hipHostFree(host_ids_pin_[p]);
     if (err_host_) (void)hipHostFree(err_host_);
     // (copy_stream_ is side stream 3)
@@ -1584,6 +1586,17 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     loss_stop_event_ = loss_event ? ev_loss_ : nullptr;
     try { compute_cost(batch, entity_ids); } catch (...) { loss_stop_event_ = nullptr; throw; }
     loss_stop_event_ = nullptr;
+    // The caller wants this step's loss: the loss word is final behind the loss kernel, 0.3 ms into a 0.9 ms step. A copy on side
+    // stream 3 behind an event recorded here lets the host read it while the backward pass and the updates still run, and
+    // queue the next step in the meantime (waiting for the whole step instead — get_cost() — left the GPU idle while the host
+    // queued: 5 % of the NVSM step). Not under data parallelism, where the word is summed over the ranks in the backward pass.
+    const bool early_cost = cost && cfg_.world_size <= 1 && aux3_stream_ && cost_host_;
+    if (early_cost) {
+        NVSM_HIP_CHECK(hipEventRecord(ev_cost_ready_, stream_));
+        NVSM_HIP_CHECK(hipStreamWaitEvent(aux3_stream_, ev_cost_ready_, 0));
+        NVSM_HIP_CHECK(hipMemcpyAsync(cost_host_, stats_bwd_, sizeof(double), hipMemcpyDeviceToHost, aux3_stream_));
+        NVSM_HIP_CHECK(hipEventRecord(ev_cost_copied_, aux3_stream_));
+    }
     const float sl = scaled_regularization_lambda();
     if (lr < 0.f || sl < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");
     // Data parallel: the dT GEMM, the all-reduce of the projection gradient and the projection update ride on side stream 2
@@ -1678,7 +1691,15 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     if (dp) update_transform(lr, sl, stream_);
     NVSM_HIP_CHECK(hipGetLastError());
     have_grads_ = false;
-    if (cost) *cost = get_cost();
+    if (early_cost) {
+        NVSM_HIP_CHECK(hipEventSynchronize(ev_cost_copied_));
+        raise_device_error();
+        cost_ = -(*cost_host_ / static_cast<double>(B_));
+        cost_valid_ = true;
+        *cost = static_cast<float>(cost_);
+    } else if (cost) {
+        *cost = get_cost();
+    }
 }
 
 int64_t Model::step_deferred(const nvsm_batch& batch, const int64_t* entity_ids, float lr) {

@@ -206,6 +206,8 @@ class Model {
     // dx GEMM and the words update on the main stream
     hipEvent_t ev_gathered_ = nullptr;
     hipEvent_t ev_loss_ = nullptr, ev_dx_ = nullptr, ev_bwdx_ = nullptr, ev_E_done_ = nullptr, ev_T_done_ = nullptr, ev_words_late_ = nullptr;
+    hipEvent_t ev_cost_ready_ = nullptr, ev_cost_copied_ = nullptr;      // step(cost): the loss word copied out behind the loss kernel
+    double* cost_host_ = nullptr;                                         // ... into this page-locked word
     hipStream_t words_csr_stream_ = nullptr;            // the side stream that built this step's words CSR (NVSM_SORT_LAYOUT)
     hipStream_t words_untouched_stream_ = nullptr;      // set by step() around update_words (kernels.h launch_table_pass untouched_s)
     bool words_tail_pending_ = false;                   // side stream 2 still decays words rows: the next word gather joins it

@@ -165,7 +165,10 @@ int nvsm_get_cost_f64(nvsm_model* m, double* cost);
 float nvsm_scaled_regularization_lambda(nvsm_model* m);
 
 /* One iterate_data loop body (cpp/main.cu:400-444): compute_cost + compute_gradients + update with
- * scaled lambda; fully asynchronous. cost may be NULL (no read-back, no sync). */
+ * scaled lambda; fully asynchronous. cost may be NULL (no read-back, no sync). With a cost pointer the call returns once
+ * the step's loss kernel has run and its loss word has been copied out (single GPU: the backward pass and the updates
+ * are still running then, and the caller can queue the next step); under data parallelism, where the word is summed
+ * over the ranks in the backward pass, it waits for the step as nvsm_get_cost does. */
 int nvsm_step(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids, float learning_rate, float* cost);
 
 /* The same step for training loops that want the loss of EVERY batch, as cpp/main.cu:427-444 does, without putting the

@@ -54,13 +54,18 @@ struct DtArgs {
 };
 
 __device__ __forceinline__ void dt_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
-    h = (b0 >> 16) | (b1 & 0xffff0000u);
-    const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
-    const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
-    m = (c0 >> 16) | (c1 & 0xffff0000u);
-    const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
-    l = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+    // round-to-nearest pieces (v_cvt_pk_bf16_f32: two elements per instruction): h = bf16(x), m = bf16(x - h), l = x - h - m.
+    // Both differences are exact in fp32 and the last one has at most eight significant bits, so x = h + m + l exactly;
+    // the pieces are at most half an ulp of the piece above them (a cut by truncation leaves up to a whole one, all of x's
+    // sign): the partial products a six-product run leaves out are below 2^-26 of a·b and of either sign.
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {x0, x1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t r = v - f32x2_t{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+    const f32x2_t s2 = r - f32x2_t{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(s2, bf16x2_t));
 }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // 32x32x16: half as many instructions as 16x16x32 for the same flops, and 32 cycles of matrix pipe behind each in which

@@ -4,14 +4,16 @@
 //                                                                + the batch-norm backward on the way in: cpp/cudnn_utils.cu:143-183)
 // gfx950 multiplies fp32 operands in its matrix cores at the fp32 VECTOR rate (v_mfma_f32_32x32x2_f32: 157 TFLOP/s, 1/16 of
 // the bf16 rate) and has no TF32-like mode. But an fp32 number is EXACTLY the sum of three bf16 numbers — x = h + m + l with
-// h = x cut to its upper 16 bits, m = (x − h) cut likewise, l = x − h − m: 8 + 8 + 8 significant bits — so a product a·b is
+// h = bf16(x), m = bf16(x − h), l = x − h − m (round to nearest; both differences are exact and the last has at most eight
+// significant bits) — so a product a·b is
 // exactly the sum of the nine products of their pieces, each of which the bf16 MFMA forms exactly (8 x 8 bits) and adds into
 // an fp32 accumulator: fp32 accumulation of exact products, as the fp32 pipe does, in a different order. Six products
-// (NVSM_GEMM_SPLIT=6, the default) leave out m·l, l·m and l·l, each below 2^-24 of a·b; NVSM_GEMM_SPLIT=9 keeps all nine;
+// (NVSM_GEMM_SPLIT=6, the default) leave out m·l, l·m and l·l, each below 2^-26 of a·b; NVSM_GEMM_SPLIT=9 keeps all nine;
 // 0 switches this kernel off (exact-fp32 MFMA kernels: gemm_tstat / gemm_rows). Measured against an fp64 product (tools/exp/
 // gemm_accuracy.py, M = 51 200, errors relative to Σ|a·b|, operands over 16 binades): exact-fp32 kernels max 1.31e-6 / rms
-// 9.9e-8, nine products 1.06e-6 / 8.2e-8, six products 1.11e-6 / 8.4e-8 — the bf16 pipe's wider internal sum makes both
-// forms slightly MORE accurate than the k-ordered fp32 chain. tests/test_gpu_parity.py asserts that relation.
+// 9.9e-8, nine products 0.94e-6 / 7.56e-8, six products 0.94e-6 / 7.56e-8 (the two agree to four digits) — the bf16 pipe's
+// wider internal sum makes both forms slightly MORE accurate than the k-ordered fp32 chain. tests/test_gpu_parity.py
+// asserts that relation.
 //
 // Shape of the work: M = batch is huge (51 200), N and K are a few hundred. One workgroup (eight waves, two per SIMD, 256
 // registers each: the compiler keeps everything in arch VGPRs — a 512-register, one-wave-per-SIMD form of the same loop
@@ -99,13 +101,18 @@ constexpr int kSplitEpiStats = 1, kSplitEpiRowsq = 2, kSplitEpiBias = 4;
 
 // x0, x1 -> one 32-bit word per plane, x0's piece in the lower half (element 2j of a fragment), x1's in the upper
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
-    h = (b0 >> 16) | (b1 & 0xffff0000u);
-    const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);      // exact
-    const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
-    m = (c0 >> 16) | (c1 & 0xffff0000u);
-    const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);      // exact, <= 8 bits left
-    l = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+    // round-to-nearest pieces (v_cvt_pk_bf16_f32: two elements per instruction): h = bf16(x), m = bf16(x - h), l = x - h - m.
+    // Both differences are exact in fp32 and the last one has at most eight significant bits, so x = h + m + l exactly;
+    // the pieces are at most half an ulp of the piece above them (a cut by truncation leaves up to a whole one, all of x's
+    // sign): the partial products a six-product run leaves out are below 2^-26 of a·b and of either sign.
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {x0, x1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t r = v - f32x2_t{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+    const f32x2_t s2 = r - f32x2_t{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(s2, bf16x2_t));
 }
 
 struct SplitFrag { u32x4 h, m, l; };

@@ -589,6 +589,7 @@ void Model::initialize_from_rng_state() {
     glorot(words_.P, cfg_.word_repr_size, cfg_.num_words);
     glorot(ents_.P, cfg_.entity_repr_size, cfg_.num_entities);
     glorot(T_, cfg_.entity_repr_size, cfg_.word_repr_size);
+    split_fwd_.ready = split_bwd_.ready = false;      // (T rewritten: its bf16 planes are stale)
     NVSM_HIP_CHECK(hipMemset(b_.p, 0, b_.n * sizeof(float)));                                   // params.cu:368-369
     NVSM_HIP_CHECK(hipStreamSynchronize(nullptr));      // (queued on the null stream, which the handle's streams do not wait for)
 }

@@ -349,6 +349,35 @@ def test_forward_backward_parity(name, B):
     assert rel_err(g.get_tensor("multipliers"), o.get("multipliers") * sign) < GRAD_TOL
 
 
+def test_split_kernels_follow_a_rewritten_projection():
+    """The split-bf16 projection kernels read T as bf16 planes that are cut when T changes (behind the projection update,
+    off the critical path): anything else that writes T — set_param, initialize — must leave them stale-marked. A handle
+    that has trained, then has its parameters replaced, must compute exactly what a fresh handle with those parameters does."""
+    spec = SPECS["nvsm"]
+    B = 8300
+    rs = np.random.RandomState(3)
+    words, ww, labels, iw, ids = random_batch(spec, rs, B, zipf=True)
+    batch = ca.Batch(words, labels, ww, iw)
+    used = gpu_model(spec, B)
+    load_params(used, random_params(spec, rs), True)
+    for _ in range(2):
+        used.step(batch, 0.05, entity_ids=ids)                 # the planes now hold the trained projection
+    params = random_params(spec, rs)
+    fresh = gpu_model(spec, B)
+    for m in (used, fresh):
+        load_params(m, params, True)                           # set_param
+        m.compute_cost(batch, ids)
+        m.compute_gradients()
+    for t in ("pre", "grad_phrase", "grad_transform"):
+        np.testing.assert_array_equal(used.get_tensor(t), fresh.get_tensor(t))
+    used.step(batch, 0.05, entity_ids=ids)
+    used.initialize(9)                                         # initialize
+    fresh.initialize(9)
+    for m in (used, fresh):
+        m.compute_cost(batch, ids)
+    np.testing.assert_array_equal(used.get_tensor("pre"), fresh.get_tensor("pre"))
+
+
 @pytest.mark.parametrize("method", ["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
 @pytest.mark.parametrize("name", ["nvsm", "tiny", "lse", "tiny_odd", "k4_window1", "many_negatives", "sparse_touch", "sparse_touch_odd",
                                   "l2_phrase", "l2_entity", "l2_both"])

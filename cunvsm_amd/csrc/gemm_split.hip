@@ -117,15 +117,6 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
 
 struct SplitFrag { u32x4 h, m, l; };
 
-__device__ __forceinline__ void split8(const float (&x)[8], SplitFrag& f) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        unsigned h, m, l;
-        split_pair(x[2 * j], x[2 * j + 1], h, m, l);
-        f.h[j] = h; f.m[j] = m; f.l[j] = l;
-    }
-}
-
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -139,7 +130,6 @@ __device__ __forceinline__ float split_row16_sum(float v) {
     return v;
 }
 
-// Eight waves of at most CBW column blocks each, RBP row blocks per pass (the accumulators: 4 RBP CBW registers);
 // The K loop is branch-free and issues the same loads in the same order every turn (past the last tile: harmless repeats of
 // the last one), so that the compiler's wait-count bookkeeping comes out exact: vmcnt(NLD - 1 + NB) where a chunk of A is
 // cut, vmcnt(NLD) where the planes of B are taken over. With the loads under `if (kt + 1 < KT)` it merged the branches'

@@ -228,11 +228,12 @@ constexpr int kFan = 64;      // level-1 partials per level-2 chunk
 
 // bounds + long-row chunk list, from sorted_key; counters_cleared: row_begin | row_end | num_chunks | num_touched (one
 // allocation of csr_counter_ints(rows) ints) are already zero (sort_pairs cleared them), otherwise a memset does it
-void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared = false);
+// order_key (optional, [max_chunks], with Csr::chunk_order): the chunk fill also writes the keys of launch_chunk_order (keys_written)
+void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared = false, int* order_key = nullptr);
 // Csr::chunk_order: the level-1 chunks by where in the batch their entries start (512 buckets; update.hip table_pass_kernel
 // gives each XCD one eighth of the batch so that the chunks of different hot rows over the same windows share an L2).
 // key_in / key_out: [max_chunks] scratch; sort_temp: a sort_pairs workspace for max_chunks pairs
-void launch_chunk_order(const Csr& c, int* key_in, int* key_out, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
+void launch_chunk_order(const Csr& c, int* key_in, int* key_out, void* sort_temp, size_t sort_temp_bytes, hipStream_t s, bool keys_written = false);
 inline int64_t csr_counter_ints(int64_t rows) { return (2 * rows + 3 + 63) / 64 * 64; }
 bool row_pass_split(const Csr& c);                    // rows · ratio >= entries: touched-row list + streaming pass over the rest
 double table_split_ratio();                           // that ratio (2 unless NVSM_SPLIT_RATIO says otherwise)

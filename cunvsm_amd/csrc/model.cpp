@@ -1306,8 +1306,8 @@ void Model::build_csr(TableState& t, const int* keys, int64_t n, hipStream_t s) 
     // (the sort's first launch also clears the CSR's per-step counters: no memset launch)
     sort_pairs(t.sort_temp.p, t.sort_temp_bytes, &t.sort_epoch, keys, x.sorted_key.p, nullptr, x.sorted_entry.p, n, t.sort_bits, err_host_, s,
                x.csr_zeroed.p, csr_counter_ints(t.rows));
-    launch_csr_build(csr_of(t, n), s, n > 0);
-    if (x.chunk_order.p) launch_chunk_order(csr_of(t, n), t.chunk_key.p, t.chunk_key_sorted.p, t.sort_temp.p, t.sort_temp_bytes, s);
+    launch_csr_build(csr_of(t, n), s, n > 0, x.chunk_order.p ? t.chunk_key.p : nullptr);
+    if (x.chunk_order.p) launch_chunk_order(csr_of(t, n), t.chunk_key.p, t.chunk_key_sorted.p, t.sort_temp.p, t.sort_temp_bytes, s, /*keys_written=*/n > 0);
 }
 
 static void fill_adam_consts(RowPassArgs& a, float bc, float sl);

@@ -67,10 +67,17 @@ __global__ void csr_chunks_kernel(const int* __restrict__ row_begin, const int* 
 __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, const int* __restrict__ row_begin,
                                       const int* __restrict__ row_end, const int* __restrict__ chunk_base,
                                       const int* __restrict__ chunk2_base, int* __restrict__ chunk_desc,
-                                      int* __restrict__ chunk2_desc, int max_chunks, int max_chunks2, const int* __restrict__ num_chunks) {
+                                      int* __restrict__ chunk2_desc, int max_chunks, int max_chunks2, const int* __restrict__ num_chunks,
+                                      const int* __restrict__ sorted_entry, int* __restrict__ order_key) {
     // no row of more than kChunk entries this step (the documents table, most steps): nothing to describe — the kernel would
     // otherwise read three words per entry to find that out (27 us next to the loss kernel for 870 k entries)
     if (num_chunks[0] == 0) return;
+    // the key of the chunks' batch order (launch_chunk_order) is written on the way: the entry that opens a chunk knows the
+    // chunk's first entry; slots behind the chunks in use sort last (one launch less per build)
+    if (order_key) {
+        const int nchunks = min(num_chunks[0], max_chunks);
+        for (int ci = nchunks + blockIdx.x * blockDim.x + threadIdx.x; ci < max_chunks; ci += gridDim.x * blockDim.x) order_key[ci] = 511;
+    }
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int r = key[i];
@@ -85,6 +92,10 @@ __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, co
             chunk_desc[(base + c) * 3 + 0] = r;
             chunk_desc[(base + c) * 3 + 1] = static_cast<int>(i);
             chunk_desc[(base + c) * 3 + 2] = min(e, static_cast<int>(i) + kChunk);
+            if (order_key) {
+                const uint64_t first = static_cast<uint32_t>(sorted_entry[i]);
+                order_key[base + c] = static_cast<int>(min<uint64_t>(511, first * 512 / static_cast<uint64_t>(n)));
+            }
         }
         if (nch > kFan && c % kFan == 0) {                // ... and level-2 chunk c / kFan
             const int c2 = c / kFan;
@@ -109,7 +120,7 @@ static int csr_grid(int64_t items, bool sparse_table) {
     return (cap > 0 && g > cap) ? cap : g;
 }
 
-void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared) {
+void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared, int* order_key) {
     // row_begin | row_end | num_chunks | num_touched are one allocation (model.cpp), padded so that one fill kernel does it
     const bool sparse = row_pass_split(c);
     if (!counters_cleared) (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * csr_counter_ints(c.rows), s);
@@ -120,7 +131,8 @@ void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared) {
                        c.chunk_base, c.chunk2_base, c.num_chunks);
     if (c.n > 0)
         hipLaunchKernelGGL(csr_chunk_fill_kernel, dim3(csr_grid(c.n, sparse)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin,
-                           c.row_end, c.chunk_base, c.chunk2_base, c.chunk_desc, c.chunk2_desc, c.max_chunks, c.max_chunks2, c.num_chunks);
+                           c.row_end, c.chunk_base, c.chunk2_base, c.chunk_desc, c.chunk2_desc, c.max_chunks, c.max_chunks2, c.num_chunks,
+                           c.sorted_entry, c.chunk_order ? order_key : nullptr);
 }
 
 // =============================================================================================
@@ -1081,9 +1093,9 @@ __global__ void chunk_order_key_kernel(Csr c, int* __restrict__ key) {
         key[ci] = k;
     }
 }
-void launch_chunk_order(const Csr& c, int* key_in, int* key_out, void* sort_temp, size_t sort_temp_bytes, hipStream_t s) {
+void launch_chunk_order(const Csr& c, int* key_in, int* key_out, void* sort_temp, size_t sort_temp_bytes, hipStream_t s, bool keys_written) {
     if (!c.chunk_order || c.n <= 0 || c.max_chunks <= 0) return;
-    hipLaunchKernelGGL(chunk_order_key_kernel, dim3(stream_grid(c.max_chunks, 256)), dim3(256), 0, s, c, key_in);
+    if (!keys_written) hipLaunchKernelGGL(chunk_order_key_kernel, dim3(stream_grid(c.max_chunks, 256)), dim3(256), 0, s, c, key_in);
     sort_pairs(sort_temp, sort_temp_bytes, nullptr, key_in, key_out, nullptr, c.chunk_order, c.max_chunks, 9, nullptr, s, nullptr, 0, c.num_chunks);
 }
 

@@ -133,8 +133,10 @@ def test_out_of_range_ids_are_reported_not_dereferenced(sampler, what, bad):
         words[17] = bad
     else:
         labels[9] = bad
-    m.compute_cost(ca.Batch(words, labels, ww, iw))
+    # (the error surfaces at the next synchronisation point: get_cost — or compute_cost itself under NVSM_DEBUG=1, which
+    #  synchronises after every call)
     with pytest.raises(ca.NvsmError) as e:
+        m.compute_cost(ca.Batch(words, labels, ww, iw))
         m.get_cost()
     assert e.value.status == 1 and ("word id" if what == "word" else "document id") in str(e.value)
     # the handle stays usable, the error is reported once, and the tables were not corrupted
@@ -155,8 +157,8 @@ def test_out_of_range_explicit_entity_ids_and_fused_step():
     words, ww, labels, iw, ids = random_batch(spec, rs, B)
     ids = ids.copy()
     ids[7] = 100
-    t = m.step_deferred(ca.Batch(words, labels, ww, iw), 1e-3, entity_ids=ids)
-    with pytest.raises(ca.NvsmError) as e:
+    with pytest.raises(ca.NvsmError) as e:            # at the cost read, or at the step itself under NVSM_DEBUG=1
+        t = m.step_deferred(ca.Batch(words, labels, ww, iw), 1e-3, entity_ids=ids)
         m.deferred_cost(t)
     assert e.value.status == 1
     m.synchronize()                                   # reported once

@@ -35,7 +35,8 @@ class NvsmConfig(C.Structure):
         ("update_method", C.c_int32), ("adam_mode", C.c_int32), ("max_batch_size", C.c_int32),
         ("device", C.c_int32), ("sampler", C.c_int32),
         ("world_size", C.c_int32), ("rank", C.c_int32), ("sync_batch_norm", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("dp_exact_tables", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 

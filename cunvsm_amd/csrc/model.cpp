@@ -21,10 +21,11 @@ struct RcclApi {
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;      // (send, recv, count per rank, type, comm, stream)
     int (*CommDestroy)(void*) = nullptr;
     int (*CommCount)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
-    static constexpr int kFloat32 = 7, kFloat64 = 8, kSum = 0;   // ncclFloat32, ncclFloat64, ncclSum
+    static constexpr int kInt8 = 0, kFloat32 = 7, kFloat64 = 8, kSum = 0;   // ncclInt8, ncclFloat32, ncclFloat64, ncclSum
 
     static RcclApi* load() {
         static RcclApi api;
@@ -43,6 +44,7 @@ struct RcclApi {
         api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
         api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.handle, "ncclCommCount"));
@@ -85,9 +87,18 @@ void rccl_selftest(int device) {
     NVSM_HIP_CHECK(hipEventRecord(e2, s2));
     NVSM_HIP_CHECK(hipStreamWaitEvent(s, e2, 0));
     if (rc == 0) rc = api->AllReduce(d.p, d.p, n, RcclApi::kFloat64, RcclApi::kSum, comm, s);
+    // the byte all-gather of the exact-tables mode: one rank's gather is a copy
+    DevBuf<float> g;
+    g.alloc(n);
+    if (rc == 0 && api->AllGather) rc = api->AllGather(f.p, g.p, n * sizeof(float), RcclApi::kInt8, comm, s);
     NVSM_HIP_CHECK(hipStreamSynchronize(s));
     NVSM_HIP_CHECK(hipStreamSynchronize(s2));
     (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipStreamDestroy(s2);
+    if (rc == 0 && api->AllGather) {
+        std::vector<float> rg(n);
+        NVSM_HIP_CHECK(hipMemcpy(rg.data(), g.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (rg != hf) { api->CommDestroy(comm); (void)hipStreamDestroy(s); throw Error(NVSM_ERR_DEVICE, "1-rank all-gather did not return its input"); }
+    }
     std::vector<float> rf(n); std::vector<double> rd(n);
     NVSM_HIP_CHECK(hipMemcpy(rf.data(), f.p, n * sizeof(float), hipMemcpyDeviceToHost));
     NVSM_HIP_CHECK(hipMemcpy(rd.data(), d.p, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -382,6 +393,11 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     if (B * std::max<int64_t>(cfg.word_repr_size, cfg.entity_repr_size) >= (int64_t(1) << 32) ||
         B * R_ * cfg.entity_repr_size >= (int64_t(1) << 40))
         bad("max_batch_size too large for 32-bit work indexing");
+    exact_ = cfg.dp_exact_tables != 0 && cfg.world_size > 1;
+    const int64_t Bu = exact_ ? B * cfg.world_size : B;      // windows per table update
+    if (exact_ && (Bu * std::max<int64_t>(cfg.window_size, R_) >= (int64_t(1) << 26) ||
+                   Bu * std::max<int64_t>(cfg.word_repr_size, cfg.entity_repr_size) >= (int64_t(1) << 32)))
+        bad("dp_exact_tables: world_size x max_batch_size exceeds the limits of a single batch");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -426,12 +442,13 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     *err_host_ = 0;
     { const char* d = std::getenv("NVSM_DEBUG"); debug_ = d && d[0] && d[0] != '0'; }
     { const char* d = std::getenv("NVSM_DP_T_ON_MAIN"); dp_single_stream_ = d && d[0] && d[0] != '0'; }
+    if (exact_) dp_single_stream_ = true;      // (every collective of that mode is issued on the main stream)
 
     const int dw = cfg.word_repr_size, de = cfg.entity_repr_size, w = cfg.window_size;
     const int64_t N = B * R_;
-    alloc_table(words_, cfg.num_words, dw, B * w);
+    alloc_table(words_, cfg.num_words, dw, Bu * w);
     ents_.idx_sets = 2;
-    alloc_table(ents_, cfg.num_entities, de, N);
+    alloc_table(ents_, cfg.num_entities, de, Bu * R_);
     T_.alloc(static_cast<size_t>(de) * dw, true); b_.alloc(de, true);
     if (cfg.update_method != NVSM_SGD) { s0T_.alloc(static_cast<size_t>(de) * dw, true); s0b_.alloc(de, true); }
     if (cfg.update_method == NVSM_ADAM) { s1T_.alloc(static_cast<size_t>(de) * dw, true); s1b_.alloc(de, true); }
@@ -444,10 +461,15 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     widx_.alloc(B * w); ids_buf_[0].alloc(N); ids_buf_[1].alloc(N); ids_p_ = ids_buf_[0].p;
     phrase_.alloc(B * dw); phrase_alt_.alloc(B * dw); phrase_p_ = phrase_.p; pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
     if (cfg.l2_normalize_phrase_reprs) { phrase_raw_.alloc(B * dw); phrase_norms_.alloc(B); }
-    if (cfg.l2_normalize_entity_reprs) { grad_entity_.alloc(N * de); ge_msq_.alloc(N); }
+    if (cfg.l2_normalize_entity_reprs) { grad_entity_.alloc(Bu * R_ * de); ge_msq_.alloc(Bu * R_); }
     coef_.alloc(N); probs_.alloc(N); pp_.alloc(B); msq_w_.alloc(B); msq_parts_.alloc(B * gemm_rowsq_parts(dw));
-    if (cfg.update_method == NVSM_ADAM && cfg.adam_mode <= NVSM_ADAM_SPARSE) U_.alloc(B * dw);
-    if (cfg.update_method == NVSM_ADAGRAD) scale_w_.alloc(B);
+    if (cfg.update_method == NVSM_ADAM && cfg.adam_mode <= NVSM_ADAM_SPARSE) U_.alloc(Bu * dw);
+    if (cfg.update_method == NVSM_ADAGRAD) scale_w_.alloc(Bu);
+    if (exact_) {
+        xg_ids_[0].alloc(Bu * R_); xg_ids_[1].alloc(Bu * R_); xg_ids_p_ = xg_ids_[0].p;
+        xg_widx_.alloc(Bu * w); xg_wwts_.alloc(Bu * w);
+        xg_proj_.alloc(Bu * de); xg_coef_.alloc(Bu * R_); xg_pp_.alloc(Bu); xg_gphrase_.alloc(Bu * dw); xg_msq_w_.alloc(Bu);
+    }
     stats_.alloc(4 * de + 1, true); stats_fwd_ = stats_.p; stats_bwd_ = stats_.p + 2 * de;
     {
         // projection GEMM: one column group per column part (LDS-stationary kernel: <= 4, a workgroup per CU) or per 128-column
@@ -608,6 +630,7 @@ void Model::comm_init(const char id[128]) {
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
     const int rc = rccl_->CommInitRank(&comm_, cfg_.world_size, u, cfg_.rank);
     if (rc != 0) throw Error(NVSM_ERR_DEVICE, std::string("ncclCommInitRank: ") + (rccl_->GetErrorString ? rccl_->GetErrorString(rc) : "error"));
+    if (exact_ && !rccl_->AllGather) throw Error(NVSM_ERR_DEVICE, "librccl lacks ncclAllGather (dp_exact_tables)");
     comm_ranks_ = cfg_.world_size;
     if (rccl_->CommCount) { int n = 0; if (rccl_->CommCount(comm_, &n) == 0) comm_ranks_ = n; }
     // The step issues its collectives on ONE communicator from two streams ordered by events (never two in flight). Before
@@ -672,7 +695,7 @@ bool Model::comm_order_check(bool two_streams) {
 // averaging; the optimiser state stays rank-local) — a collective every rank must call; the trainer calls it before each
 // model dump and at the end of every epoch so that what rank 0 writes carries all ranks' updates.
 void Model::average_tables() {
-    if (cfg_.world_size <= 1) return;
+    if (cfg_.world_size <= 1 || exact_) return;      // (exact tables: the replicas are bit-identical already)
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
     synchronize();
     lazy_flush_all();
@@ -722,6 +745,51 @@ void Model::allreduce_f32(float* dev, int64_t n, hipStream_t strm) {
     } else {
         throw Error(NVSM_ERR_STATE, "world_size > 1 but neither nvsm_comm_init nor an all-reduce callback was set");
     }
+}
+
+// `bytes` from every rank, rank-major (dp_exact_tables). RCCL: one ncclAllGather of bytes. Callback transport (tests): the
+// callback can only sum doubles, so every rank lays its 32-bit words into its own slot of a zeroed buffer — a sum with one
+// non-zero term per element, exact in a double.
+void Model::allgather(const void* send, void* recv, size_t bytes, hipStream_t strm) {
+    const size_t G = static_cast<size_t>(cfg_.world_size);
+    if (comm_ && !ar_fn_) {
+        const int rc = rccl_->AllGather(send, recv, bytes, RcclApi::kInt8, comm_, strm);
+        if (rc != 0) throw Error(NVSM_ERR_DEVICE, "ncclAllGather failed");
+    } else if (ar_fn_) {
+        if (bytes % 4 != 0) throw Error(NVSM_ERR_INVALID_ARGUMENT, "all-gather of a size that is not a multiple of 4 bytes");
+        const size_t n = bytes / 4;
+        std::vector<uint32_t> h(n), all(G * n);
+        NVSM_HIP_CHECK(hipMemcpyAsync(h.data(), send, bytes, hipMemcpyDeviceToHost, strm));
+        NVSM_HIP_CHECK(hipStreamSynchronize(strm));
+        ar_host_.assign(G * n, 0.0);
+        for (size_t i = 0; i < n; ++i) ar_host_[static_cast<size_t>(cfg_.rank) * n + i] = static_cast<double>(h[i]);
+        if (ar_fn_(ar_host_.data(), static_cast<int64_t>(G * n), ar_user_) != 0) throw Error(NVSM_ERR_DEVICE, "all-reduce callback failed");
+        for (size_t i = 0; i < G * n; ++i) all[i] = static_cast<uint32_t>(ar_host_[i]);
+        NVSM_HIP_CHECK(hipMemcpyAsync(recv, all.data(), G * bytes, hipMemcpyHostToDevice, strm));
+        NVSM_HIP_CHECK(hipStreamSynchronize(strm));
+    } else {
+        throw Error(NVSM_ERR_STATE, "world_size > 1 but neither nvsm_comm_init nor an all-reduce callback was set");
+    }
+}
+
+// exact tables: what the loss kernel and the backward product left for the table passes, from every rank (main stream, in
+// front of the passes). The ids were gathered by compute_cost, for the CSR builds.
+void Model::gather_update_inputs() {
+    if (!exact_) return;
+    PROF("allgather_update_inputs");
+    const int64_t B = B_;
+    const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size;
+    allgather(proj_.p, xg_proj_.p, B * de * sizeof(float), stream_);
+    allgather(coef_.p, xg_coef_.p, B * R_ * sizeof(float), stream_);
+    allgather(pp_.p, xg_pp_.p, B * sizeof(float), stream_);
+    allgather(gphrase_.p, xg_gphrase_.p, B * dw * sizeof(float), stream_);
+    allgather(msq_w_.p, xg_msq_w_.p, B * sizeof(float), stream_);
+}
+
+Model::UpdateInputs Model::update_inputs() const {
+    if (!exact_) return UpdateInputs{proj_.p, coef_.p, pp_.p, ids_p_, gphrase_.p, wwts_, msq_w_.p, widx_.p, B_};
+    return UpdateInputs{xg_proj_.p, xg_coef_.p, xg_pp_.p, xg_ids_p_, xg_gphrase_.p, wwts_ ? xg_wwts_.p : nullptr, xg_msq_w_.p,
+                        xg_widx_.p, B_ * cfg_.world_size};
 }
 
 // UniformLabelGenerator::generate (cpp/labels.cu:4-22) → generate_random_indexes (include/cuNVSM/cuda_utils.h:24-33): slot 0 of
@@ -911,10 +979,22 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         }
     }
     ++step_count_;
+    if (exact_) {
+        // exact tables: the CSRs are those of the global batch — every rank's ids, rank-major (the gathered document ids
+        // alternate between two buffers for the reason the rank's own do)
+        PROF("allgather_ids");
+        xg_ids_p_ = (xg_ids_p_ == xg_ids_[0].p) ? xg_ids_[1].p : xg_ids_[0].p;
+        allgather(ids_p_, xg_ids_p_, N * sizeof(int), stream_);
+        allgather(widx_.p, xg_widx_.p, B * w * sizeof(int), stream_);
+        if (wwts_) allgather(wwts_, xg_wwts_.p, B * w * sizeof(float), stream_);
+    }
+    const int64_t Bu = exact_ ? B * cfg_.world_size : B;          // windows of the table updates
+    const int* csr_ids = exact_ ? xg_ids_p_ : ids_p_;
+    const int* csr_widx = exact_ ? xg_widx_.p : widx_.p;
 
     // Row-order (CSR) of both tables for the update, on the side streams: needs only the indices.
     static const int csr_after = [] { const char* e = std::getenv("NVSM_CSR_AFTER"); return e ? std::atoi(e) : 0; }();
-    if (!fused_prologue) NVSM_HIP_CHECK(hipEventRecord(ev_inputs_, stream_));
+    if (!fused_prologue || exact_) NVSM_HIP_CHECK(hipEventRecord(ev_inputs_, stream_));
     inputs_recorded_ = true;
     // two side streams: the sorts are latency-bound chains of small launches, so the two tables' builds run next to
     // each other (at batch 4096 one behind the other they were the longest chain of the whole step)
@@ -942,8 +1022,8 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         if ((which & 1) && se != aux_stream_ && E_pending_ && ents_.idx_sets < 2) NVSM_HIP_CHECK(hipStreamWaitEvent(se, ev_E_done_, 0));
         if (which & 1) csr_joined_ents_ = false;
         if (which & 2) { csr_joined_words_ = false; words_csr_stream_ = sw; }
-        auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, ids_p_, N, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
-        auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, widx_.p, B * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
+        auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, csr_ids, Bu * R_, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
+        auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, csr_widx, Bu * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
         if (layout == 1) { if (which & 2) wrds(); if (which & 1) ents(); } else { if (which & 1) ents(); if (which & 2) wrds(); }
         if ((which & 1) && se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
     };
@@ -1039,7 +1119,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
                 // the generic loss kernel (odd dimensions, entity normaliser) reads the rows as they are: the documents of
                 // this batch (the touched list of their CSR) are brought up to date first, behind the sort
                 NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));
-                Csr ce = csr_of(ents_, N);
+                Csr ce = csr_of(ents_, Bu * R_);
                 lazy_refresh(ents_, &ce, stream_);
             }
         }
@@ -1400,12 +1480,13 @@ static void fill_adam_consts(RowPassArgs& a, float bc, float sl) {
 }
 
 void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row_pass_after) {
-    const int64_t N = B_ * R_;
+    const UpdateInputs u = update_inputs();
+    const int64_t N = u.B * R_;
     const int de = cfg_.entity_repr_size;
     TableState& t = ents_;
     Csr c = csr_of(t, N);
     RowPassArgs a{};
-    a.table = 1; a.X = proj_.p; a.coefs = coef_.p; a.sq_src = pp_.p; a.div = static_cast<uint32_t>(R_);
+    a.table = 1; a.X = u.proj; a.coefs = u.coef; a.sq_src = u.pp; a.div = static_cast<uint32_t>(R_);
     a.div_magic = (uint64_t(1) << 37) / a.div + 1;
     a.P = t.P.p; a.m = t.m.p; a.v = t.vfull.p; a.dim = de;
     a.lr = lr; a.lambda = sl; a.eps = 1e-6f;
@@ -1427,7 +1508,7 @@ void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row
     if (cfg_.l2_normalize_entity_reprs) {
         // optional entity normaliser: the per-entry gradient rows are materialised (as the reference does) and scattered as
         // they are: source row = entry, coefficient 1, per-entry mean of squares
-        launch_materialize_grad_entity_l2(coef_.p, proj_.p, t.P.p, ids_p_, N, R_, de, grad_entity_.p, ge_msq_.p, strm);
+        launch_materialize_grad_entity_l2(u.coef, u.proj, t.P.p, u.ids, N, R_, de, grad_entity_.p, ge_msq_.p, strm);
         a.X = grad_entity_.p; a.coefs = nullptr; a.div = 1; a.div_magic = (uint64_t(1) << 37) + 1;
         if (a.sq_src) a.sq_src = ge_msq_.p;
     }
@@ -1449,11 +1530,12 @@ void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row
 
 void Model::update_words(float lr, float sl) {
     const int dw = cfg_.word_repr_size, w = cfg_.window_size;
-    const int64_t n = B_ * w;
+    const UpdateInputs u = update_inputs();
+    const int64_t n = u.B * w;
     TableState& t = words_;
     Csr c = csr_of(t, n);
     RowPassArgs a{};
-    a.table = 0; a.X = gphrase_.p; a.wts = wwts_; a.div = static_cast<uint32_t>(w);
+    a.table = 0; a.X = u.gphrase; a.wts = u.wwts; a.div = static_cast<uint32_t>(w);
     a.div_magic = (uint64_t(1) << 37) / a.div + 1;
     a.P = t.P.p; a.m = t.m.p; a.v = t.vfull.p; a.dim = dw;
     a.lr = lr; a.lambda = sl; a.eps = 1e-6f;
@@ -1471,10 +1553,10 @@ void Model::update_words(float lr, float sl) {
         RowPassArgs s = a;                                             // accumulator pass (updates_adagrad.cu:136-158)
         // the row's accumulator is read and written by one lane only (no other lane of the row's group looks at it), so
         // it is updated in place: rows without entries keep their value without being visited at all
-        s.kind = ROW_SCALAR_ACC; s.sq_src = msq_w_.p; s.dense = 0;
+        s.kind = ROW_SCALAR_ACC; s.sq_src = u.msq_w; s.dense = 0;
         s.sc_in = t.sc[t.sc_cur].p; s.sc_out = t.sc[t.sc_cur].p;
         { PROF("adagrad_acc_words"); launch_table_pass(c, s, stream_, words_untouched_stream_); }
-        { PROF("adagrad_scale_words"); launch_adagrad_scale(t.sc[t.sc_cur].p, widx_.p, w, B_, 1e-6f, scale_w_.p, stream_); }
+        { PROF("adagrad_scale_words"); launch_adagrad_scale(t.sc[t.sc_cur].p, u.widx, w, u.B, 1e-6f, scale_w_.p, stream_); }
         a.kind = ROW_SGD; a.src_scale = scale_w_.p; a.dense = sl > 0.f;
         lazy_begin_update(t, a, false);
         { PROF("row_pass_words"); launch_table_pass(c, a, stream_, words_untouched_stream_); }
@@ -1489,7 +1571,7 @@ void Model::update_words(float lr, float sl) {
         { PROF("row_pass_words"); launch_table_pass(c, a, stream_, words_untouched_stream_); }
         return;
     }
-    a.sq_src = msq_w_.p; a.dense = 1;     // from the dx GEMM's epilogue
+    a.sq_src = u.msq_w; a.dense = 1;     // from the dx GEMM's epilogue
     a.sc_in = t.sc[t.sc_cur].p; a.sc_out = t.sc[t.sc_cur ^ 1].p;
     if (mode == NVSM_ADAM_DENSE_UPDATE) {
         a.kind = ROW_ADAM_DENSE;
@@ -1506,7 +1588,7 @@ void Model::update_words(float lr, float sl) {
     { PROF("row_pass_words_mv"); path = launch_table_pass(c, a, stream_, words_untouched_stream_); }
     if (path == TABLE_PASS_ENTRY_WALK) prof.note("entry_walk_words");
     if (!t.lazy) t.sc_cur ^= 1;
-    { PROF("adam_u_words"); launch_adam_u(t.m.p, t.sc[t.sc_cur].p, dw, widx_.p, w, B_, a.bc, a.eps, U_.p, stream_); }
+    { PROF("adam_u_words"); launch_adam_u(t.m.p, t.sc[t.sc_cur].p, dw, u.widx, w, u.B, a.bc, a.eps, U_.p, stream_); }
     RowPassArgs r = a;
     r.kind = ROW_SGD; r.X = U_.p; r.sq_src = nullptr; r.dense = sl > 0.f;
     r.nt_m = 0; r.nt_p = (nt_mask() >> 3) & 1;
@@ -1564,6 +1646,7 @@ void Model::update(float lr, float scaled_lambda) {
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_ents_, 0));     // join the side-stream CSR builds
     NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_csr_, 0));
     csr_joined_ents_ = csr_joined_words_ = true;
+    gather_update_inputs();
     update_entities(lr, scaled_lambda, stream_);
     update_words(lr, scaled_lambda);
     update_transform(lr, scaled_lambda, stream_);
@@ -1580,6 +1663,17 @@ void Model::update(float lr, float scaled_lambda) {
 // and the two side-stream tails are joined by the NEXT compute_cost where it needs T and E (join_T / join_E), not here.
 // Results are identical to compute_cost; compute_gradients; update — only the interleaving differs.
 void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, float* cost) {
+    if (exact_) {
+        // exact data-parallel tables: the table passes need every rank's loss-kernel and backward results, gathered on the main
+        // stream — nothing to run next to anything: the three calls in a row
+        compute_cost(batch, entity_ids);
+        const float sl_exact = scaled_regularization_lambda();
+        if (lr < 0.f || sl_exact < 0.f) throw Error(NVSM_ERR_INVALID_ARGUMENT, "learning_rate and lambda must be >= 0");
+        compute_gradients();
+        update(lr, sl_exact);
+        if (cost) *cost = get_cost();
+        return;
+    }
     static const bool fewer_events = [] { const char* e = std::getenv("NVSM_FEWER_EVENTS"); return !(e && e[0] == '0'); }();
     static const int docs_after_dx_env = [] { const char* e = std::getenv("NVSM_DOCS_AFTER_DX"); return e ? std::atoi(e) : -1; }();
     const bool docs_after_dx = docs_after_dx_env >= 0 ? docs_after_dx_env != 0 : batch.num_instances >= 16384;

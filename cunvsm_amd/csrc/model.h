@@ -294,6 +294,21 @@ class Model {
     nvsm_allreduce_fn ar_fn_ = nullptr;
     void* ar_user_ = nullptr;
     std::vector<double> ar_host_;
+
+    // Data parallel with exact tables (nvsm_config.dp_exact_tables): what the table updates read — ids, projected phrases,
+    // multipliers, phrase gradients — of ALL ranks, rank-major, all-gathered on the main stream; the CSR builds and the table
+    // passes then run on world_size x B windows, i.e. every rank performs the single-GPU update of the global batch.
+    bool exact_ = false;
+    struct UpdateInputs {
+        const float* proj; const float* coef; const float* pp; const int* ids; const float* gphrase; const float* wwts;
+        const float* msq_w; const int* widx; int64_t B;
+    };
+    UpdateInputs update_inputs() const;      // the rank's own buffers, or the gathered ones
+    DevBuf<int> xg_ids_[2], xg_widx_;
+    int* xg_ids_p_ = nullptr;                // alternates like ids_p_
+    DevBuf<float> xg_proj_, xg_coef_, xg_pp_, xg_gphrase_, xg_msq_w_, xg_wwts_;
+    void allgather(const void* send, void* recv, size_t bytes, hipStream_t s);      // recv: world_size x bytes, rank-major
+    void gather_update_inputs();
 };
 
 }  // namespace cunvsm

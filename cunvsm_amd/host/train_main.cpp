@@ -45,7 +45,7 @@ double FLAGS_regularization_lambda, FLAGS_learning_rate, FLAGS_max_document_freq
     FLAGS_term_similarity_weight;
 bool FLAGS_bias_negative_samples, FLAGS_l2_phrase_normalization, FLAGS_l2_entity_normalization, FLAGS_batch_normalization,
     FLAGS_include_oov, FLAGS_compute_initial_cost, FLAGS_check_gradients, FLAGS_no_shuffle, FLAGS_dump_initial_model,
-    FLAGS_allow_ragged_batches, FLAGS_logtostderr, FLAGS_alsologtostderr;
+    FLAGS_allow_ragged_batches, FLAGS_logtostderr, FLAGS_alsologtostderr, FLAGS_dp_exact_tables;
 int64_t FLAGS_dump_every, FLAGS_v, FLAGS_device, FLAGS_minloglevel, FLAGS_gpus, FLAGS_world_size, FLAGS_rank;
 std::string FLAGS_comm_id_file, FLAGS_comm_nonce;
 
@@ -91,6 +91,10 @@ void define_flags(Flags* f) {      // names, defaults and help strings of cpp/ma
                     "0..N-1). Every global batch of --batch_size windows is split into N contiguous slices; the projection / bias / batch-norm "
                     "gradients are all-reduced over RCCL each step, the embedding tables are updated rank-locally and averaged over the ranks at the "
                     "end of every epoch and before every model dump (rank 0 writes the outputs).");
+    f->define_bool("dp_exact_tables", &FLAGS_dp_exact_tables, false, "Data parallel: every rank applies the embedding updates of ALL ranks' windows "
+                   "(an all-gather of the update's inputs per step): the replicas stay identical and follow the single-GPU run on the "
+                   "whole batch, at the table-update cost of the whole batch on every rank. Default: rank-local updates, averaged at "
+                   "epoch ends and before dumps.");
     f->define_int64("world_size", &FLAGS_world_size, 0, "Data-parallel ranks when an external launcher starts them (default: WORLD_SIZE, else 1).");
     f->define_int64("rank", &FLAGS_rank, -1, "This process's rank (default: RANK, else 0).");
     f->define_string("comm_id_file", &FLAGS_comm_id_file, "", "File through which rank 0 hands the RCCL unique id to the other ranks "
@@ -536,6 +540,7 @@ int run(int argc, char** argv) {
     cfg.update_method = tc.update_method; cfg.adam_mode = tc.adam_mode;
     cfg.max_batch_size = static_cast<int32_t>(tc.batch_size / static_cast<uint64_t>(world_size));      // this rank's slice
     cfg.world_size = world_size; cfg.rank = rank; cfg.sync_batch_norm = 1;
+    cfg.dp_exact_tables = (world_size > 1 && FLAGS_dp_exact_tables) ? 1 : 0;
     cfg.device = static_cast<int32_t>(FLAGS_device);
     cfg.sampler = FLAGS_sampler == "host" ? NVSM_SAMPLER_HOST_MINSTD : NVSM_SAMPLER_DEVICE;
     nvsm_model* model = nullptr;

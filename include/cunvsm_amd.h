@@ -78,7 +78,11 @@ typedef struct {
     int32_t world_size;
     int32_t rank;
     int32_t sync_batch_norm;           /* 1: global batch statistics (exact single-GPU maths); 0: per-shard */
-    int32_t reserved[5];
+    int32_t dp_exact_tables;           /* world_size > 1 — 0: embedding tables are updated from the rank's own windows (replicas drift);
+                                          1: every rank applies the sparse gradients of ALL ranks' windows (all-gather of the update's
+                                          inputs in front of the table passes): replicas stay bit-identical and follow the single-GPU
+                                          trajectory on the global batch, at world_size x the table-update work per rank (see below) */
+    int32_t reserved[4];
 } nvsm_config;
 
 /* Fills the reference CLI defaults (cpp/main.cu:15-76,637-721; scripts/functions.sh:380-399). */
@@ -210,6 +214,14 @@ int nvsm_synchronize(nvsm_model* m);
  * nvsm_dp_average_tables replaces every replica's tables by their mean over the ranks; cuNVSMTrainModel calls it at the
  * end of every epoch and before every model dump, so that what rank 0 writes carries every rank's updates. A caller
  * that checkpoints one rank without it drops the other ranks' embedding updates.
+ * EXACT TABLES (nvsm_config.dp_exact_tables = 1): the window ids, document ids, projected phrases, multipliers and phrase
+ * gradients of every rank are all-gathered (ncclAllGather on the main stream, 2 x B x (d_e + d_w) floats per rank and step)
+ * and every rank runs the table updates of the whole global batch in rank order — exactly the single-GPU update on the
+ * concatenated batch, so the tables of all ranks are bit-identical after every step and equal the single-GPU tables up to the
+ * summation order of the all-reduced dense statistics. Every rank must pass the same num_instances and agree on whether
+ * feature_weights is NULL. The step's collectives all run on the main stream in this mode, the table passes are not
+ * overlapped with the backward products, and nvsm_dp_average_tables has nothing to do (it returns at once). The update work
+ * per rank is that of the global batch: the mode buys the single-GPU trajectory, not update throughput.
  * nvsm_get_cost with world_size > 1 is a collective when called before nvsm_compute_gradients (it all-reduces a copy of
  * the loss word); every rank must make the same sequence of calls.
  * NEGATIVES with world_size > 1: rank r is taken to hold instances [r·B, (r+1)·B) of a global batch of world_size·B.

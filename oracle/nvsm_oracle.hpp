@@ -543,6 +543,21 @@ struct Model {
     // data-parallel test hooks: world size and an in-place cross-rank sum
     size_t world = 1;
     AllReduce allreduce;
+    // exact data-parallel tables (test hook): every rank applies the sparse gradients of ALL ranks' windows, in rank order —
+    // the update of the single process on the global batch. -1 = off (tables are updated from the rank's own windows).
+    int exact_rank = -1;
+
+    // all-gather through the cross-rank sum: every rank contributes its slice at its own offset of a zeroed buffer
+    // (float, double and ids below 2^53 pass through a double unchanged)
+    template <typename T>
+    std::vector<T> all_gather(const T* p, size_t n) const {
+        std::vector<double> t(n * world, 0.0);
+        for (size_t i = 0; i < n; ++i) t[static_cast<size_t>(exact_rank) * n + i] = static_cast<double>(p[i]);
+        allreduce(t.data(), t.size());
+        std::vector<T> out(t.size());
+        for (size_t i = 0; i < t.size(); ++i) out[i] = static_cast<T>(t[i]);
+        return out;
+    }
 
     explicit Model(const Config& c) : cfg(c),
         words(c.num_words, c.word_dim), entities(c.num_entities, c.entity_dim),
@@ -779,6 +794,22 @@ struct Model {
     void update(F lr, F scaled_lambda) {
         const ForwardResult<F>& f = fwd;
         const size_t N = f.B * f.R;
+        if (world > 1 && allreduce && exact_rank >= 0) {
+            // the global batch's sparse gradients on every rank (the multipliers already carry 1 / B_global)
+            std::vector<F> ge_all = all_gather(grads.grad_entity.data(), grads.grad_entity.size());
+            std::vector<idx_t> ids_all = all_gather(f.entity_ids.data(), N);
+            std::vector<F> gp_all = all_gather(grads.grad_phrase.data(), grads.grad_phrase.size());
+            std::vector<idx_t> words_all = all_gather(f.words.data(), f.words.size());
+            std::vector<F> ww_all = all_gather(f.word_weights.data(), f.word_weights.size());
+            std::vector<SparseGrad<F>> ge{{ge_all.data(), N * world, static_cast<size_t>(cfg.entity_dim), ids_all.data(), 1,
+                                           static_cast<const F*>(nullptr)}};
+            entities_upd.update(&entities, &ge, lr, scaled_lambda);
+            std::vector<SparseGrad<F>> gw{{gp_all.data(), f.B * world, static_cast<size_t>(cfg.word_dim), words_all.data(), f.window,
+                                           ww_all.data()}};
+            words_upd.update(&words, &gw, lr, scaled_lambda);
+            transform_upd.update(&transform, grads.grad_transform.data(), grads.grad_bias.data(), lr, scaled_lambda);
+            return;
+        }
         std::vector<SparseGrad<F>> ge{{grads.grad_entity.data(), N, static_cast<size_t>(cfg.entity_dim),
                                        f.entity_ids.data(), 1, static_cast<const F*>(nullptr)}};             // intermediate_results.cu:300-308
         entities_upd.update(&entities, &ge, lr, scaled_lambda);

@@ -63,6 +63,7 @@ struct ModelBase {
     virtual double scaled_lambda() = 0;
     virtual int gradcheck(const idx_t*, const double*, const idx_t*, const double*, size_t, double, double, double*, int*) = 0;
     virtual void set_allreduce(int (*fn)(double*, int64_t, void*), void* user, int world) = 0;
+    virtual void set_exact_tables(int rank) = 0;
 };
 
 template <typename F>
@@ -104,6 +105,7 @@ struct ModelImpl : ModelBase {
         if (fn) m.allreduce = [fn, user](double* p, size_t n) { if (fn(p, static_cast<int64_t>(n), user) != 0) throw std::runtime_error("allreduce failed"); };
         else m.allreduce = nullptr;
     }
+    void set_exact_tables(int rank) override { m.exact_rank = rank; }
     void backward() override { m.backward(); }
     void update(double lr, double sl) override { m.update(static_cast<F>(lr), static_cast<F>(sl)); }
     double scaled_lambda() override { return static_cast<double>(m.scaled_regularization_lambda()); }
@@ -297,6 +299,7 @@ int orc_model_update(void* h, double lr, double scaled_lambda) {
 void orc_model_set_allreduce(void* h, int (*fn)(double*, int64_t, void*), void* user, int world) {
     static_cast<ModelBase*>(h)->set_allreduce(fn, user, world);
 }
+void orc_model_set_exact_tables(void* h, int rank) { static_cast<ModelBase*>(h)->set_exact_tables(rank); }
 double orc_model_scaled_lambda(void* h) { return static_cast<ModelBase*>(h)->scaled_lambda(); }
 int orc_model_gradcheck(void* h, const idx_t* words, const double* ww, const idx_t* ids, const double* iw, int64_t B,
                         double eps, double thresh, double* max_rel, int* num_checked) {

@@ -56,7 +56,7 @@ def test_product_package_never_touches_the_oracle():
 
 
 def test_config_struct_matches_header_size():
-    # 2 x int64 + 19 x int32/float + 5 reserved int32 = 16 + 24*4 = 112 bytes
+    # 2 x int64 + 20 x int32/float + 4 reserved int32 = 16 + 24*4 = 112 bytes
     assert C.sizeof(ca.NvsmConfig) == 112
     assert C.sizeof(ca.NvsmBatch) == 48
 

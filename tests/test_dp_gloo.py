@@ -138,7 +138,7 @@ def test_dp_hip_equals_single_gpu(spec, B, tmp_path):
     assert rel_err(np.concatenate([r[0]["gphrase"], r[1]["gphrase"]]), ref.get_tensor("grad_phrase")) < 1e-5
 
 
-def _worker_gpu_step(rank, port, spec, B, out_dir):
+def _worker_gpu_step(rank, port, spec, B, out_dir, exact=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import cunvsm_amd as ca
@@ -147,7 +147,7 @@ def _worker_gpu_step(rank, port, spec, B, out_dir):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
     params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
     w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
-    m = gpu_model(spec, B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0)
+    m = gpu_model(spec, B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0, dp_exact_tables=int(exact))
     load_params(m, params, True)
     m.set_allreduce_callback(dp.torch_allreduce(dist))
     costs = [m.step(ca.Batch(w, wl, wwt, wi), 0.05, entity_ids=wid, want_cost=True)]
@@ -155,7 +155,8 @@ def _worker_gpu_step(rank, port, spec, B, out_dir):
     for _ in range(3):
         m.step(ca.Batch(w, wl, wwt, wi), 0.05, entity_ids=wid)
     np.savez(os.path.join(out_dir, "step_rank%d.npz" % rank), cost=np.array(costs), T1=T_after_1, T=m.get_param("word_entity_mapping-transform"),
-             b=m.get_param("word_entity_mapping-bias"), E=m.get_param("entity_representations-representations"))
+             b=m.get_param("word_entity_mapping-bias"), E=m.get_param("entity_representations-representations"),
+             W=m.get_param("word_representations-representations"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -225,7 +226,7 @@ def _traj_batches(spec):
     return params, batches
 
 
-def _worker_traj(rank, port, spec, out_dir, use_gpu):
+def _worker_traj(rank, port, spec, out_dir, use_gpu, exact=False, lr=None, separate_calls=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from cunvsm_amd import dp
@@ -234,29 +235,38 @@ def _worker_traj(rank, port, spec, out_dir, use_gpu):
     params, batches = _traj_batches(spec)
     if use_gpu:
         import cunvsm_amd as ca
-        m = gpu_model(spec, TRAJ_B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0)
+        m = gpu_model(spec, TRAJ_B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0, dp_exact_tables=int(exact))
         load_params(m, params, True)
         m.set_allreduce_callback(dp.torch_allreduce(dist))
     else:
         m = oracle_model(spec)
         load_params(m, params, False)
         m.set_allreduce(dp.torch_allreduce(dist), WORLD)
+        if exact:
+            m.set_exact_tables(rank)
     costs = []
     for words, ww, labels, iw, ids in batches:
         w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
-        if use_gpu:
-            costs.append(m.step(ca.Batch(w, wl, wwt, wi), TRAJ_LR, entity_ids=wid, want_cost=True))
+        if use_gpu and separate_calls:
+            m.compute_cost(ca.Batch(w, wl, wwt, wi), wid)
+            m.compute_gradients()
+            costs.append(m.get_cost())
+            m.update(lr or TRAJ_LR)
+        elif use_gpu:
+            costs.append(m.step(ca.Batch(w, wl, wwt, wi), lr or TRAJ_LR, entity_ids=wid, want_cost=True))
         else:
             m.forward(w, wwt, wid, wi)
             m.backward()
             costs.append(m.get_cost())
-            m.update(TRAJ_LR)
+            m.update(lr or TRAJ_LR)
     if use_gpu:
-        m.dp_average_tables()
-        E, T = m.get_param("entity_representations-representations"), m.get_param("word_entity_mapping-transform")
+        if not exact:
+            m.dp_average_tables()
+        get = m.get_param
     else:
-        E, T = m.get("entity_representations-representations"), m.get("word_entity_mapping-transform")
-    np.savez(os.path.join(out_dir, "traj_rank%d.npz" % rank), cost=np.array(costs, np.float64), E=E, T=T)
+        get = m.get
+    E, T, W = get("entity_representations-representations"), get("word_entity_mapping-transform"), get("word_representations-representations")
+    np.savez(os.path.join(out_dir, "traj_rank%d.npz" % rank), cost=np.array(costs, np.float64), E=E, T=T, W=W)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -296,6 +306,103 @@ def _single_oracle_trajectory(spec):
         costs.append(o.get_cost())
         o.update(TRAJ_LR)
     return params, costs, o.get("entity_representations-representations"), o.get("word_entity_mapping-transform")
+
+
+# ---------------------------------------------------------------------------------------------
+# exact data-parallel tables (nvsm_config.dp_exact_tables): every rank applies the sparse gradients of ALL ranks' windows —
+# an all-gather of the update's inputs in front of the table passes — so N ranks follow the single-process trajectory on the
+# global batch: same losses, same tables, replicas bit-identical, nothing to average.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("method", ["sgd", "adagrad", "sparse_adam", "full_adam"])
+def test_dp_exact_tables_oracle(tmp_path, method):
+    import torch.multiprocessing as mp
+    from tests.helpers import load_params, oracle_model
+    spec = dict(TRAJ_SPEC, update_method=method)
+    port = _free_port()
+    mp.spawn(_worker_traj, args=(port, spec, str(tmp_path), False, True), nprocs=WORLD, join=True)
+    params, batches = _traj_batches(spec)
+    o = oracle_model(spec)
+    load_params(o, params, False)
+    costs = []
+    for words, ww, labels, iw, ids in batches:
+        o.forward(words, ww, ids, iw)
+        o.backward()
+        costs.append(o.get_cost())
+        o.update(TRAJ_LR)
+    r = [np.load(os.path.join(str(tmp_path), "traj_rank%d.npz" % k)) for k in range(WORLD)]
+    for name in ("E", "W", "T"):
+        np.testing.assert_array_equal(r[0][name], r[1][name])
+    np.testing.assert_allclose(r[0]["cost"], costs, rtol=1e-9)
+    np.testing.assert_allclose(r[0]["E"], o.get("entity_representations-representations"), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(r[0]["W"], o.get("word_representations-representations"), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(r[0]["T"], o.get("word_entity_mapping-transform"), rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_dp_exact_tables_hip_wide(tmp_path):
+    """The metric's dimensions at a per-rank batch above 8 192 rows (split-bf16 projection kernels, the large-batch CSR with
+    its chunk order): four steps on one batch, tables against the single handle on the whole batch."""
+    import torch.multiprocessing as mp
+    import cunvsm_amd as ca
+    from tests.helpers import gpu_model, load_params
+    spec = dict(SPEC_WIDE, update_method="sparse_adam")
+    B = 2 * 8704
+    port = _free_port()
+    mp.spawn(_worker_gpu_step, args=(port, spec, B, str(tmp_path), True), nprocs=WORLD, join=True)
+    params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
+    ref = gpu_model(spec, B)
+    load_params(ref, params, True)
+    for _ in range(4):
+        ref.step(ca.Batch(words, labels, ww, iw), 0.05, entity_ids=ids)
+    r = [np.load(os.path.join(str(tmp_path), "step_rank%d.npz" % k)) for k in range(WORLD)]
+    for name, pname in (("E", "entity_representations-representations"), ("W", "word_representations-representations"),
+                        ("T", "word_entity_mapping-transform")):
+        np.testing.assert_array_equal(r[0][name], r[1][name])
+        single = ref.get_param(pname).astype(np.float64).ravel()
+        moved = np.linalg.norm(single - params[pname].astype(np.float64).ravel())
+        diff = np.linalg.norm(r[0][name].astype(np.float64).ravel() - single)
+        print(name, diff / moved)
+        assert diff <= 2e-2 * moved, (name, diff, moved)      # (Adam divides by |g|: a sign flip of a tiny gradient is a whole step)
+
+
+EXACT_LR = {"sgd": 5.0, "adagrad": 0.5, "sparse_adam": 0.02, "dense_adam": 0.02, "full_adam": 0.02}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,variant", [("sgd", "step"), ("sgd", "calls"), ("adagrad", "step"), ("sparse_adam", "step"),
+                                            ("sparse_adam", "calls"), ("dense_adam", "step"), ("full_adam", "step"),
+                                            ("sparse_adam", "lazy"), ("sgd", "lazy"), ("sparse_adam", "l2_entity")])
+def test_dp_exact_tables_hip(tmp_path, method, variant, monkeypatch):
+    """nvsm_config.dp_exact_tables on two ranks sharing GPU 0 (gloo as the transport): after 20 steps the ranks' tables are
+    bit-identical, and they are the tables of ONE handle stepping through the whole batches — up to the summation order of the
+    all-reduced statistics (measured against how far the parameters moved)."""
+    import torch.multiprocessing as mp
+    import cunvsm_amd as ca
+    from tests.helpers import gpu_model, load_params
+    spec = dict(TRAJ_SPEC, update_method=method)
+    if variant == "lazy":           # lazily decayed tables (rows >= entries of the GLOBAL batch; small tables need the override)
+        spec.update(num_words=6000, num_entities=9000)
+        monkeypatch.setenv("NVSM_LAZY_MIN_MB", "0")
+    if variant == "l2_entity":
+        spec["l2_entity"] = True
+    lr = EXACT_LR[method]
+    port = _free_port()
+    mp.spawn(_worker_traj, args=(port, spec, str(tmp_path), True, True, lr, variant == "calls"), nprocs=WORLD, join=True)
+    params, batches = _traj_batches(spec)
+    ref = gpu_model(spec, TRAJ_B)
+    load_params(ref, params, True)
+    costs = [ref.step(ca.Batch(words, labels, ww, iw), lr, entity_ids=ids, want_cost=True) for words, ww, labels, iw, ids in batches]
+    r = [np.load(os.path.join(str(tmp_path), "traj_rank%d.npz" % k)) for k in range(WORLD)]
+    for name in ("E", "W", "T", "cost"):
+        np.testing.assert_array_equal(r[0][name], r[1][name])
+    np.testing.assert_allclose(r[0]["cost"], costs, rtol=2e-4)
+    for name, pname in (("E", "entity_representations-representations"), ("W", "word_representations-representations"),
+                        ("T", "word_entity_mapping-transform")):
+        single = ref.get_param(pname).astype(np.float64).ravel()
+        moved = np.linalg.norm(single - params[pname].astype(np.float64).ravel())
+        diff = np.linalg.norm(r[0][name].astype(np.float64).ravel() - single)
+        print(method, variant, name, diff / moved)
+        assert diff <= 2e-5 * moved, (name, diff, moved)
 
 
 def test_dp_loss_trajectory_oracle(tmp_path):

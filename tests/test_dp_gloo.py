@@ -244,14 +244,18 @@ def _worker_traj(rank, port, spec, out_dir, use_gpu, exact=False, lr=None, separ
         m.set_allreduce(dp.torch_allreduce(dist), WORLD)
         if exact:
             m.set_exact_tables(rank)
-    costs = []
+    costs, tickets = [], []
     for words, ww, labels, iw, ids in batches:
         w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
-        if use_gpu and separate_calls:
+        if use_gpu and separate_calls is True:
             m.compute_cost(ca.Batch(w, wl, wwt, wi), wid)
             m.compute_gradients()
             costs.append(m.get_cost())
             m.update(lr or TRAJ_LR)
+        elif use_gpu and separate_calls == "deferred":          # the trainer's protocol: the loss is read one step late
+            tickets.append(m.step_deferred(ca.Batch(w, wl, wwt, wi), lr or TRAJ_LR, entity_ids=wid))
+            if len(tickets) > 1:
+                costs.append(m.deferred_cost(tickets[-2]))
         elif use_gpu:
             costs.append(m.step(ca.Batch(w, wl, wwt, wi), lr or TRAJ_LR, entity_ids=wid, want_cost=True))
         else:
@@ -259,6 +263,8 @@ def _worker_traj(rank, port, spec, out_dir, use_gpu, exact=False, lr=None, separ
             m.backward()
             costs.append(m.get_cost())
             m.update(lr or TRAJ_LR)
+    if tickets:
+        costs.append(m.deferred_cost(tickets[-1]))
     if use_gpu:
         if not exact:
             m.dp_average_tables()
@@ -370,7 +376,7 @@ EXACT_LR = {"sgd": 5.0, "adagrad": 0.5, "sparse_adam": 0.02, "dense_adam": 0.02,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("method,variant", [("sgd", "step"), ("sgd", "calls"), ("adagrad", "step"), ("sparse_adam", "step"),
-                                            ("sparse_adam", "calls"), ("dense_adam", "step"), ("full_adam", "step"),
+                                            ("sparse_adam", "calls"), ("sparse_adam", "deferred"), ("dense_adam", "step"), ("full_adam", "step"),
                                             ("sparse_adam", "lazy"), ("sgd", "lazy"), ("sparse_adam", "l2_entity")])
 def test_dp_exact_tables_hip(tmp_path, method, variant, monkeypatch):
     """nvsm_config.dp_exact_tables on two ranks sharing GPU 0 (gloo as the transport): after 20 steps the ranks' tables are
@@ -387,7 +393,8 @@ def test_dp_exact_tables_hip(tmp_path, method, variant, monkeypatch):
         spec["l2_entity"] = True
     lr = EXACT_LR[method]
     port = _free_port()
-    mp.spawn(_worker_traj, args=(port, spec, str(tmp_path), True, True, lr, variant == "calls"), nprocs=WORLD, join=True)
+    mp.spawn(_worker_traj, args=(port, spec, str(tmp_path), True, True, lr, {"calls": True, "deferred": "deferred"}.get(variant, False)),
+             nprocs=WORLD, join=True)
     params, batches = _traj_batches(spec)
     ref = gpu_model(spec, TRAJ_B)
     load_params(ref, params, True)

@@ -210,7 +210,7 @@ def self_launch(args):
 class Leg:
     """One engine handle + its pool of synthetic batches: everything a timed region needs."""
 
-    def __init__(self, env, wl, method, B, uniform_words=False, host_batches=False, seed=1234):
+    def __init__(self, env, wl, method, B, uniform_words=False, host_batches=False, seed=1234, exact_tables=False):
         import cunvsm_amd as ca
         self.env, self.wl, self.method, self.B = env, wl, method, B
         self.uniform_words = uniform_words
@@ -220,7 +220,8 @@ class Leg:
                                 nonlinearity=wl["nonlinearity"], clip_sigmoid=1,
                                 bias_negative_samples=wl["bias_negative_samples"], regularization_lambda=1e-2, update_method=method,
                                 max_batch_size=B, device=env.local_rank, sampler=ca.SAMPLER_DEVICE,
-                                world_size=env.world, rank=env.rank, sync_batch_norm=1)
+                                world_size=env.world, rank=env.rank, sync_batch_norm=1,
+                                dp_exact_tables=int(bool(exact_tables) and env.world > 1))
         self.model = ca.Model(cfg)
         self.model.initialize(1)                # --seed 1 (scripts/functions.sh:393); identical replicas on every rank
         self.transport, self.comm_ranks = env.connect(self.model)
@@ -378,6 +379,8 @@ def main():
     ap.add_argument("--weak-scaling", action="store_true", help="N > 1: make the weak figure (51 200 windows per rank) the headline "
                     "`value` instead of the strong split of the metric's 51 200-window batch; both are always measured")
     ap.add_argument("--strong-scaling", action="store_true", help="(the default since round 3; kept for older command lines)")
+    ap.add_argument("--exact-tables-leg", action="store_true", help="N > 1: also time the strong split with nvsm_config.dp_exact_tables "
+                    "(every rank applies the whole batch's embedding updates: the single-GPU trajectory) -> \"exact_tables\" in the line")
     ap.add_argument("--test-shared-gpu", action="store_true", help="test of the N > 1 control flow on a 1-GPU box: every rank on "
                     "device 0, gloo rendezvous, all-reduces through the host-callback transport (not a measurement)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous only (gloo, no GPU): proves that the N-rank launch works")
@@ -543,6 +546,16 @@ def main():
                            scaling="weak" if headline_strong else "strong", global_batch=total, batch_per_rank=other_B,
                            steps=args.steps, **st)
                 extra["weak" if headline_strong else "strong"] = fig
+                del leg
+            if args.exact_tables_leg and strong_ok:
+                # the strong split again with exact data-parallel tables: what the single-GPU trajectory costs
+                leg = Leg(env, wl, method, Bg // world, uniform_words=args.uniform_words, host_batches=args.host_batches, seed=4321,
+                          exact_tables=True)
+                leg.run_steps(2 + max(3, args.warmup))
+                med, st = leg_value(leg)
+                extra["exact_tables"] = dict(value=round(Bg * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), scaling="strong",
+                                             global_batch=Bg, batch_per_rank=Bg // world, steps=args.steps,
+                                             note="nvsm_config.dp_exact_tables: every rank applies the table updates of all ranks' windows", **st)
                 del leg
 
     if rank == 0:

@@ -65,10 +65,11 @@ def test_bench_two_ranks_control_flow():
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--test-shared-gpu"]
+           "--test-shared-gpu", "--exact-tables-leg"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
+    assert d["exact_tables"]["batch_per_rank"] == 25600 and d["exact_tables"]["value"] > 0      # (opt-in leg: dp_exact_tables)
     # the metric says batch = 51 200: the headline is the strong split (25 600 windows per rank), the weak figure rides along
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 51200 and d["config"]["batch_per_rank"] == 25600
     assert d["scaling"] == "strong" and d["config"]["parallelism"] == "dp2"

@@ -1305,11 +1305,9 @@ void Model::backward_T(hipStream_t strm) {
         PROF_ON("gemm_bwd_T", strm);
         const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
         const size_t stride = static_cast<size_t>(de) * dw;
-        static const bool skip_dt = [] { const char* e = std::getenv("NVSM_EXP_SKIP_DT"); return e && e[0] == '1'; }();      // timing experiment only: WRONG results
         static const int dt_split_env = [] { const char* e = std::getenv("NVSM_DT_SPLIT"); return e ? std::atoi(e) : -1; }();      // A/B runs: 0 never, 1 always
         const bool dt_split = dt_split_env >= 0 ? dt_split_env != 0 : dt_split_now_;
-        if (skip_dt) {
-        } else if (dt_split && gemm_dt_covers(dw, de, static_cast<int>(B))) {
+        if (dt_split && gemm_dt_covers(dw, de, static_cast<int>(B))) {
             // the split-bf16 product (gemm_dt.hip): few, long slabs on a quarter of the chip, next to the updates
             const int dslabs = gemm_dt_slabs(static_cast<int>(B), dt_slabs_want_);
             if (!launch_gemm_dt(phrase_p_, dy_.p, dslabs == 1 ? gT_.p : gT_partial_.p, dw, de, static_cast<int>(B), dw, de, dt_slabs_want_, strm))

@@ -371,6 +371,53 @@ def test_dp_exact_tables_hip_wide(tmp_path):
         assert diff <= 2e-2 * moved, (name, diff, moved)      # (Adam divides by |g|: a sign flip of a tiny gradient is a whole step)
 
 
+def _worker_exact_odd(rank, port, spec, B, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import cunvsm_amd as ca
+    from cunvsm_amd import dp
+    from tests.helpers import gpu_model, load_params
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
+    params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 11)
+    w, wl, _, _, wid = dp.shard_batch(words, labels, None, None, ids, spec["window"], spec["num_random"], rank, WORLD)
+    m = gpu_model(spec, B // WORLD + 5, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0, dp_exact_tables=1)      # (capacity above the batch)
+    load_params(m, params, True)
+    m.set_allreduce_callback(dp.torch_allreduce(dist))
+    for _ in range(3):
+        m.step(ca.Batch(w, wl, None, None), 0.1, entity_ids=wid)
+    np.savez(os.path.join(out_dir, "odd_rank%d.npz" % rank), E=m.get_param("entity_representations-representations"),
+             W=m.get_param("word_representations-representations"), T=m.get_param("word_entity_mapping-transform"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["sgd", "sparse_adam"])
+def test_dp_exact_tables_hip_odd_batch_no_weights(tmp_path, method):
+    """An odd per-rank batch (77 windows, below the handle's capacity) without feature / instance weights (NULL pointers: nothing
+    to gather for them)."""
+    import torch.multiprocessing as mp
+    import cunvsm_amd as ca
+    from tests.helpers import gpu_model, load_params
+    spec = dict(SPEC, update_method=method)
+    B = 2 * 77
+    port = _free_port()
+    mp.spawn(_worker_exact_odd, args=(port, spec, B, str(tmp_path)), nprocs=WORLD, join=True)
+    params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 11)
+    ref = gpu_model(spec, B)
+    load_params(ref, params, True)
+    for _ in range(3):
+        ref.step(ca.Batch(words, labels, None, None), 0.1, entity_ids=ids)
+    r = [np.load(os.path.join(str(tmp_path), "odd_rank%d.npz" % k)) for k in range(WORLD)]
+    for name, pname in (("E", "entity_representations-representations"), ("W", "word_representations-representations"),
+                        ("T", "word_entity_mapping-transform")):
+        np.testing.assert_array_equal(r[0][name], r[1][name])
+        single = ref.get_param(pname).astype(np.float64).ravel()
+        moved = np.linalg.norm(single - params[pname].astype(np.float64).ravel())
+        diff = np.linalg.norm(r[0][name].astype(np.float64).ravel() - single)
+        assert diff <= (2e-2 if method.endswith("adam") else 2e-5) * moved, (name, diff, moved)
+
+
 EXACT_LR = {"sgd": 5.0, "adagrad": 0.5, "sparse_adam": 0.02, "dense_adam": 0.02, "full_adam": 0.02}
 
 

@@ -145,6 +145,10 @@ def test_multi_gpu_flags_fail_cleanly_on_one_gpu(tmp_path):
     assert r.returncode == 1 and "--gpus 2 but only 1 HIP device" in r.stderr
     r = run_trainer(["--world_size", "2", "--rank", "2", "--seed", "1", "--update_method", "sgd", "--nonlinearity", "tanh", CRANFIELD], timeout=120)
     assert r.returncode == 1 and "bad --world_size / --rank" in r.stderr
+    # --dp_exact_tables is a data-parallel option: a single rank takes it and trains as without it
+    r = run_trainer(["--dp_exact_tables", "--seed", "1", "--update_method", "sgd", "--nonlinearity", "tanh", "--num_epochs", "1",
+                     "--batch_size", "1024", CRANFIELD], timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
 
 
 def test_rccl_selftest_and_pinned_alloc():

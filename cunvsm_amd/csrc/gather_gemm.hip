@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include "../../include/cunvsm_amd.h"
 #include "kernels.h"
 #include "device_utils.h"
 
@@ -456,7 +457,8 @@ int gemm_split_k_slabs(int K, int want) {
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
                  hipStream_t s, double* colstats, float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip,
-                 const GridSumWs* sums, GemmSplitWs* split_ws) {
+                 const GridSumWs* sums, GemmSplitWs* split_ws, const Planes* a_planes, bool* a_planes_written) {
+    if (a_planes_written) *a_planes_written = false;
     if (M <= 0 || N <= 0) return;
     if (rowsq_parts) *rowsq_parts = rowsq ? tiled_rowsq_parts(N) : 0;
     // per-rank batch sizes: a workgroup per 32 rows and all columns (gemm_rows.hip); its row sums of squares are complete: one part
@@ -467,8 +469,10 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
     }
     // large batches: the bf16 matrix pipe at fp32 accuracy (gemm_split.hip); complete row sums of squares: one part
     if (split_k <= 1 && a_layout == 0 && M > gemm_rows_max_m() &&
-        launch_gemm_split(b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, s, colstats, sums, rowsq, rowsq_scale, split_ws)) {
+        launch_gemm_split(b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, s, colstats, sums, rowsq, rowsq_scale, split_ws, nullptr,
+                          a_planes_written ? a_planes : nullptr)) {
         if (rowsq_parts) *rowsq_parts = rowsq ? 1 : 0;
+        if (a_planes_written) *a_planes_written = a_planes != nullptr;
         return;
     }
     // batch-sized products against the projection matrix: the matrix stationary in LDS (gemm_tstat.hip)
@@ -506,8 +510,8 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
         const int fan = grid_sum_fan(g.mtiles);
         if (!sums || sums->colgroups < g.ntiles || sums->contrib_cap < g.mtiles || sums->width_cap < 2 * BN ||
             sums->groups_cap < (g.mtiles + fan - 1) / fan) {
-            std::fprintf(stderr, "cunvsm_amd: launch_gemm with column statistics needs a GridSumWs of %d x %d x %d\n", g.ntiles, g.mtiles, 2 * BN);
-            std::abort();
+            throw Error(NVSM_ERR_INVALID_ARGUMENT, "launch_gemm with column statistics needs a GridSumWs of " + std::to_string(g.ntiles) + " x " +
+                                                           std::to_string(g.mtiles) + " x " + std::to_string(2 * BN));
         }
         g.sums = *sums;
         g.sums.fan = fan;

@@ -477,6 +477,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         hipDeviceProp_t prop{};
         NVSM_HIP_CHECK(hipGetDeviceProperties(&prop, cfg.device));
         const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        num_cus_ = cus;
         // or per 32 rows and all columns at once (row-panel kernel, per-rank batch sizes)
         alloc_sums(sums_fwd_, std::max(4, (de + 127) / 128), std::max<int>(cus, static_cast<int>((B + 31) / 32)), std::max(2 * 160, 2 * de));
         alloc_sums(sums_bwd_, 1, static_cast<int>((B + 3) / 4), 2 * de + 1);
@@ -498,11 +499,19 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         const char* e = std::getenv("NVSM_DT_SLABS");
         gemm_slabs_want_ = e ? std::atoi(e) : (B > gemm_rows_max_m() ? 16 : static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, B / 128))));
     }
-    {
-        const char* e = std::getenv("NVSM_DT_SPLIT_SLABS");
-        dt_slabs_want_ = e ? std::atoi(e) : 64;
+    // the dT product on bf16 planes (gemm_dtp.hip): at most a slab per two CUs (two workgroups per slab)
+    dtp_ok_ = gemm_dtp_covers(dw, de, static_cast<int>(B));
+    if (dtp_ok_) {
+        for (int p = 0; p < 2; ++p) {
+            phrase_planes_buf_[p].alloc(planes_bytes(B, dw), true);      // zeroed once: padding columns and the zero row stay zero
+            phrase_planes_[p] = planes_view(phrase_planes_buf_[p].p, B, dw);
+        }
+        dx_planes_buf_.alloc(planes_bytes(B, de), true);
+        dx_planes_ = planes_view(dx_planes_buf_.p, B, de);
     }
-    const int slabs = std::max(gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_), gemm_dt_slabs(static_cast<int>(B), dt_slabs_want_));
+    // A batch BELOW max_batch_size can need MORE slabs than the full one (slab lengths round up to whole K tiles: 6 400 rows cut
+    // 64 ways are 50 slabs of 128, 6 144 rows are 64 slabs of 96), but never more than asked for: size for that bound.
+    const int slabs = std::max({gemm_slabs_want_, num_cus_ / 2, 1});
     gT_partial_.alloc(static_cast<size_t>(slabs) * de * dw);
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -1065,11 +1074,13 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     if (join_e_at == 1) join_E();
     {
         PROF("gemm_fwd");
+        // (the split-bf16 kernel cuts the phrase matrix into its bf16 planes on the way in: it writes them out for the dT product)
+        phrase_planes_fresh_ = false;
         launch_gemm(0, 0, phrase_p_, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
                     cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_,
                     cfg_.batch_normalization ? stats_fwd_ : nullptr, nullptr, 0.f, nullptr,
                     /*busy_chip=*/words_.lazy || ents_.lazy,       // long sorts and a long documents-update tail next to it
-                    &sums_fwd_.ws, &split_fwd_);
+                    &sums_fwd_.ws, &split_fwd_, dtp_ok_ ? &phrase_planes_[phrase_p_ == phrase_.p ? 0 : 1] : nullptr, &phrase_planes_fresh_);
     }
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
@@ -1158,8 +1169,6 @@ void Model::compute_gradients() {
     NVSM_HIP_CHECK(hipSetDevice(cfg_.device));
     RangeScope range_cg("ComputeGradients");            // cpp/main.cu:414
     backward_dx();
-    // (alone on its stream the split-bf16 dT kernel is the faster one from a few thousand rows on)
-    dt_split_now_ = B_ >= 4096 && gemm_dt_covers(cfg_.word_repr_size, cfg_.entity_repr_size, static_cast<int>(B_));
     backward_T(stream_);
     NVSM_HIP_CHECK(hipGetLastError());
     have_grads_ = true;
@@ -1193,9 +1202,15 @@ void Model::backward_dx() {
     auto split_ready = [&] {
         if (!split_bwd_.ready) { launch_gemm_split_planes(1, T_.p, dw, de, de, split_bwd_.planes, stream_); split_bwd_.ready = true; }
     };
+    dx_planes_fresh_ = false;
     auto dx_product = [&](const BnDxFused* fused) {
-        if (big) return launch_gemm_split(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
-                                          nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &split_bwd_, fused);
+        if (big) {
+            // (... and writes the planes of dx out as it cuts them)
+            const bool ok = launch_gemm_split(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
+                                              nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &split_bwd_, fused, dtp_ok_ ? &dx_planes_ : nullptr);
+            dx_planes_fresh_ = ok && dtp_ok_;
+            return ok;
+        }
         return launch_gemm_rows(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
                                 nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, fused);
     };
@@ -1281,7 +1296,8 @@ void Model::backward_dx() {
         // (A/B, interleaved: 1.235 ms per step with the epilogue fusion vs 1.262 ms with a separate row-mean-of-squares pass)
         int msq_parts = 0;
         launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, l2p ? 1.f : inv_w, nullptr, 1, 0, stream_,
-                    nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw, &msq_parts, false, nullptr, &split_bwd_);
+                    nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw, &msq_parts, false, nullptr, &split_bwd_,
+                    dtp_ok_ ? &dx_planes_ : nullptr, &dx_planes_fresh_);
         // ev_bwdx_: the dx GEMM, the last reader of T before its update, is through (and gphrase / its row statistics final)
         if (l2p) {      // Normalizer::backward, then the division by the window (objective.cu:461-476); mean of squares of the result
             launch_l2_rows_backward(gphrase_.p, phrase_raw_.p, phrase_norms_.p, B, dw, inv_w, gphrase_.p,
@@ -1305,12 +1321,17 @@ void Model::backward_T(hipStream_t strm) {
         PROF_ON("gemm_bwd_T", strm);
         const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
         const size_t stride = static_cast<size_t>(de) * dw;
-        static const int dt_split_env = [] { const char* e = std::getenv("NVSM_DT_SPLIT"); return e ? std::atoi(e) : -1; }();      // A/B runs: 0 never, 1 always
-        const bool dt_split = dt_split_env >= 0 ? dt_split_env != 0 : dt_split_now_;
-        if (dt_split && gemm_dt_covers(dw, de, static_cast<int>(B))) {
-            // the split-bf16 product (gemm_dt.hip): few, long slabs on a quarter of the chip, next to the updates
-            const int dslabs = gemm_dt_slabs(static_cast<int>(B), dt_slabs_want_);
-            if (!launch_gemm_dt(phrase_p_, dy_.p, dslabs == 1 ? gT_.p : gT_partial_.p, dw, de, static_cast<int>(B), dw, de, dt_slabs_want_, strm))
+        if (use_dtp()) {
+            // the split-K product on bf16 planes (gemm_dtp.hip). Operands whose producer did not write the planes on the way
+            // (batches below the split-bf16 projection products', the optional normalisers, odd shapes) are cut here, on this
+            // stream: dx is final in front of this call, the phrase matrix long before.
+            const Planes& pp = phrase_planes_[phrase_p_ == phrase_.p ? 0 : 1];
+            if (!phrase_planes_fresh_) { launch_cut_planes(phrase_p_, B, dw, dw, pp, strm); prof.note("dt_cut_phrase"); }
+            if (!dx_planes_fresh_) { launch_cut_planes(dy_.p, B, de, de, dx_planes_, strm); prof.note("dt_cut_dx"); }
+            phrase_planes_fresh_ = dx_planes_fresh_ = true;
+            const int want = gemm_dtp_default_slabs(static_cast<int>(B), num_cus_);
+            const int dslabs = gemm_dtp_slabs(static_cast<int>(B), want);
+            if (!launch_gemm_dtp(pp, dx_planes_, dslabs == 1 ? gT_.p : gT_partial_.p, dw, de, static_cast<int>(B), want, strm))
                 throw Error(NVSM_ERR_UNSUPPORTED, "dT product refused a shape its caller had checked");
             if (dslabs > 1) launch_splitk_reduce(gT_partial_.p, dslabs, stride, gT_.p, static_cast<int64_t>(stride), strm);
         } else if (slabs == 1) {
@@ -1618,11 +1639,13 @@ int Model::csr_stream_layout() const {
     return sort_layout_env >= 0 ? sort_layout_env : (dt_on_main() ? 2 : 4);
 }
 
-// the fused step's dT product on the main stream with the split-bf16 kernel (see step()): large batches of eager tables
+// this step's dT product runs on bf16 planes (gemm_dtp.hip): shapes the kernel covers, unless the exact-fp32 kernels are asked for
+bool Model::use_dtp() const { return dtp_ok_ && gemm_split_products() != 0 && B_ >= 64; }
+
+// the fused step's dT product on the main stream (see step()): large batches of eager tables
 bool Model::dt_on_main() const {
     static const int dt_main_env = [] { const char* e = std::getenv("NVSM_DT_ON_MAIN"); return e ? std::atoi(e) : -1; }();
-    return (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy)) && cfg_.world_size <= 1 &&
-           gemm_dt_covers(cfg_.word_repr_size, cfg_.entity_repr_size, static_cast<int>(B_));
+    return (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy)) && cfg_.world_size <= 1 && use_dtp();
 }
 
 // T changed: its bf16 planes for the next two projection products, behind the writer on the writer's stream (off the critical
@@ -1724,7 +1747,6 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     if (!docs_after_dx && !docs_on_main) backward_dx();
     dx_follower_ = nullptr;
     if (dp) {
-        dt_split_now_ = B_ >= 4096 && gemm_dt_covers(cfg_.word_repr_size, cfg_.entity_repr_size, static_cast<int>(B_));
         backward_T(stream_);
     } else {
         // side stream 2 (behind the words CSR build): the MFMA-bound dT GEMM next to the HBM-bound words update, then the
@@ -1739,8 +1761,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         // for 45-70 us while the documents pass starts up, and the projection update still runs on side stream 2.
         // Interleaved A/B: NVSM shape 0.931 -> 0.921 ms, full_adam 0.850 -> 0.787; batch 25 600 0.588 -> 0.597 and
         // |D| = 2 M 1.71 -> 1.72 the other way (the main stream is their longer chain): hence the rule. NVSM_DT_ON_MAIN=0 / 1.
-        dt_split_now_ = dt_on_main();
-        if (dt_split_now_) {
+        if (dt_on_main()) {
             backward_T(stream_);
             NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_));
             NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_gathered_, 0));

@@ -117,7 +117,6 @@ def lib():
         "nvsm_profile_get": (C.c_int, [vp, cp, P(C.c_double), P(i64)]),
         "nvsm_debug_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
         "nvsm_debug_gemm_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]),
-        "nvsm_debug_planes_roundtrip": (C.c_int, [C.c_int64, C.c_int, vp, vp]),
         "nvsm_debug_dt_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]),
         "nvsm_debug_sort": (C.c_int, [i64, C.c_int, vp, vp, vp, C.c_int, P(C.c_float)]),
         "nvsm_debug_gather_mean": (C.c_int, [i64, C.c_int, vp, vp, vp, C.c_int, i64, vp]),

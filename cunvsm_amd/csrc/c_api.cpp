@@ -200,17 +200,11 @@ int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const 
         NVSM_HIP_CHECK(hipMemcpy(A.p, hostA, A.n * sizeof(float), hipMemcpyHostToDevice));
         NVSM_HIP_CHECK(hipMemcpy(B.p, hostB, B.n * sizeof(float), hipMemcpyHostToDevice));
         const int lda = al ? M : K, ldb = bl ? K : N;
-        if (split >= 1 && al == 1 && bl == 0 && !exact && cunvsm::gemm_dtp_covers(M, N, K)) {
-            // the projection-gradient shape: the split-K kernel on bf16 planes the model uses for it (gemm_dtp.hip), behind the
-            // stand-alone cut of both operands
-            cunvsm::DevBuf<char> pa, pb;
-            pa.alloc(cunvsm::planes_bytes(K, M), true); pb.alloc(cunvsm::planes_bytes(K, N), true);
-            const cunvsm::Planes PA = cunvsm::planes_view(pa.p, K, M), PB = cunvsm::planes_view(pb.p, K, N);
-            cunvsm::launch_cut_planes(A.p, K, M, lda, PA, nullptr);
-            cunvsm::launch_cut_planes(B.p, K, N, ldb, PB, nullptr);
-            const int slabs = cunvsm::gemm_dtp_slabs(K, split);
+        if (split >= 1 && al == 1 && bl == 0 && !exact && cunvsm::gemm_dt_covers(M, N, K)) {
+            // the projection-gradient shape: the split-bf16 split-K kernel the model uses for it (gemm_dt.hip)
+            const int slabs = cunvsm::gemm_dt_slabs(K, split);
             P.alloc(static_cast<size_t>(slabs) * M * N);
-            if (!cunvsm::launch_gemm_dtp(PA, PB, P.p, M, N, K, split, nullptr)) throw Error(NVSM_ERR_UNSUPPORTED, "gemm_dtp refused a covered shape");
+            if (!cunvsm::launch_gemm_dt(A.p, B.p, P.p, M, N, K, lda, ldb, split, nullptr)) throw Error(NVSM_ERR_UNSUPPORTED, "gemm_dt refused a covered shape");
             cunvsm::launch_splitk_reduce(P.p, slabs, static_cast<size_t>(M) * N, C.p, static_cast<int64_t>(M) * N, nullptr);
             NVSM_HIP_CHECK(hipDeviceSynchronize());
         } else if (split > 1) {
@@ -285,25 +279,8 @@ int nvsm_debug_gemm_time(int b_layout, int M, int N, int K, int extras, int repe
     });
 }
 
-// X [rows][cols] -> bf16 planes -> fp32 (tests: the cut is exact)
-int nvsm_debug_planes_roundtrip(int64_t rows, int cols, const float* hostX, float* hostOut) {
-    NVSM_REQUIRE(hostX); NVSM_REQUIRE(hostOut);
-    return guarded([&] {
-        cunvsm::DevBuf<float> X, O;
-        cunvsm::DevBuf<char> pb;
-        X.alloc(static_cast<size_t>(rows) * cols); O.alloc(X.n);
-        pb.alloc(cunvsm::planes_bytes(rows, cols), true);
-        const cunvsm::Planes P = cunvsm::planes_view(pb.p, rows, cols);
-        NVSM_HIP_CHECK(hipMemcpy(X.p, hostX, X.n * sizeof(float), hipMemcpyHostToDevice));
-        cunvsm::launch_cut_planes(X.p, rows, cols, cols, P, nullptr);
-        cunvsm::launch_join_planes(P, rows, cols, O.p, nullptr);
-        NVSM_HIP_CHECK(hipDeviceSynchronize());
-        NVSM_HIP_CHECK(hipMemcpy(hostOut, O.p, O.n * sizeof(float), hipMemcpyDeviceToHost));
-    });
-}
-
-// the dT product alone on device-resident operands (phrase [rows][M], dx [rows][N], cut into planes once): average ms of the
-// split-K kernel and of the reduce behind it. which 0 = gemm_dtp (planes), 2 = the tiled exact-fp32 kernel
+// the dT product alone on device-resident operands (phrase [rows][M], dx [rows][N]): average ms of the split-K kernel and of
+// the reduce behind it. which 0 = gemm_dt (split-bf16), 2 = the tiled exact-fp32 kernel
 int nvsm_debug_dt_time(int M, int N, int rows, int slabs, int repeats, int which, float* kernel_ms, float* reduce_ms) {
     NVSM_REQUIRE(kernel_ms); NVSM_REQUIRE(reduce_ms);
     return guarded([&] {
@@ -318,20 +295,15 @@ int nvsm_debug_dt_time(int M, int N, int rows, int slabs, int repeats, int which
             };
             fill(A, 0.5f); fill(B, 0.1f);
         }
-        cunvsm::DevBuf<char> pa, pb;
-        pa.alloc(cunvsm::planes_bytes(rows, M), true); pb.alloc(cunvsm::planes_bytes(rows, N), true);
-        const cunvsm::Planes PA = cunvsm::planes_view(pa.p, rows, M), PB = cunvsm::planes_view(pb.p, rows, N);
         hipStream_t s;
         NVSM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        cunvsm::launch_cut_planes(A.p, rows, M, M, PA, s);
-        cunvsm::launch_cut_planes(B.p, rows, N, N, PB, s);
-        if (which != 0 && which != 2) throw Error(NVSM_ERR_INVALID_ARGUMENT, "which: 0 = planes kernel, 2 = tiled fp32 kernel");
-        const int ns = which == 0 ? cunvsm::gemm_dtp_slabs(rows, slabs) : cunvsm::gemm_split_k_slabs(rows, slabs);
+        if (which != 0 && which != 2) throw Error(NVSM_ERR_INVALID_ARGUMENT, "which: 0 = split-bf16 kernel, 2 = tiled fp32 kernel");
+        const int ns = which == 0 ? cunvsm::gemm_dt_slabs(rows, slabs) : cunvsm::gemm_split_k_slabs(rows, slabs);
         const size_t stride = static_cast<size_t>(M) * N;
         P.alloc(static_cast<size_t>(std::max(ns, 1)) * stride);
         auto product = [&] {
             bool ok = true;
-            if (which == 0) ok = cunvsm::launch_gemm_dtp(PA, PB, P.p, M, N, rows, slabs, s);
+            if (which == 0) ok = cunvsm::launch_gemm_dt(A.p, B.p, P.p, M, N, rows, M, N, slabs, s);
             else cunvsm::launch_gemm(1, 0, A.p, B.p, P.p, M, N, rows, M, N, N, 1.f, nullptr, slabs, stride, s);
             if (!ok) throw Error(NVSM_ERR_UNSUPPORTED, "the dT kernel refused the shape");
         };

@@ -457,8 +457,7 @@ int gemm_split_k_slabs(int K, int want) {
 void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, float alpha, const float* bias_n, int split_k, size_t c_split_stride,
                  hipStream_t s, double* colstats, float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip,
-                 const GridSumWs* sums, GemmSplitWs* split_ws, const Planes* a_planes, bool* a_planes_written) {
-    if (a_planes_written) *a_planes_written = false;
+                 const GridSumWs* sums, GemmSplitWs* split_ws) {
     if (M <= 0 || N <= 0) return;
     if (rowsq_parts) *rowsq_parts = rowsq ? tiled_rowsq_parts(N) : 0;
     // per-rank batch sizes: a workgroup per 32 rows and all columns (gemm_rows.hip); its row sums of squares are complete: one part
@@ -469,10 +468,8 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
     }
     // large batches: the bf16 matrix pipe at fp32 accuracy (gemm_split.hip); complete row sums of squares: one part
     if (split_k <= 1 && a_layout == 0 && M > gemm_rows_max_m() &&
-        launch_gemm_split(b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, s, colstats, sums, rowsq, rowsq_scale, split_ws, nullptr,
-                          a_planes_written ? a_planes : nullptr)) {
+        launch_gemm_split(b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, s, colstats, sums, rowsq, rowsq_scale, split_ws)) {
         if (rowsq_parts) *rowsq_parts = rowsq ? 1 : 0;
-        if (a_planes_written) *a_planes_written = a_planes != nullptr;
         return;
     }
     // batch-sized products against the projection matrix: the matrix stationary in LDS (gemm_tstat.hip)

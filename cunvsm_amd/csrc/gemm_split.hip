@@ -84,8 +84,6 @@ struct SplitArgs {
     // pre == null, only the bias gradient grad_bias = (float) bn_sums (launch_colsum_finalize's)
     float* A_rw; const float* pre; const float* mean; const float* inv_std; const double* bn_sums;
     float* dbeta; float* dgamma; float* grad_bias; float inv_n;
-    // the three bf16 planes of A (of dx under PRE) written out as they are cut (kernels.h Planes: the dT product's operands)
-    unsigned char* planes_out; size_t planes_out_plane; unsigned planes_out_pitch;      // null: not wanted | bytes between planes | bytes per row
 };
 
 #ifdef NVSM_SPLIT_TIMING
@@ -246,19 +244,6 @@ __device__ __forceinline__ void split_body(const SplitArgs& g) {
                 *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2*>(p + kPlane) = make_uint2(m0, m1);
                 *reinterpret_cast<uint2*>(p + 2 * kPlane) = make_uint2(l0, l1);
-                if (g.planes_out) {
-                    // ... and to the planes the dT product reads (every element of A passes here exactly once; columns past K
-                    // inside the last tile are the zeros the padding of a Planes row must hold). Rows past the matrix and
-                    // columns past the pitch: the dump word.
-                    const unsigned col2 = static_cast<unsigned>(2 * (32 * kt + 4 * k4));
-                    const bool wr = row < nrows && col2 < g.planes_out_pitch && kt < KT;
-                    unsigned char* q = wr ? g.planes_out + static_cast<size_t>(row0 + row) * g.planes_out_pitch + col2
-                                          : reinterpret_cast<unsigned char*>(g.dump);
-                    const size_t ps = wr ? g.planes_out_plane : 0;
-                    *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
-                    *reinterpret_cast<uint2*>(q + ps) = make_uint2(m0, m1);
-                    *reinterpret_cast<uint2*>(q + 2 * ps) = make_uint2(l0, l1);
-                }
             }
         };
         // the wave's column blocks of K tile kt: three 16 B loads per block from the planes of B (gemm_split_planes_kernel;
@@ -567,9 +552,8 @@ bool gemm_split_covers(int b_layout, int M, int N, int K, bool bn) {
 // ws: the planes of B (cut here, on `s`, unless ws->ready says they are current).
 bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                        float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
-                       float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn, const Planes* a_planes) {
+                       float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn) {
     const int nprod = gemm_split_products();
-    if (a_planes && (a_planes->cols != K || a_planes->rows_cap < M)) return false;
     if (bn && (b_layout != 1 || K > 320 || (bn->pre && (bn->dy != A || reinterpret_cast<uintptr_t>(bn->pre) % 16)))) return false;
     if (!nprod || M < 1024 || !ws || !ws->planes || ws->bytes < gemm_split_planes_bytes(N, K)) return false;
     // (the kernel addresses A — and pre — by 32-bit byte offsets from the base)
@@ -597,7 +581,6 @@ bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, i
         g.dbeta = bn->dbeta; g.dgamma = bn->dgamma; g.grad_bias = bn->grad_bias; g.inv_n = static_cast<float>(1.0 / bn->n_global);
     }
     { const char* e = std::getenv("NVSM_SPLIT_NT"); g.nt_store = e ? std::atoi(e) : 0; }
-    if (a_planes) { g.planes_out = a_planes->p; g.planes_out_plane = a_planes->plane_bytes; g.planes_out_pitch = static_cast<unsigned>(a_planes->pitch * 2); }
     g.nblocks = (M + 15) / 16; g.np = 16 * cbs; g.dump = dump; g.planes = static_cast<const unsigned char*>(ws->planes);
     int wgs = num_cus < g.nblocks ? num_cus : g.nblocks;
     if (colstats) {

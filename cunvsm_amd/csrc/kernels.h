@@ -63,18 +63,6 @@ struct BnDxFused { float* dy; const float* pre; const float* mean; const float* 
 struct GemmSplitWs { void* planes; size_t bytes; bool ready; };
 inline int grid_sum_fan(int contributions) { return contributions > 256 ? 32 : 16; }
 
-// An fp32 matrix [rows <= rows_cap][cols] as its three exact bf16 planes (x = h + m + l, gemm_split.hip): three row-major
-// bf16 matrices [rows_cap + 1][pitch] one behind the other (plane_bytes apart), pitch = cols rounded up to 64, the padding
-// columns of every written row zero, and row rows_cap all zero for ever (allocate zeroed; writers never touch it): the
-// reduction tails of launch_gemm_dtp read that row instead of branching. Written by the projection products on the way
-// (launch_gemm_split planes_out) or by launch_cut_planes; read by launch_gemm_dtp.
-struct Planes { unsigned char* p; size_t plane_bytes; int pitch; int cols; int64_t rows_cap; };
-int planes_pitch(int cols);
-size_t planes_bytes(int64_t rows_cap, int cols);
-Planes planes_view(void* buf, int64_t rows_cap, int cols);      // buf: planes_bytes(rows_cap, cols) bytes, zero-filled once
-void launch_cut_planes(const float* X, int64_t rows, int cols, int ld, const Planes& p, hipStream_t s);
-void launch_join_planes(const Planes& p, int64_t rows, int cols, float* X, hipStream_t s);      // h + m + l (exact): tests
-
 // ---- gather-mean (F3/F9; replaces average_repr_kernel, cpp/params.cu:75-95) ------------------
 void launch_gather_mean(const float* table, int dim, const int* idx, const float* wts, int window,
                         int64_t num_out, float* out, hipStream_t s, const LazyView* lazy = nullptr);
@@ -92,9 +80,7 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
                  float* rowsq = nullptr, float rowsq_scale = 0.f, int* rowsq_parts = nullptr,
                  bool busy_chip = false,      // the launch lands next to long-running kernels of other streams (kernel choice)
                  const GridSumWs* sums = nullptr,       // workspace of the ordered column sums (required with colstats)
-                 GemmSplitWs* split_ws = nullptr,       // planes of B for the split-bf16 kernel (null: exact-fp32 MFMA kernels)
-                 const Planes* a_planes = nullptr,      // wanted: the bf16 planes of A (the dT product's operand) ...
-                 bool* a_planes_written = nullptr);     // ... set when the chosen kernel wrote them on the way (else: launch_cut_planes)
+                 GemmSplitWs* split_ws = nullptr);      // planes of B for the split-bf16 kernel (null: exact-fp32 MFMA kernels)
 // rowsq [gemm_rowsq_parts(N)][M]: rowsq_scale · Σ_cols C² per row, split by column tile (128 columns in the tiled kernel,
 // 16 in the LDS-stationary one): *rowsq_parts = the number of parts this launch wrote; launch_sum_parts adds them in
 // order (a runtime-length loop over the parts inside the row passes' unrolled gather was measured: it halves their
@@ -121,15 +107,15 @@ size_t gemm_split_planes_bytes(int N, int K);
 void launch_gemm_split_planes(int b_layout, const float* B, int N, int K, int ldb, void* planes, hipStream_t s);
 bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                        float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
-                       float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn = nullptr,       // bn: as launch_gemm_rows (b_layout 1 only)
-                       const Planes* a_planes = nullptr);      // OUT: the planes of A (of dx with bn) as the kernel cuts them: the dT product's operand
+                       float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn = nullptr);      // bn: as launch_gemm_rows (b_layout 1 only)
 bool gemm_split_covers(int b_layout, int M, int N, int K, bool bn);      // shapes launch_gemm_split accepts
-// dT = Aᵀ[M x rows] · B[rows x N], split-K over the rows (the batch), from planes (gemm_dtp.hip): partial
-// [gemm_dtp_slabs(rows, want)][M][N] — never more slabs than `want` —, the caller adds them with launch_splitk_reduce.
-bool gemm_dtp_covers(int M, int N, int rows);
-int gemm_dtp_slabs(int rows, int want);
-int gemm_dtp_default_slabs(int rows, int cus);
-bool launch_gemm_dtp(const Planes& A, const Planes& B, float* partial, int M, int N, int rows, int want_slabs, hipStream_t s);
+// dT = Aᵀ[M x rows] · B[rows x N], split-K over the rows (the batch), split-bf16 arithmetic (gemm_dt.hip): A [rows][M] (lda),
+// B [rows][N] (ldb), partial [gemm_dt_slabs(rows, want)][M][N] — never more slabs than `want` —; the caller adds the slabs with
+// launch_splitk_reduce. false: shape not covered, nothing launched.
+bool gemm_dt_covers(int M, int N, int rows);
+int gemm_dt_slabs(int rows, int want);
+int gemm_dt_default_slabs(int rows, int cus);      // a slab per two CUs (two workgroups per slab), at least 64 rows each
+bool launch_gemm_dt(const float* A, const float* B, float* partial, int M, int N, int rows, int lda, int ldb, int want_slabs, hipStream_t s);
 int gemm_split_products();               // NVSM_GEMM_SPLIT: 6 (default), 9, or 0 = exact-fp32 MFMA kernels only
 int gemm_rows_max_m();                   // largest M launch_gemm sends to the row-panel kernel (NVSM_GEMM_ROWS_MAX, default 8192; 0 = never): above it the split-bf16 kernel
 float* gemm_dump_buffer();               // 256 B per device nobody reads (gemm_tstat.hip): the target of masked-out stores

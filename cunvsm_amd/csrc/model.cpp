@@ -499,16 +499,8 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         const char* e = std::getenv("NVSM_DT_SLABS");
         gemm_slabs_want_ = e ? std::atoi(e) : (B > gemm_rows_max_m() ? 16 : static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, B / 128))));
     }
-    // the dT product on bf16 planes (gemm_dtp.hip): at most a slab per two CUs (two workgroups per slab)
-    dtp_ok_ = gemm_dtp_covers(dw, de, static_cast<int>(B));
-    if (dtp_ok_) {
-        for (int p = 0; p < 2; ++p) {
-            phrase_planes_buf_[p].alloc(planes_bytes(B, dw), true);      // zeroed once: padding columns and the zero row stay zero
-            phrase_planes_[p] = planes_view(phrase_planes_buf_[p].p, B, dw);
-        }
-        dx_planes_buf_.alloc(planes_bytes(B, de), true);
-        dx_planes_ = planes_view(dx_planes_buf_.p, B, de);
-    }
+    // the split-K dT kernel (gemm_dt.hip): at most a slab per two CUs (two workgroups per slab)
+    dt_ok_ = gemm_dt_covers(dw, de, static_cast<int>(B));
     // A batch BELOW max_batch_size can need MORE slabs than the full one (slab lengths round up to whole K tiles: 6 400 rows cut
     // 64 ways are 50 slabs of 128, 6 144 rows are 64 slabs of 96), but never more than asked for: size for that bound.
     const int slabs = std::max({gemm_slabs_want_, num_cus_ / 2, 1});
@@ -1074,13 +1066,11 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     if (join_e_at == 1) join_E();
     {
         PROF("gemm_fwd");
-        // (the split-bf16 kernel cuts the phrase matrix into its bf16 planes on the way in: it writes them out for the dT product)
-        phrase_planes_fresh_ = false;
         launch_gemm(0, 0, phrase_p_, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
                     cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_,
                     cfg_.batch_normalization ? stats_fwd_ : nullptr, nullptr, 0.f, nullptr,
                     /*busy_chip=*/words_.lazy || ents_.lazy,       // long sorts and a long documents-update tail next to it
-                    &sums_fwd_.ws, &split_fwd_, dtp_ok_ ? &phrase_planes_[phrase_p_ == phrase_.p ? 0 : 1] : nullptr, &phrase_planes_fresh_);
+                    &sums_fwd_.ws, &split_fwd_);
     }
 
     const double B_global = static_cast<double>(B) * ((cfg_.world_size > 1) ? cfg_.world_size : 1);
@@ -1202,15 +1192,9 @@ void Model::backward_dx() {
     auto split_ready = [&] {
         if (!split_bwd_.ready) { launch_gemm_split_planes(1, T_.p, dw, de, de, split_bwd_.planes, stream_); split_bwd_.ready = true; }
     };
-    dx_planes_fresh_ = false;
     auto dx_product = [&](const BnDxFused* fused) {
-        if (big) {
-            // (... and writes the planes of dx out as it cuts them)
-            const bool ok = launch_gemm_split(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
-                                              nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &split_bwd_, fused, dtp_ok_ ? &dx_planes_ : nullptr);
-            dx_planes_fresh_ = ok && dtp_ok_;
-            return ok;
-        }
+        if (big) return launch_gemm_split(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
+                                          nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &split_bwd_, fused);
         return launch_gemm_rows(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
                                 nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, fused);
     };
@@ -1296,8 +1280,7 @@ void Model::backward_dx() {
         // (A/B, interleaved: 1.235 ms per step with the epilogue fusion vs 1.262 ms with a separate row-mean-of-squares pass)
         int msq_parts = 0;
         launch_gemm(0, 1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, l2p ? 1.f : inv_w, nullptr, 1, 0, stream_,
-                    nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw, &msq_parts, false, nullptr, &split_bwd_,
-                    dtp_ok_ ? &dx_planes_ : nullptr, &dx_planes_fresh_);
+                    nullptr, (need_msq && !l2p) ? msq_parts_.p : nullptr, inv_dw, &msq_parts, false, nullptr, &split_bwd_);
         // ev_bwdx_: the dx GEMM, the last reader of T before its update, is through (and gphrase / its row statistics final)
         if (l2p) {      // Normalizer::backward, then the division by the window (objective.cu:461-476); mean of squares of the result
             launch_l2_rows_backward(gphrase_.p, phrase_raw_.p, phrase_norms_.p, B, dw, inv_w, gphrase_.p,
@@ -1321,17 +1304,16 @@ void Model::backward_T(hipStream_t strm) {
         PROF_ON("gemm_bwd_T", strm);
         const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
         const size_t stride = static_cast<size_t>(de) * dw;
-        if (use_dtp()) {
-            // the split-K product on bf16 planes (gemm_dtp.hip). Operands whose producer did not write the planes on the way
-            // (batches below the split-bf16 projection products', the optional normalisers, odd shapes) are cut here, on this
-            // stream: dx is final in front of this call, the phrase matrix long before.
-            const Planes& pp = phrase_planes_[phrase_p_ == phrase_.p ? 0 : 1];
-            if (!phrase_planes_fresh_) { launch_cut_planes(phrase_p_, B, dw, dw, pp, strm); prof.note("dt_cut_phrase"); }
-            if (!dx_planes_fresh_) { launch_cut_planes(dy_.p, B, de, de, dx_planes_, strm); prof.note("dt_cut_dx"); }
-            phrase_planes_fresh_ = dx_planes_fresh_ = true;
-            const int want = gemm_dtp_default_slabs(static_cast<int>(B), num_cus_);
-            const int dslabs = gemm_dtp_slabs(static_cast<int>(B), want);
-            if (!launch_gemm_dtp(pp, dx_planes_, dslabs == 1 ? gT_.p : gT_partial_.p, dw, de, static_cast<int>(B), want, strm))
+        if (use_dt()) {
+            // the split-K product on the bf16 matrix pipe (gemm_dt.hip): two workgroups per slab, a slab per two CUs at most
+            // Slabs: the kernel ALONE is fastest with a workgroup on every CU (128 slabs: 55 us at batch 51 200), but in a step it
+            // runs next to the documents pass, which wants the CUs it leaves free and the bandwidth its partials do not take: on
+            // the main stream 48 slabs (96 workgroups, 15 MB of partials) — 0.891 ms per step against 0.90 with 128 and 0.899 with
+            // 32; full_adam 0.764 / 0.79 / 0.763 —; on side stream 2 next to both table passes of a lazily decayed pair of tables
+            // 16 (|D| = 2 M: 1.61 ms against 1.65 with 128). Interleaved A/B, tools/ab_shapes.sh.
+            const int want = std::min(strm == stream_ ? 48 : 16, gemm_dt_default_slabs(static_cast<int>(B), num_cus_));
+            const int dslabs = gemm_dt_slabs(static_cast<int>(B), want);
+            if (!launch_gemm_dt(phrase_p_, dy_.p, dslabs == 1 ? gT_.p : gT_partial_.p, dw, de, static_cast<int>(B), dw, de, want, strm))
                 throw Error(NVSM_ERR_UNSUPPORTED, "dT product refused a shape its caller had checked");
             if (dslabs > 1) launch_splitk_reduce(gT_partial_.p, dslabs, stride, gT_.p, static_cast<int64_t>(stride), strm);
         } else if (slabs == 1) {
@@ -1639,13 +1621,18 @@ int Model::csr_stream_layout() const {
     return sort_layout_env >= 0 ? sort_layout_env : (dt_on_main() ? 2 : 4);
 }
 
-// this step's dT product runs on bf16 planes (gemm_dtp.hip): shapes the kernel covers, unless the exact-fp32 kernels are asked for
-bool Model::use_dtp() const { return dtp_ok_ && gemm_split_products() != 0 && B_ >= 64; }
+// This step's dT product runs on the split-bf16 split-K kernel (gemm_dt.hip): large batches of the shapes it covers, unless the
+// exact-fp32 kernels are asked for. Not per-rank batches: there the product rides on side stream 2 next to the two table passes,
+// and a kernel whose workgroups each need a whole CU's registers waits for CUs to fall empty — 152 us in-step at batch 6 400
+// for 18 us alone, exactly as long as the 128 x 128-tiled fp32 kernel takes there, whose small workgroups slip in between the
+// passes' and leave the step shorter: batch 6 400 / 12 800 / 25 600: 0.291 / 0.403 / 0.584 ms tiled against 0.312 / 0.426 /
+// 0.610 (0.340 / 0.438 / 0.593 with this kernel on the main stream). Interleaved A/B, tools/ab_shapes.sh.
+bool Model::use_dt() const { return dt_ok_ && gemm_split_products() != 0 && B_ >= 40960; }
 
 // the fused step's dT product on the main stream (see step()): large batches of eager tables
 bool Model::dt_on_main() const {
     static const int dt_main_env = [] { const char* e = std::getenv("NVSM_DT_ON_MAIN"); return e ? std::atoi(e) : -1; }();
-    return (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy)) && cfg_.world_size <= 1 && use_dtp();
+    return (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy)) && cfg_.world_size <= 1 && use_dt();
 }
 
 // T changed: its bf16 planes for the next two projection products, behind the writer on the writer's stream (off the critical

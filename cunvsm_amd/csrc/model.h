@@ -263,16 +263,10 @@ class Model {
     double* stats_bwd_ = nullptr;
     DevBuf<float> bn_mean_, bn_inv_std_, dbeta_, dgamma_;
     DevBuf<float> gT_, gb_, gT_partial_;
-    int gemm_slabs_want_ = 128;        // split-K slabs of the exact-fp32 dT product (shapes / settings gemm_dtp.hip does not cover)
-    // The dT product on bf16 planes (gemm_dtp.hip): its operands — the phrase matrix and dx — as planes, written by the forward
-    // / backward projection product on the way (gemm_split.hip) or cut by a launch of their own in front of the product. Two
-    // sets for the phrase matrix, like the matrix itself (the product of step k may still read one while step k + 1 writes the other).
-    DevBuf<char> phrase_planes_buf_[2], dx_planes_buf_;
-    Planes phrase_planes_[2]{}, dx_planes_{};
-    bool phrase_planes_fresh_ = false, dx_planes_fresh_ = false;      // the current forward / backward result's planes are written
-    bool dtp_ok_ = false;              // the planes exist: shapes the kernel covers
+    int gemm_slabs_want_ = 128;        // split-K slabs of the exact-fp32 dT product (shapes / settings gemm_dt.hip does not cover)
+    bool dt_ok_ = false;               // the split-K dT kernel (gemm_dt.hip) covers this model's shapes
     int num_cus_ = 256;
-    bool use_dtp() const;              // this step's dT product runs on planes
+    bool use_dt() const;               // this step's dT product runs on it (else: the exact-fp32 tiled / panel kernels)
 
     bool have_forward_ = false, have_grads_ = false;
     struct DeferredCost { double* host = nullptr; hipEvent_t ev = nullptr; double batch = 1.0; int64_t ticket = -1; };

@@ -273,10 +273,8 @@ int nvsm_debug_set_table_pass_form(int one_launch);
 /* the stable (row, entry) radix sort alone: keys of `bits` significant bits in, sorted keys + their original positions out */
 /* average ms per launch of a batch-sized projection product on device operands (extras: 1 = column statistics, 2 = row sums of squares) */
 int nvsm_debug_gemm_time(int b_layout, int M, int N, int K, int extras, int repeats, float* avg_ms);
-/* the projection-gradient product alone (which 0 = split-K kernel on bf16 planes, 2 = tiled exact-fp32 kernel): average ms of the product and of its slab reduce */
+/* the projection-gradient product alone (which 0 = the split-bf16 split-K kernel, 2 = tiled exact-fp32 kernel): average ms of the product and of its slab reduce */
 int nvsm_debug_dt_time(int M, int N, int rows, int slabs, int repeats, int which, float* kernel_ms, float* reduce_ms);
-/* X [rows][cols] cut into its three bf16 planes and joined again (the cut is exact: out == X) */
-int nvsm_debug_planes_roundtrip(int64_t rows, int cols, const float* hostX, float* hostOut);
 int nvsm_debug_sort(int64_t n, int bits, const int32_t* keys, int32_t* keys_out, int32_t* vals_out, int repeats, float* avg_ms);
 int nvsm_debug_gather_mean(int64_t num_rows, int dim, const float* table, const int64_t* idx, const float* wts,
                            int window, int64_t num_out, float* out);

@@ -79,8 +79,8 @@ def test_gemm_split_bf16_is_fp32_accurate(M, layout, N, K, monkeypatch):
 @pytest.mark.parametrize("split", [2, 7, 128])
 @pytest.mark.parametrize("exact", [0, 1])
 def test_gemm_split_k(split, exact):
-    """The projection gradient's shape: dT = Aᵀ·B split-K over the batch — the kernel on bf16 planes (gemm_dtp.hip, behind
-    launch_cut_planes) and the tiled exact-fp32 one (variant bit 30)."""
+    """The projection gradient's shape: dT = Aᵀ·B split-K over the batch — the split-bf16 kernel (gemm_dt.hip) and the tiled
+    exact-fp32 one (variant bit 30)."""
     rs = np.random.RandomState(split)
     M, N, K = 300, 256, 4096
     A = rs.uniform(-1, 1, (K, M)).astype(np.float32)       # stored [K][M] like phrase
@@ -94,7 +94,7 @@ def test_gemm_split_k(split, exact):
                                          (300, 256, 16, 1), (128, 128, 4096, 256), (300, 256, 12800 + 5, 247), (292, 228, 333, 2), (4, 4, 1, 1)])
 @pytest.mark.parametrize("products", ["6", "9"])
 def test_gemm_dt_split_bf16(M, N, K, split, products, monkeypatch):
-    """gemm_dtp.hip on ragged slabs (a last tile of 1 / 5 / 13 rows, a batch shorter than a slab, a batch of one tile, padding
+    """gemm_dt.hip on ragged slabs (a last tile of 1 / 5 / 13 rows, a batch shorter than a slab, a batch of one tile, padding
     columns, shapes with and without idle waves: the FULL and the general instantiation, one and two column halves), an
     asymmetric operand, values over many binades; against an fp64 product, relative to Σ|a b|."""
     monkeypatch.setenv("NVSM_GEMM_SPLIT", products)
@@ -106,18 +106,6 @@ def test_gemm_dt_split_bf16(M, N, K, split, products, monkeypatch):
     ref = A.T.astype(np.float64) @ Bm.astype(np.float64)
     scale = np.abs(A.T).astype(np.float64) @ np.abs(Bm).astype(np.float64)
     assert np.abs((Cout - ref) / scale).max() < 1.5e-6
-
-
-def test_planes_are_exact():
-    """launch_cut_planes / launch_join_planes: h + m + l reproduces every fp32 value bit for bit (ragged width: the padding
-    columns of a plane row must read back as nothing), including denormal-range pieces, huge values and signed zeros."""
-    rs = np.random.RandomState(5)
-    X = (rs.standard_normal((333, 300)) * np.exp2(rs.randint(-60, 60, (333, 300)))).astype(np.float32)
-    X[0, :8] = [0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.1754944e-38, 1e-30]
-    out = np.empty_like(X)
-    ca._lib.check(ca.lib().nvsm_debug_planes_roundtrip(X.shape[0], X.shape[1], X.ctypes.data, out.ctypes.data))
-    finite = np.abs(X) < 1e38          # (h = bf16(x) rounds 3e38 up to the largest bf16, fine; beyond it to infinity: excluded by contract)
-    np.testing.assert_array_equal(out[finite], X[finite])
 
 
 def test_gemm_identity_asymmetric():

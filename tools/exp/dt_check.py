@@ -1,4 +1,4 @@
-"""The dT product on bf16 planes (gemm_dtp.hip): correctness against fp64 on ragged shapes, then its time alone by batch size
+"""The dT product on bf16 planes (gemm_dt.hip): correctness against fp64 on ragged shapes, then its time alone by batch size
 and slab count next to round 3's kernel (which 1) and the tiled fp32 kernel (which 2)."""
 import ctypes as C, os, sys
 import numpy as np
@@ -18,7 +18,7 @@ for (M, N, K, split) in [(300, 256, 6400 + 17, 50), (64, 200, 1000, 3), (320, 13
 if "--time" in sys.argv:
     a, b = C.c_float(), C.c_float()
     for K in (6400, 12800, 51200):
-        for which, slabs in ((0, 32), (0, 64), (0, 128), (0, 200), (0, 247), (0, 256), (1, 64), (1, 128), (2, 16)):
+        for which, slabs in ((0, 32), (0, 64), (0, 100), (0, 128), (2, 16)):
             if which == 0 and slabs > K // 32: continue
             ca._lib.check(L.nvsm_debug_dt_time(300, 256, K, slabs, 30, which, C.byref(a), C.byref(b)))
             print("rows %6d which %d slabs %4d: product %7.1f us  reduce %6.1f us" % (K, which, slabs, a.value * 1e3, b.value * 1e3), flush=True)

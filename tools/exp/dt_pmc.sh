@@ -19,7 +19,7 @@ for CTRS in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYC
   i=$((i+1)); cd /tmp
   rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/run$i -o g -- python $OUT/run.py > $OUT/out$i.txt 2> $OUT/err$i.txt
   cd $ROOT; DB=$(find $OUT/run$i -name "*.db" | head -1)
-  if [ -n "$DB" ]; then python tools/pmc_dump.py $DB gemm_dtp >> gpurun_out/dtp_pmc.txt; else echo "pass $i failed: $(tail -2 $OUT/err$i.txt)" >> gpurun_out/dtp_pmc.txt; fi
+  if [ -n "$DB" ]; then python tools/pmc_dump.py $DB gemm_dt >> gpurun_out/dtp_pmc.txt; else echo "pass $i failed: $(tail -2 $OUT/err$i.txt)" >> gpurun_out/dtp_pmc.txt; fi
   rm -rf $OUT/run$i
 done
 cat gpurun_out/dtp_pmc.txt

@@ -99,6 +99,13 @@ __device__ unsigned long long g_split_times[1024 * 8];
 #endif
 constexpr int kSplitEpiStats = 1, kSplitEpiRowsq = 2, kSplitEpiBias = 4;
 
+// a - b as ONE v_sub_f32: as vector arithmetic (or SLP-vectorised) the two subtractions of a pair become v_pk_add_f32, and
+// packed fp32 VALU is slow next to MFMAs (MI355X_MICROARCH.md: "packed f32 VALU ... an anti-lever beside MFMAs"; gemm_dt.hip)
+__device__ __forceinline__ float split_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // x0, x1 -> one 32-bit word per plane, x0's piece in the lower half (element 2j of a fragment), x1's in the upper
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
     // round-to-nearest pieces (v_cvt_pk_bf16_f32: two elements per instruction): h = bf16(x), m = bf16(x - h), l = x - h - m.
@@ -107,12 +114,11 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
     // sign): the partial products a six-product run leaves out are below 2^-26 of a·b and of either sign.
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t v = {x0, x1};
-    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-    const f32x2_t r = v - f32x2_t{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
-    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
-    const f32x2_t s2 = r - f32x2_t{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
-    l = __builtin_bit_cast(unsigned, __builtin_convertvector(s2, bf16x2_t));
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t));
+    const float r0 = split_sub(x0, __uint_as_float(h << 16)), r1 = split_sub(x1, __uint_as_float(h & 0xffff0000u));
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
+    const float s0 = split_sub(r0, __uint_as_float(m << 16)), s1 = split_sub(r1, __uint_as_float(m & 0xffff0000u));
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t));
 }
 
 struct SplitFrag { u32x4 h, m, l; };

@@ -519,6 +519,34 @@ def main():
                 med, st = leg_value(leg)
                 secondary["full_adam"] = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), **st)
                 del leg
+            # (e') the other BASELINE configs that fit one GPU, on engines of their own: configs[4]'s tables at the metric's batch
+            #      (|V| = 500 k, |D| = 2 M: E is 2 GB, i.e. the document gather comes out of HBM proper, not the Infinity Cache —
+            #      its loss-kernel roofline is reported here) and configs[3] (LSE, batch 4 096, Adagrad)
+            if args.config == "nvsm" and Bg == 51200 and method == "sparse_adam":
+                for name in ("large_tables", "lse_small"):
+                    wl2 = dict(num_words=50000, num_entities=100000, word_dim=300, entity_dim=256, window=10, num_random=16, batch=51200,
+                               nonlinearity="hard_tanh", batch_norm=1, bias_negative_samples=0, lr=1e-3, update_method="sparse_adam")
+                    wl2.update(PRESETS[name])
+                    m2, B2 = wl2.pop("update_method"), wl2["batch"]
+                    leg = Leg(env, wl2, m2, B2)
+                    leg.run_steps(max(5, args.warmup))
+                    leg.model.profile_enable(True)
+                    leg.model.profile_select(ROOFLINE_KERNEL)
+                    leg.model.profile_reset()
+                    med, st = leg_value(leg, repeats=3)
+                    pr = leg.model.profile()
+                    leg.model.profile_enable(False)
+                    ent = dict(value=round(B2 * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), batch=B2, update_method=m2,
+                               workload="|V|=%d |D|=%d d_word=%d d_doc=%d" % (wl2["num_words"], wl2["num_entities"], wl2["word_dim"], wl2["entity_dim"]), **st)
+                    if pr.get(ROOFLINE_KERNEL, (0, 0))[1] > 0:
+                        avg2 = pr[ROOFLINE_KERNEL][0] / pr[ROOFLINE_KERNEL][1]
+                        ab2 = algorithmic_bytes(ROOFLINE_KERNEL, wl2, m2, B2)
+                        ent["roofline"] = {"kernel": ROOFLINE_KERNEL, "bound": "hbm", "achieved": round(ab2 / (avg2 * 1e-3) / 1e9, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab2 / (avg2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "avg_launch_ms": round(avg2, 4), "algorithmic_bytes_per_launch": ab2, "traffic": None,
+                                           "note": "in-step time of the kernel (events riding on its launch)"}
+                    secondary[name] = ent
+                    del leg
             if secondary:
                 extra["secondary"] = secondary
             # (e) the per-rank share of the N-GPU metric (51 200 / N windows per rank) on this one GPU, each
@@ -562,7 +590,7 @@ def main():
         ms_per_step, tstats = ms_stats(times, args.steps)
         global_batch = Bg if (headline_strong or world == 1) else Bg * world
         value = global_batch * 1e3 / ms_per_step
-        scaling = "strong" if headline_strong else "weak"
+        scaling = "single" if world == 1 else ("strong" if headline_strong else "weak")
         this_fig = dict(value=round(value, 1), unit="windows/s", ms_per_step=round(ms_per_step, 4), scaling=scaling,
                         global_batch=global_batch, batch_per_rank=B, steps=args.steps, **tstats)
         # a lazily decayed table's row passes only read and write the rows the batch touches (the engine notes a
@@ -596,14 +624,9 @@ def main():
                 ent["TFLOPs"] = round(gemm_flops(wl, B) / (avg * 1e-3) / 1e12, 1)
                 ent["over_f32_mfma_peak"] = round(ent["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 3)      # 157.3 TF/s: what exact-fp32 MFMAs could do at best
                 nprod = gemm_split_products(B)
-                # (the dT product runs the split kernel, on the main stream, for large batches of eagerly decayed tables only:
-                #  model.cpp step(); a table decays lazily from 96 MB of sparse-Adam state — 384 MB otherwise — when it has
-                #  at least half as many rows as a batch has entries)
-                def lazy(rows_, dim_, entries_):
-                    state_mb = rows_ * dim_ * 4 * (2 if "adam" in method else 1) / 2 ** 20
-                    return state_mb >= (96 if method == "sparse_adam" else 384) and rows_ * 2 >= entries_
-                if k == "gemm_bwd_T" and not (B >= 40960 and not lazy(wl["num_words"], wl["word_dim"], B * wl["window"])
-                                              and not lazy(wl["num_entities"], wl["entity_dim"], B * (wl["num_random"] + 1))):
+                # (the dT product runs the split-bf16 kernel — gemm_dt.hip — from batch 40 960 on, the tiled exact-fp32 kernel
+                #  below: model.cpp use_dt())
+                if k == "gemm_bwd_T" and B < 40960:
                     nprod = 0
                 if nprod:
                     ent["arithmetic"] = "f32 as 3 bf16 planes, %d of 9 partial products, f32 accumulation" % nprod
@@ -615,7 +638,8 @@ def main():
         # largest kernel of the step that runs with nothing else next to it but the (tiny) side-stream sorts. In the fused
         # step the documents update / dT GEMM overlap the dx GEMM / words update on a second stream; their event-timed
         # durations (marked "overlapped") include the time they share the chip and are not per-kernel roofline figures.
-        for k in (() if args.sequential else ("update_entities", "row_pass_entities", "gemm_bwd_T", "transform_update", "csr_entities", "csr_words")):
+        # (gemm_bwd_T and its slab reduce are timed by events riding on their launches: the kernels' own execution times)
+        for k in (() if args.sequential else ("update_entities", "row_pass_entities", "transform_update", "csr_entities", "csr_words")):
             if k in breakdown:
                 breakdown[k]["overlapped"] = True
         have = lambda k: prof_timed.get(k, (0, 0))[1] > 0
@@ -655,7 +679,11 @@ def main():
             "metric": "n-gram windows/sec (batch=51200, NVSM config)" if args.config == "nvsm" and Bg == 51200
                       else "n-gram windows/sec (--config %s, batch=%d)" % (args.config, Bg), "value": round(value, 1), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+            "dtype_detail": ("f32 storage and accumulation; the three projection products multiply f32 operands as 3 exact bf16 planes, "
+                             "%d of 9 partial products, on the bf16 matrix pipe (DESIGN 4.1)" % gemm_split_products(B)) if gemm_split_products(B)
+                            else "f32 throughout (exact-f32 MFMA kernels at this batch size)",
+            "data": "synthetic",
             "config": {"workload": "%s synthetic |V|=%d |D|=%d d_word=%d d_doc=%d window=%d neg=%d global batch=%d (%d/GPU) "
                                    "%s%s %s lambda=1e-2 lr=%g %s word ids, inputs %s, device negative sampler"
                                    % ("NVSM" if wl["batch_norm"] else "LSE", wl["num_words"], wl["num_entities"], wl["word_dim"],
@@ -665,6 +693,9 @@ def main():
                                       "handed over as page-locked host buffers" if args.host_batches else "resident in HBM"),
                        "global_batch": global_batch, "batch_per_rank": B, "parallelism": "dp%d" % world, "update_method": method,
                        "collectives": main_leg.transport, "comm_ranks": main_leg.comm_ranks,
+                       # per step and rank under data parallelism: [Σx | Σx²] (f64, forward, batch-norm only), [loss | Σdy | Σdy·x̂]
+                       # (f64, backward), dT (f32, 307 KB) — DESIGN.md §6
+                       "collectives_per_step": 0 if world == 1 else (3 if wl["batch_norm"] else 2),
                        "inputs": "host" if args.host_batches else "hbm", "step": "sequential calls" if args.sequential else "fused nvsm_step",
                        "workload_signature": sig},
             "timing": tstats,

@@ -103,6 +103,16 @@ __device__ __forceinline__ double ld_agent_f64(const double* p) {
 // Which workgroup that is varies; what it computes does not: results are the same bits every run. Counters return to
 // zero for the next launch. part [total][n], part2 [ceil(total / fan)][n], arrive [ceil(total / fan) + 1] (zero before
 // the first launch). Every thread of the workgroup must call it; `flag` is one int of LDS; nothing block-wide may follow.
+// Memory order of the hand-over: the vectors travel as agent-scope write-through stores (st_agent1), every wave drains its
+// stores (s_waitcnt vmcnt(0): on gfx9 / CDNA, stores count in vmcnt and a store has reached the agent-coherent L2 when the
+// counter lets go), the workgroup meets, and only then one lane bumps the counter with a RELAXED agent-scope atomic; the last
+// arriver reads the vectors with agent-scope loads. That is correct on gfx90a / gfx942 / gfx950 as written and is NOT what the
+// HIP memory model promises in general (it would ask for a release on the bump and an acquire on the last arriver — an L2
+// write-back and an invalidate per workgroup, which the write-through / cache-bypassing accesses make redundant here). Targets
+// that count stores in a separate counter (vscnt: gfx10+) would let the last arriver read stale vectors: refused below.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "grid_sum_ordered orders its hand-over with s_waitcnt vmcnt(0) + relaxed agent-scope atomics: valid on gfx90a / gfx942 / gfx950 only"
+#endif
 template <int THREADS, class Val, class Out>
 __device__ __forceinline__ void grid_sum_ordered(float* part, double* part2, int* arrive, int fan, int n, int me, int total,
                                                  Val val, Out out, int* flag) {

@@ -524,14 +524,14 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
     if (rowsq && split_k <= 1) {
         if (fast && a_layout == 0 && b_layout == 1 && !g.colstats) {
             g.rowsq = rowsq;
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, 1, true, true>), grid, block, lds_pad, s, g);
+            NVSM_LAUNCH((gemm_f32_mfma_kernel<0, 1, true, true>), grid, block, lds_pad, s, g);
             return;
         }
     }
 #define NVSM_GEMM_CASE(AL, BL)                                                                              \
     if (a_layout == AL && b_layout == BL) {                                                                 \
-        if (fast) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AL, BL, true>), grid, block, lds_pad, s, g);     \
-        else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AL, BL, false>), grid, block, 0, s, g);               \
+        if (fast) NVSM_LAUNCH((gemm_f32_mfma_kernel<AL, BL, true>), grid, block, lds_pad, s, g);     \
+        else NVSM_LAUNCH((gemm_f32_mfma_kernel<AL, BL, false>), grid, block, 0, s, g);               \
     }
     NVSM_GEMM_CASE(0, 0) NVSM_GEMM_CASE(0, 1) NVSM_GEMM_CASE(1, 0) NVSM_GEMM_CASE(1, 1)
 #undef NVSM_GEMM_CASE
@@ -582,9 +582,9 @@ void launch_splitk_reduce(const float* partial, int slabs, size_t stride, float*
                      (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     if (vec) {
         const int64_t n4 = n / 4;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((n4 + 15) / 16)), dim3(256), 0, s, partial, slabs, stride, out, n4);
+        NVSM_LAUNCH(splitk_reduce_kernel, dim3(static_cast<unsigned>((n4 + 15) / 16)), dim3(256), 0, s, partial, slabs, stride, out, n4);
     } else {
-        hipLaunchKernelGGL(splitk_reduce_scalar_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, partial, slabs, stride, out, n);
+        NVSM_LAUNCH(splitk_reduce_scalar_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, partial, slabs, stride, out, n);
     }
 }
 

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(PanelArgs g) {
 template <int ALAY, int BLAY, int TM, int TN, int PBK>
 static void launch_panel(const PanelArgs& g, hipStream_t s) {
     const int grid = g.mpanels * g.npanels * g.slabs;
-    hipLaunchKernelGGL((gemm_panel_kernel<ALAY, BLAY, TM, TN, PBK>), dim3(grid), dim3(256), 0, s, g);
+    NVSM_LAUNCH((gemm_panel_kernel<ALAY, BLAY, TM, TN, PBK>), dim3(grid), dim3(256), 0, s, g);
 }
 
 // Returns true when the panel kernel took the GEMM; false → the caller uses the tiled kernel.

@@ -556,6 +556,12 @@ void Model::raise_device_error() {
     const int code = *static_cast<volatile int*>(err_host_);
     if (code == 0) return;
     *err_host_ = 0;
+    // The arrival counters of the ordered sums and of the one-launch table passes return to zero at the end of every launch
+    // that runs to completion; a launch that flagged an error may have left some behind, and every later sum would silently
+    // add the wrong partials: clear them before the caller goes on (all streams are quiet when an error is raised).
+    for (DevBuf<int>* b : {&sums_fwd_.arrive, &sums_bwd_.arrive, &words_.arrive_row, &words_.arrive2, &ents_.arrive_row, &ents_.arrive2})
+        if (b->p) (void)hipMemset(b->p, 0, b->n * sizeof(int));
+    (void)hipDeviceSynchronize();
     if (code == NVSM_BAD_WORD_ID) throw Error(NVSM_ERR_INVALID_ARGUMENT, "a word id of the batch is outside [0, num_words)");
     if (code == NVSM_BAD_ENTITY_ID) throw Error(NVSM_ERR_INVALID_ARGUMENT, "a document id of the batch is outside [0, num_entities)");
     if (code == NVSM_SORT_TIMEOUT) throw Error(NVSM_ERR_DEVICE, "the row sort's grid-wide wait timed out (workgroups not co-resident?)");
@@ -1301,11 +1307,15 @@ void Model::backward_T(hipStream_t strm) {
     const int64_t B = B_;
     const bool dp = cfg_.world_size > 1;
     {
-        PROF_ON("gemm_bwd_T", strm);
+        // (timed by events that ride on the launches themselves: the product's and the slab reduce's own execution times, which
+        //  is what a kernel trace reports — a record pair around the group on a side stream timed the wait for CUs as well)
         const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
         const size_t stride = static_cast<size_t>(de) * dw;
+        auto reduce = [&](int n) {
+            timed_launch(prof, "gemm_bwd_T_reduce", strm, true, [&] { launch_splitk_reduce(gT_partial_.p, n, stride, gT_.p, static_cast<int64_t>(stride), strm); });
+        };
         if (use_dt()) {
-            // the split-K product on the bf16 matrix pipe (gemm_dt.hip): two workgroups per slab, a slab per two CUs at most
+            // the split-K product on the bf16 matrix pipe (gemm_dt.hip): two workgroups per slab.
             // Slabs: the kernel ALONE is fastest with a workgroup on every CU (128 slabs: 55 us at batch 51 200), but in a step it
             // runs next to the documents pass, which wants the CUs it leaves free and the bandwidth its partials do not take: on
             // the main stream 48 slabs (96 workgroups, 15 MB of partials) — 0.891 ms per step against 0.90 with 128 and 0.899 with
@@ -1313,16 +1323,24 @@ void Model::backward_T(hipStream_t strm) {
             // 16 (|D| = 2 M: 1.61 ms against 1.65 with 128). Interleaved A/B, tools/ab_shapes.sh.
             const int want = std::min(strm == stream_ ? 48 : 16, gemm_dt_default_slabs(static_cast<int>(B), num_cus_));
             const int dslabs = gemm_dt_slabs(static_cast<int>(B), want);
-            if (!launch_gemm_dt(phrase_p_, dy_.p, dslabs == 1 ? gT_.p : gT_partial_.p, dw, de, static_cast<int>(B), dw, de, want, strm))
-                throw Error(NVSM_ERR_UNSUPPORTED, "dT product refused a shape its caller had checked");
-            if (dslabs > 1) launch_splitk_reduce(gT_partial_.p, dslabs, stride, gT_.p, static_cast<int64_t>(stride), strm);
+            bool ok = true;
+            timed_launch(prof, "gemm_bwd_T", strm, true, [&] {
+                ok = launch_gemm_dt(phrase_p_, dy_.p, dslabs == 1 ? gT_.p : gT_partial_.p, dw, de, static_cast<int>(B), dw, de, want, strm);
+            });
+            if (!ok) throw Error(NVSM_ERR_UNSUPPORTED, "dT product refused a shape its caller had checked");
+            prof.note("dt_split_bf16");
+            if (dslabs > 1) reduce(dslabs);
         } else if (slabs == 1) {
-            launch_gemm(1, 0, phrase_p_, dy_.p, gT_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr, 1, 0, strm);
+            timed_launch(prof, "gemm_bwd_T", strm, true, [&] {
+                launch_gemm(1, 0, phrase_p_, dy_.p, gT_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr, 1, 0, strm);
+            });
         } else {
-            launch_gemm(1, 0, phrase_p_, dy_.p, gT_partial_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr,
-                        gemm_slabs_want_, stride, strm, nullptr, nullptr, 0.f, nullptr,
-                        /*busy_chip=*/strm != stream_);      // fused step: next to the words / documents update
-            launch_splitk_reduce(gT_partial_.p, slabs, stride, gT_.p, static_cast<int64_t>(stride), strm);
+            timed_launch(prof, "gemm_bwd_T", strm, true, [&] {
+                launch_gemm(1, 0, phrase_p_, dy_.p, gT_partial_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr,
+                            gemm_slabs_want_, stride, strm, nullptr, nullptr, 0.f, nullptr,
+                            /*busy_chip=*/strm != stream_);      // fused step: next to the words / documents update
+            });
+            reduce(slabs);
         }
     }
     // data parallel: one all-reduce of the dense projection gradient over xGMI

@@ -172,7 +172,13 @@ float nvsm_scaled_regularization_lambda(nvsm_model* m);
  * scaled lambda; fully asynchronous. cost may be NULL (no read-back, no sync). With a cost pointer the call returns once
  * the step's loss kernel has run and its loss word has been copied out (single GPU: the backward pass and the updates
  * are still running then, and the caller can queue the next step); under data parallelism, where the word is summed
- * over the ranks in the backward pass, it waits for the step as nvsm_get_cost does. */
+ * over the ranks in the backward pass, it waits for the step as nvsm_get_cost does.
+ * LIFETIME of a device-resident batch (batch->on_device): the word update reads batch->feature_weights — and the loss
+ * kernel batch->weights — long after the prologue has consumed the ids, and nvsm_step(cost) returns BEFORE the updates have
+ * run: the caller must leave all four arrays untouched until nvsm_synchronize — or, when the handle runs on the caller's own
+ * stream (nvsm_set_stream), order the refill on that stream behind the step (everything that reads the batch is on that stream
+ * or joined to it by the next call on the handle). Double-buffer device batches otherwise. nvsm_wait_inputs covers host batches
+ * only. Errors flagged by the backward and update kernels of a step surface at the next call that waits. */
 int nvsm_step(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids, float learning_rate, float* cost);
 
 /* The same step for training loops that want the loss of EVERY batch, as cpp/main.cu:427-444 does, without putting the

@@ -40,7 +40,7 @@ def test_bench_single_gpu_line():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert REQUIRED <= set(d)
-    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "single" and d["dtype"] == "f32" and "bf16 planes" in d["dtype_detail"]
     assert d["value"] > 1e6 and abs(d["value"] - 51200 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
     # the median of `repeats` timed regions of exactly `steps` steps each, all of them in the line
     t = d["timing"]
@@ -53,6 +53,14 @@ def test_bench_single_gpu_line():
     assert set(d["per_rank_shapes"]) == {"6400", "12800", "25600"} and d["per_rank_shapes"]["6400"]["ms_per_step"] > 0
     assert d["strong_projection_8gpu"]["speedup_over_1gpu"] > 1.0
     assert d["secondary"]["full_adam"]["value"] > 1e6 and d["secondary"]["uniform_words"]["value"] > 1e6
+    # every BASELINE config that fits one GPU is in the line: configs[4]'s tables (E out of the Infinity Cache: its own loss-kernel
+    # roofline) and configs[3]
+    lt, ls = d["secondary"]["large_tables"], d["secondary"]["lse_small"]
+    assert lt["batch"] == 51200 and lt["ms_per_step"] > d["ms_per_step"] and 0.2 < lt["roofline"]["frac"] < 1.0
+    assert ls["batch"] == 4096 and ls["update_method"] == "adagrad" and 0 < ls["ms_per_step"] < 1.0
+    # the dT product is timed by its own launch: a kernel time, below the backward product's + the loss kernel's
+    assert not d["kernel_breakdown"]["gemm_bwd_T"].get("overlapped")
+    assert d["kernel_breakdown"]["gemm_bwd_T"]["avg_ms"] < d["kernel_breakdown"]["loss_fused"]["avg_ms"]
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.3 < roof["frac"] < 1.0

@@ -42,6 +42,17 @@ SPEC_NOBN = dict(SPEC, batch_norm=False, nonlinearity="tanh", bias_negative_samp
 SPEC_WIDE = dict(SPEC, num_words=2000, num_entities=3000, word_dim=300, entity_dim=256, window=4, num_random=3)
 
 
+def _connect(m, dist, rank, transport):
+    """the handle's collectives: gloo through the host callback (ranks share GPU 0), or the engine's own RCCL communicator (one
+    rank per device: tests/test_dp_rccl.py)"""
+    from cunvsm_amd import dp
+    if transport == "rccl":
+        dp.init_rccl(m, dist, rank)
+        assert m.comm_size() == WORLD
+    else:
+        m.set_allreduce_callback(dp.torch_allreduce(dist))
+
+
 def _worker_oracle(rank, port, spec, B, out_dir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -95,7 +106,7 @@ def test_shard_batch_rules():
         dp.shard_bounds(9, 0, 2)
 
 
-def _worker_gpu(rank, port, spec, B, out_dir):
+def _worker_gpu(rank, port, spec, B, out_dir, transport="gloo"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import cunvsm_amd as ca
@@ -104,9 +115,9 @@ def _worker_gpu(rank, port, spec, B, out_dir):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
     params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
     w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
-    m = gpu_model(spec, B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0)
+    m = gpu_model(spec, B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=rank if transport == "rccl" else 0)
     load_params(m, params, True)
-    m.set_allreduce_callback(dp.torch_allreduce(dist))
+    _connect(m, dist, rank, transport)
     m.compute_cost(ca.Batch(w, wl, wwt, wi), wid)
     m.compute_gradients()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), cost=m.get_cost(), gT=m.get_tensor("grad_transform"),
@@ -138,7 +149,7 @@ def test_dp_hip_equals_single_gpu(spec, B, tmp_path):
     assert rel_err(np.concatenate([r[0]["gphrase"], r[1]["gphrase"]]), ref.get_tensor("grad_phrase")) < 1e-5
 
 
-def _worker_gpu_step(rank, port, spec, B, out_dir, exact=False):
+def _worker_gpu_step(rank, port, spec, B, out_dir, exact=False, transport="gloo"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import cunvsm_amd as ca
@@ -147,9 +158,10 @@ def _worker_gpu_step(rank, port, spec, B, out_dir, exact=False):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
     params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
     w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
-    m = gpu_model(spec, B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0, dp_exact_tables=int(exact))
+    m = gpu_model(spec, B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=rank if transport == "rccl" else 0,
+                  dp_exact_tables=int(exact))
     load_params(m, params, True)
-    m.set_allreduce_callback(dp.torch_allreduce(dist))
+    _connect(m, dist, rank, transport)
     costs = [m.step(ca.Batch(w, wl, wwt, wi), 0.05, entity_ids=wid, want_cost=True)]
     T_after_1 = m.get_param("word_entity_mapping-transform")
     for _ in range(3):
@@ -226,7 +238,7 @@ def _traj_batches(spec):
     return params, batches
 
 
-def _worker_traj(rank, port, spec, out_dir, use_gpu, exact=False, lr=None, separate_calls=False):
+def _worker_traj(rank, port, spec, out_dir, use_gpu, exact=False, lr=None, separate_calls=False, transport="gloo"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from cunvsm_amd import dp
@@ -235,9 +247,10 @@ def _worker_traj(rank, port, spec, out_dir, use_gpu, exact=False, lr=None, separ
     params, batches = _traj_batches(spec)
     if use_gpu:
         import cunvsm_amd as ca
-        m = gpu_model(spec, TRAJ_B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=0, dp_exact_tables=int(exact))
+        m = gpu_model(spec, TRAJ_B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=1, device=rank if transport == "rccl" else 0,
+                      dp_exact_tables=int(exact))
         load_params(m, params, True)
-        m.set_allreduce_callback(dp.torch_allreduce(dist))
+        _connect(m, dist, rank, transport)
     else:
         m = oracle_model(spec)
         load_params(m, params, False)

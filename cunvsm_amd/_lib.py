@@ -107,6 +107,7 @@ def lib():
         "nvsm_deferred_cost": (C.c_int, [vp, i64, P(C.c_float)]), "nvsm_wait_inputs": (C.c_int, [vp]),
         "nvsm_tensor_size": (C.c_int, [vp, cp, P(i64)]), "nvsm_get_tensor": (C.c_int, [vp, cp, vp, i64]),
         "nvsm_set_stream": (C.c_int, [vp, vp]), "nvsm_synchronize": (C.c_int, [vp]),
+        "nvsm_describe": (C.c_int, [vp, C.c_int64, C.c_char_p, C.c_int64]),
         "nvsm_comm_unique_id": (C.c_int, [vp]), "nvsm_comm_init": (C.c_int, [vp, vp]),
         "nvsm_set_allreduce_callback": (C.c_int, [vp, ALLREDUCE_FN, vp]),
         "nvsm_comm_size": (C.c_int, [vp, P(C.c_int)]), "nvsm_dp_average_tables": (C.c_int, [vp]),

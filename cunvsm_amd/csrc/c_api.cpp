@@ -41,6 +41,20 @@ static int guarded(Fn&& fn) {
     }
 }
 
+// a call on a handle runs under the handle's switches (tuning.h): read once, by nvsm_create
+template <typename Fn>
+static int guarded_on(nvsm_model* m, Fn&& fn) {
+    cunvsm::TuningScope scope(&m->impl.tune());
+    return guarded(fn);
+}
+// a debug hook (no handle) reads the environment itself, per call: tests switch variables between calls
+template <typename Fn>
+static int guarded_hook(Fn&& fn) {
+    const cunvsm::Tuning t = cunvsm::Tuning::from_env();
+    cunvsm::TuningScope scope(&t);
+    return guarded(fn);
+}
+
 #define NVSM_REQUIRE(ptr)                                          \
     if (!(ptr)) {                                                  \
         g_last_error = "null argument: " #ptr;                     \
@@ -83,91 +97,99 @@ void nvsm_destroy(nvsm_model* m) {
     try { delete m; } catch (...) {}
 }
 
-int nvsm_initialize(nvsm_model* m, uint64_t seed) { NVSM_REQUIRE(m); return guarded([&] { m->impl.initialize(seed); }); }
-int nvsm_initialize_from_rng_state(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.initialize_from_rng_state(); }); }
+int nvsm_initialize(nvsm_model* m, uint64_t seed) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.initialize(seed); }); }
+int nvsm_initialize_from_rng_state(nvsm_model* m) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.initialize_from_rng_state(); }); }
 int nvsm_host_alloc(size_t bytes, void** out) {
     NVSM_REQUIRE(out);
     *out = nullptr;
     return guarded([&] { NVSM_HIP_CHECK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault)); });
 }
 int nvsm_host_free(void* p) { return guarded([&] { if (p) NVSM_HIP_CHECK(hipHostFree(p)); }); }
-int nvsm_rng_get_state(nvsm_model* m, uint64_t* state) { NVSM_REQUIRE(m); NVSM_REQUIRE(state); return guarded([&] { *state = m->impl.rng_get_state(); }); }
-int nvsm_rng_set_state(nvsm_model* m, uint64_t state) { NVSM_REQUIRE(m); return guarded([&] { m->impl.rng_set_state(state); }); }
+int nvsm_rng_get_state(nvsm_model* m, uint64_t* state) { NVSM_REQUIRE(m); NVSM_REQUIRE(state); return guarded_on(m, [&] { *state = m->impl.rng_get_state(); }); }
+int nvsm_rng_set_state(nvsm_model* m, uint64_t state) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.rng_set_state(state); }); }
 
 int nvsm_param_size(nvsm_model* m, const char* name, int64_t* count) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(count);
-    return guarded([&] { *count = m->impl.param_size(name); });
+    return guarded_on(m, [&] { *count = m->impl.param_size(name); });
 }
 int nvsm_get_param(nvsm_model* m, const char* name, float* dst, int64_t count) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(dst);
-    return guarded([&] { m->impl.get_param(name, dst, count); });
+    return guarded_on(m, [&] { m->impl.get_param(name, dst, count); });
 }
 int nvsm_set_param(nvsm_model* m, const char* name, const float* src, int64_t count) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(src);
-    return guarded([&] { m->impl.set_param(name, src, count); });
+    return guarded_on(m, [&] { m->impl.set_param(name, src, count); });
 }
 
 int nvsm_increment_parameter(nvsm_model* m, const char* name, int64_t index, float delta) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(name);
-    return guarded([&] { m->impl.increment_param(name, index, delta); });
+    return guarded_on(m, [&] { m->impl.increment_param(name, index, delta); });
 }
 
 int nvsm_compute_cost(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(batch);
-    return guarded([&] { m->impl.compute_cost(*batch, entity_ids); });
+    return guarded_on(m, [&] { m->impl.compute_cost(*batch, entity_ids); });
 }
-int nvsm_compute_gradients(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.compute_gradients(); }); }
-int nvsm_update(nvsm_model* m, float lr, float scaled_lambda) { NVSM_REQUIRE(m); return guarded([&] { m->impl.update(lr, scaled_lambda); }); }
-int nvsm_get_cost(nvsm_model* m, float* cost) { NVSM_REQUIRE(m); NVSM_REQUIRE(cost); return guarded([&] { *cost = m->impl.get_cost(); }); }
-int nvsm_get_cost_f64(nvsm_model* m, double* cost) { NVSM_REQUIRE(m); NVSM_REQUIRE(cost); return guarded([&] { (void)m->impl.get_cost(); *cost = m->impl.cost_f64(); }); }
+int nvsm_compute_gradients(nvsm_model* m) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.compute_gradients(); }); }
+int nvsm_update(nvsm_model* m, float lr, float scaled_lambda) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.update(lr, scaled_lambda); }); }
+int nvsm_get_cost(nvsm_model* m, float* cost) { NVSM_REQUIRE(m); NVSM_REQUIRE(cost); return guarded_on(m, [&] { *cost = m->impl.get_cost(); }); }
+int nvsm_get_cost_f64(nvsm_model* m, double* cost) { NVSM_REQUIRE(m); NVSM_REQUIRE(cost); return guarded_on(m, [&] { (void)m->impl.get_cost(); *cost = m->impl.cost_f64(); }); }
 float nvsm_scaled_regularization_lambda(nvsm_model* m) { return m ? m->impl.scaled_regularization_lambda() : 0.f; }
 int nvsm_step(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids, float lr, float* cost) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(batch);
-    return guarded([&] { m->impl.step(*batch, entity_ids, lr, cost); });
+    return guarded_on(m, [&] { m->impl.step(*batch, entity_ids, lr, cost); });
 }
 
 int nvsm_step_deferred(nvsm_model* m, const nvsm_batch* batch, const int64_t* entity_ids, float lr, int64_t* ticket) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(batch); NVSM_REQUIRE(ticket);
-    return guarded([&] { *ticket = m->impl.step_deferred(*batch, entity_ids, lr); });
+    return guarded_on(m, [&] { *ticket = m->impl.step_deferred(*batch, entity_ids, lr); });
 }
 int nvsm_deferred_cost(nvsm_model* m, int64_t ticket, float* cost) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(cost);
-    return guarded([&] { *cost = m->impl.deferred_cost(ticket); });
+    return guarded_on(m, [&] { *cost = m->impl.deferred_cost(ticket); });
 }
-int nvsm_wait_inputs(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.wait_inputs(); }); }
+int nvsm_wait_inputs(nvsm_model* m) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.wait_inputs(); }); }
 
 int nvsm_tensor_size(nvsm_model* m, const char* name, int64_t* count) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(count);
-    return guarded([&] { *count = m->impl.tensor_size(name); });
+    return guarded_on(m, [&] { *count = m->impl.tensor_size(name); });
 }
 int nvsm_get_tensor(nvsm_model* m, const char* name, float* dst, int64_t count) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(name); NVSM_REQUIRE(dst);
-    return guarded([&] { m->impl.get_tensor(name, dst, count); });
+    return guarded_on(m, [&] { m->impl.get_tensor(name, dst, count); });
 }
 
-int nvsm_set_stream(nvsm_model* m, void* s) { NVSM_REQUIRE(m); return guarded([&] { m->impl.set_stream(static_cast<hipStream_t>(s)); }); }
-int nvsm_synchronize(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.synchronize(); }); }
+int nvsm_set_stream(nvsm_model* m, void* s) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.set_stream(static_cast<hipStream_t>(s)); }); }
+int nvsm_describe(nvsm_model* m, int64_t batch, char* buf, int64_t buf_bytes) {
+    NVSM_REQUIRE(m); NVSM_REQUIRE(buf);
+    return guarded_on(m, [&] {
+        const std::string d = m->impl.describe(batch);
+        if (static_cast<int64_t>(d.size()) + 1 > buf_bytes) throw Error(NVSM_ERR_INVALID_ARGUMENT, "buffer too small");
+        std::memcpy(buf, d.c_str(), d.size() + 1);
+    });
+}
+int nvsm_synchronize(nvsm_model* m) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.synchronize(); }); }
 
 int nvsm_comm_unique_id(char id[128]) { NVSM_REQUIRE(id); return guarded([&] { cunvsm::rccl_unique_id(id); }); }
-int nvsm_comm_init(nvsm_model* m, const char id[128]) { NVSM_REQUIRE(m); NVSM_REQUIRE(id); return guarded([&] { m->impl.comm_init(id); }); }
-int nvsm_comm_size(nvsm_model* m, int* ranks) { NVSM_REQUIRE(m); NVSM_REQUIRE(ranks); return guarded([&] { *ranks = m->impl.comm_ranks(); }); }
-int nvsm_dp_average_tables(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.average_tables(); }); }
+int nvsm_comm_init(nvsm_model* m, const char id[128]) { NVSM_REQUIRE(m); NVSM_REQUIRE(id); return guarded_on(m, [&] { m->impl.comm_init(id); }); }
+int nvsm_comm_size(nvsm_model* m, int* ranks) { NVSM_REQUIRE(m); NVSM_REQUIRE(ranks); return guarded_on(m, [&] { *ranks = m->impl.comm_ranks(); }); }
+int nvsm_dp_average_tables(nvsm_model* m) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.average_tables(); }); }
 void nvsm_range_push(const char* name) { if (name) cunvsm::range_push(name); }
 void nvsm_range_pop(void) { cunvsm::range_pop(); }
-int nvsm_comm_selftest(int device) { return guarded([&] { cunvsm::rccl_selftest(device); }); }
+int nvsm_comm_selftest(int device) { return guarded_hook([&] { cunvsm::rccl_selftest(device); }); }
 int nvsm_set_allreduce_callback(nvsm_model* m, nvsm_allreduce_fn fn, void* user) {
     NVSM_REQUIRE(m);
-    return guarded([&] { m->impl.set_allreduce_callback(fn, user); });
+    return guarded_on(m, [&] { m->impl.set_allreduce_callback(fn, user); });
 }
 
 int nvsm_debug_set_table_pass_form(int one_launch) { cunvsm::set_table_pass_one_launch(one_launch != 0); return NVSM_OK; }
-int nvsm_debug_delay(nvsm_model* m, int microseconds) { NVSM_REQUIRE(m); return guarded([&] { m->impl.debug_delay(microseconds); }); }
-int nvsm_profile_enable(nvsm_model* m, int enable) { NVSM_REQUIRE(m); return guarded([&] { m->impl.synchronize(); m->impl.prof.enabled = enable != 0; }); }
+int nvsm_debug_delay(nvsm_model* m, int microseconds) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.debug_delay(microseconds); }); }
+int nvsm_profile_enable(nvsm_model* m, int enable) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.synchronize(); m->impl.prof.enabled = enable != 0; }); }
 int nvsm_profile_select(nvsm_model* m, const char* kernel) {
     NVSM_REQUIRE(m);
-    return guarded([&] { m->impl.synchronize(); m->impl.prof.only = kernel ? kernel : ""; });
+    return guarded_on(m, [&] { m->impl.synchronize(); m->impl.prof.only = kernel ? kernel : ""; });
 }
-int nvsm_profile_reset(nvsm_model* m) { NVSM_REQUIRE(m); return guarded([&] { m->impl.synchronize(); m->impl.prof.reset(); }); }
+int nvsm_profile_reset(nvsm_model* m) { NVSM_REQUIRE(m); return guarded_on(m, [&] { m->impl.synchronize(); m->impl.prof.reset(); }); }
 int nvsm_profile_names(nvsm_model* m, char* buf, int64_t buf_bytes) {
     NVSM_REQUIRE(m); NVSM_REQUIRE(buf);
     return guarded([&] {
@@ -191,7 +213,7 @@ int nvsm_profile_get(nvsm_model* m, const char* kernel, double* total_ms, int64_
 // ---- debug hooks (tests only) ----
 int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const float* hostB, float* hostC) {
     NVSM_REQUIRE(hostA); NVSM_REQUIRE(hostB); NVSM_REQUIRE(hostC);
-    return guarded([&] {
+    return guarded_hook([&] {
         const int al = (variant >> 1) & 1, bl = variant & 1;
         const bool exact = (variant >> 30) & 1;               // bit 30: the exact-fp32 tiled kernel even where the planes kernel covers the shape
         const int split = (variant & 0x3fffffff) >> 2;        // variant bits: [exact << 30 | split_k want << 2 | a_layout << 1 | b_layout]
@@ -229,7 +251,7 @@ int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const 
 // extras bit 0 = ordered column statistics (the forward product), bit 1 = row sums of squares (the backward one)
 int nvsm_debug_gemm_time(int b_layout, int M, int N, int K, int extras, int repeats, float* avg_ms) {
     NVSM_REQUIRE(avg_ms);
-    return guarded([&] {
+    return guarded_hook([&] {
         cunvsm::DevBuf<float> A, B, C, rowsq, part;
         cunvsm::DevBuf<double> stats, part2;
         cunvsm::DevBuf<int> arrive;
@@ -283,7 +305,7 @@ int nvsm_debug_gemm_time(int b_layout, int M, int N, int K, int extras, int repe
 // the reduce behind it. which 0 = gemm_dt (split-bf16), 2 = the tiled exact-fp32 kernel
 int nvsm_debug_dt_time(int M, int N, int rows, int slabs, int repeats, int which, float* kernel_ms, float* reduce_ms) {
     NVSM_REQUIRE(kernel_ms); NVSM_REQUIRE(reduce_ms);
-    return guarded([&] {
+    return guarded_hook([&] {
         cunvsm::DevBuf<float> A, B, C, P;
         A.alloc(static_cast<size_t>(rows) * M); B.alloc(static_cast<size_t>(rows) * N); C.alloc(static_cast<size_t>(M) * N);
         {
@@ -327,7 +349,7 @@ int nvsm_debug_dt_time(int M, int N, int rows, int slabs, int repeats, int which
 
 int nvsm_debug_sort(int64_t n, int bits, const int32_t* keys, int32_t* keys_out, int32_t* vals_out, int repeats, float* avg_ms) {
     NVSM_REQUIRE(keys); NVSM_REQUIRE(keys_out); NVSM_REQUIRE(vals_out);
-    return guarded([&] {
+    return guarded_hook([&] {
         if (n <= 0) return;
         cunvsm::DevBuf<int> K, KO, VO;
         cunvsm::DevBuf<char> tmp;
@@ -363,7 +385,7 @@ int nvsm_debug_sort(int64_t n, int bits, const int32_t* keys, int32_t* keys_out,
 int nvsm_debug_gather_mean(int64_t num_rows, int dim, const float* table, const int64_t* idx, const float* wts,
                            int window, int64_t num_out, float* out) {
     NVSM_REQUIRE(table); NVSM_REQUIRE(idx); NVSM_REQUIRE(out);
-    return guarded([&] {
+    return guarded_hook([&] {
         cunvsm::DevBuf<float> T, W, O;
         cunvsm::DevBuf<int64_t> I64;
         cunvsm::DevBuf<int> I;

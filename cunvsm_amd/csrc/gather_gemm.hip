@@ -421,8 +421,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
 bool launch_gemm_panel(int a_layout, int b_layout, const float* A, const float* B, float* C, int M, int N, int K,
                        int lda, int ldb, int ldc, float alpha, const float* bias_n, int slabs, int k_split_len,
                        size_t c_split_stride, hipStream_t s);   // gemm_panel.hip
-static bool g_gemm_panel_enabled = [] { const char* e = std::getenv("NVSM_GEMM_PANEL"); return !(e && e[0] == '0'); }();
-void gemm_set_panel_enabled(bool on) { g_gemm_panel_enabled = on; }
+static bool g_gemm_panel_forced_off = false;      // (process-wide test hook)
+void gemm_set_panel_enabled(bool on) { g_gemm_panel_forced_off = !on; }
 
 static int tiled_rowsq_parts(int N) { return (N + BN - 1) / BN; }
 int gemm_rowsq_parts(int N) { return (N + 15) / 16; }
@@ -494,7 +494,7 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
     // (not next to the row passes of the fused step — `busy_chip`: a panel workgroup's four waves take a CU's whole register
     //  file, and a CU that hosts one hosts nothing else for its ~100 us; the tiled kernel takes 273 instead of 184 us there
     //  but shares its CUs: NVSM shape 1.007 -> 1.000 ms, full_adam 0.913 -> 0.902, |D| = 2 M 1.915 -> 1.90, interleaved A/B)
-    if (g_gemm_panel_enabled && !(busy_chip && split_k > 1) && launch_gemm_panel(a_layout, b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, slabs,
+    if (!g_gemm_panel_forced_off && tuning().gemm_panel && !(busy_chip && split_k > 1) && launch_gemm_panel(a_layout, b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, slabs,
                                                   g.k_split_len, c_split_stride, s))
         return;
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void host_pull_kernel(HostPull p) {
 }
 void launch_host_pull(const HostPull& p, hipStream_t s) {
     if (p.count <= 0) return;
-    static const int blocks = [] { const char* e = std::getenv("NVSM_PULL_BLOCKS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 8; }();      // (4-8 workgroups saturate the link; more only take wave slots from the step: 64 -> 8: 1.12 -> 1.075 ms)
+    const int blocks = tuning().pull_blocks;      // (4-8 workgroups saturate the link; more only take wave slots from the step: 64 -> 8: 1.12 -> 1.075 ms)
     hipLaunchKernelGGL(host_pull_kernel, dim3(blocks), dim3(256), 0, s, p);
 }
 

@@ -290,7 +290,7 @@ static size_t rows_plan(int b_layout, int M, int N, int K, bool colstats, bool r
     // MFMAs), or two tiles per wave and one wave per SIMD (half the LDS fragment reads per MFMA). Alone, forward / backward at
     // 6 400 rows: 29.0 / 24.4 us against 34.7 / 29.7 us; step at batch 6 400 0.314 against 0.329 ms (interleaved A/B).
     // NVSM_ROWS_TPW=2: the two-tile form.
-    static const int tpw_env = [] { const char* e = std::getenv("NVSM_ROWS_TPW"); return e ? std::atoi(e) : 0; }();
+    const int tpw_env = tuning().rows_tpw;
     const int tpw = (N > 128 && tpw_env == 2) ? 2 : 1;
     const int wn = 32 * tpw;
     // (>= 256 threads: the A tile is one float4 per thread; rounded up to an instantiated workgroup size)
@@ -338,7 +338,7 @@ bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, in
     g.dump = gemm_dump_buffer();
     if (!g.dump) return false;
 #ifdef NVSM_ROWS_DBG
-    { const char* e = std::getenv("NVSM_ROWS_DBG"); g.dbg = e ? std::atoi(e) : 0; }
+    g.dbg = tuning().rows_dbg;
 #endif
 #define NVSM_ROWS_CASE(T, W)                                                                          \
     if (tpw == T && waves == W) {                                                                     \
@@ -352,8 +352,7 @@ bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, in
 }
 
 int gemm_rows_max_m() {
-    const char* e = std::getenv("NVSM_GEMM_ROWS_MAX");      // (read per call: tests and A/B runs switch it)
-    return e ? std::atoi(e) : 8192;
+    return tuning().gemm_rows_max;
 }
 
 }  // namespace cunvsm

@@ -538,11 +538,9 @@ void launch_gemm_split_planes(int b_layout, const float* B, int N, int K, int ld
     else NVSM_LAUNCH((gemm_split_planes_kernel<1>), dim3(grid), dim3(256), 0, s, B, N, K, ldb, np, static_cast<unsigned char*>(planes));
 }
 
-// NVSM_GEMM_SPLIT: 0 = never, 6 (default) / 9 = number of partial products. Read per call (tests switch it within a process).
+// NVSM_GEMM_SPLIT: 0 = never, 6 (default) / 9 = number of partial products (tuning.h: per handle)
 int gemm_split_products() {
-    const char* e = std::getenv("NVSM_GEMM_SPLIT");
-    const int v = e ? std::atoi(e) : 6;
-    return (v == 6 || v == 9) ? v : 0;
+    return tuning().gemm_split;
 }
 
 // what launch_gemm_split accepts (given 16 B aligned operands and leading dimensions that are multiples of 4)
@@ -586,7 +584,7 @@ bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, i
         g.A_rw = bn->dy; g.pre = bn->pre; g.mean = bn->mean; g.inv_std = bn->inv_std; g.bn_sums = bn->sums;
         g.dbeta = bn->dbeta; g.dgamma = bn->dgamma; g.grad_bias = bn->grad_bias; g.inv_n = static_cast<float>(1.0 / bn->n_global);
     }
-    { const char* e = std::getenv("NVSM_SPLIT_NT"); g.nt_store = e ? std::atoi(e) : 0; }
+    g.nt_store = tuning().split_nt;
     g.nblocks = (M + 15) / 16; g.np = 16 * cbs; g.dump = dump; g.planes = static_cast<const unsigned char*>(ws->planes);
     int wgs = num_cus < g.nblocks ? num_cus : g.nblocks;
     if (colstats) {
@@ -599,8 +597,7 @@ bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, i
     // 2 j and 2 j + 1 do): the wider slices go to waves of different SIMDs first — 19 blocks = 3, 3, 3, 2 | 2, 2, 2, 2 is
     // 5, 5, 5, 4 per SIMD.
     auto deal = [&](int waves) {
-        const char* e = std::getenv("NVSM_SPLIT_DEAL");
-        const bool adjacent = e && std::atoi(e) == 1;
+        const bool adjacent = tuning().split_deal == 1;
         const int lo = cbs / waves, wide = cbs - lo * waves;
         int n_of[kSplitMaxWaves] = {0};
         for (int k = 0; k < waves; ++k) n_of[adjacent ? ((2 * k) % waves + (2 * k) / waves) : k] = lo + (k < wide ? 1 : 0);

@@ -370,7 +370,7 @@ bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* 
                        int lda, int ldb, int ldc, float alpha, const float* bias_n, hipStream_t s, double* colstats,
                        float* rowsq, float rowsq_scale, int* rowsq_parts, bool busy_chip, const GridSumWs* sums) {
     // NVSM_GEMM_TSTAT (A/B runs): bit 0 = the forward product (B as [K][N]), bit 1 = the backward one (B stored [N][K])
-    static const int env_mask = [] { const char* e = std::getenv("NVSM_GEMM_TSTAT"); return e ? std::atoi(e) : 3; }();
+    const int env_mask = tuning().gemm_tstat;
     if (!g_gemm_tstat_enabled || !(env_mask & (b_layout ? 2 : 1)) || a_layout != 0 || M < 1024) return false;
     // The forward product of a large batch starts while the previous step's documents update and this step's sorts still
     // hold registers and LDS on most CUs, and a kernel that needs a whole CU per workgroup starts late on some of them; its
@@ -379,7 +379,7 @@ bool launch_gemm_tstat(int a_layout, int b_layout, const float* A, const float* 
     // shorter it is the other way round at the NVSM shape (1.047 against 1.055 ms, interleaved) — but not where those are
     // long, i.e. with tables much larger than the batch (configs[4]: 1.90 against 1.87 ms): the caller says which
     // (busy_chip). NVSM_GEMM_TSTAT_FWD_ANY=0 / 1 overrides.
-    static const int fwd_any = [] { const char* e = std::getenv("NVSM_GEMM_TSTAT_FWD_ANY"); return e ? std::atoi(e) : -1; }();
+    const int fwd_any = tuning().gemm_tstat_fwd_any;
     if (b_layout == 0 && M > 16384 && (fwd_any >= 0 ? fwd_any == 0 : busy_chip)) return false;
     if ((K % 4) || (N % 4) || (lda % 4) || (ldb % 4) || (ldc % 4)) return false;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) % 16) return false;

@@ -10,6 +10,8 @@
 #include <stdexcept>
 #include <string>
 
+#include "tuning.h"
+
 namespace cunvsm {
 
 // what every layer below the C ABI throws; c_api.cpp turns it into an nvsm_status + nvsm_last_error() (status: NVSM_ERR_*)

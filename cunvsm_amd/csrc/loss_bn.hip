@@ -508,7 +508,7 @@ static void launch_loss_rows(const LossArgs& a_in, hipStream_t s) {
     if (a.B >= 40960) epw = 20;
     // (batch 4096: two examples per wave, 512 workgroups — half as many fp64 atomics per column: 44 -> 33 us)
     if (epw < 2 && a.B >= 2048) epw = 2;
-    static const int epw_env = [] { const char* e = std::getenv("NVSM_LOSS_EPW"); return e ? std::atoi(e) : 0; }();      // experiments
+    const int epw_env = tuning().loss_epw;      // experiments
     if (epw_env > 0) epw = epw_env;
     const int grid = ceil_div(a.B, 4 * epw);
     a.sums.fan = grid_sum_fan(grid);

@@ -128,8 +128,7 @@ struct Roctx {
     static Roctx& get() {
         static Roctx r = [] {
             Roctx x;
-            const char* off = std::getenv("NVSM_ROCTX");
-            if (off && off[0] == '0') return x;
+            if (!tuning().roctx) return x;      // (process-wide: decided by the first caller's switches)
             void* h = nullptr;
             for (const char* n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1",
                                   "libroctx64.so", "libroctx64.so.4"}) {
@@ -258,8 +257,7 @@ hipEvent_t take_launch_events(hipEvent_t* start) {
     return e;
 }
 static bool stop_events_enabled() {
-    static const bool on = [] { const char* e = std::getenv("NVSM_STOP_EVENTS"); return !(e && e[0] == '0'); }();
-    return on;
+    return tuning().stop_events;
 }
 // `launch` enqueues ONE kernel on `s` through NVSM_LAUNCH; `ev` then stands for everything queued on `s` up to and including
 // it, exactly as a hipEventRecord behind it would (NVSM_STOP_EVENTS=0: that plain record, for A/B runs)
@@ -295,8 +293,7 @@ static void timed_launch(Profiler& prof, const char* name, hipStream_t s, bool s
 // ---------------------------------------------------------------------------------------------
 // NVSM_CHUNK_ORDER=0 (A/B runs): level-1 chunks as numbered instead of in batch order
 static bool chunk_order_enabled() {
-    const char* e = std::getenv("NVSM_CHUNK_ORDER");
-    return !(e && e[0] == '0');
+    return tuning().chunk_order;
 }
 static int bits_for(int64_t n) {
     int b = 1;
@@ -335,8 +332,7 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
     t.partial2_q.alloc(t.max_chunks2, true);
     t.arrive_row.alloc(rows, true); t.arrive2.alloc(t.max_chunks2, true);      // zero once: the last arriver resets its counter
     {
-        const char* lazy_env = std::getenv("NVSM_LAZY_DECAY");        // read per handle: tests build an eager twin
-        const bool lazy_enabled = !(lazy_env && lazy_env[0] == '0');
+        const bool lazy_enabled = tune_.lazy_decay;        // (per handle: tests build an eager twin)
         const bool sparse_adam = method == NVSM_ADAM && mode <= NVSM_ADAM_SPARSE;
         const bool decays = sparse_adam || (method != NVSM_ADAM && cfg_.regularization_lambda > 0.f);
         // When lazy decay pays. The dense passes it saves must cost more than what it adds (a snapshot and a stamp launch per
@@ -345,11 +341,9 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
         // per-rank share of the 8-GPU metric (6 400 windows against 50 k / 100 k rows) lazy for both tables: 0.335 -> 0.292 ms
         // per step (words alone 0.299, documents alone 0.322; interleaved A/B). Not the LSE shape (Adagrad, batch 4096, a
         // 100 MB words table): 0.182 -> 0.193 ms with a lazy words table. NVSM_LAZY_MIN_MB overrides (tests use small tables).
-        const char* min_env = std::getenv("NVSM_LAZY_MIN_MB");          // (per handle, as NVSM_LAZY_DECAY)
-        const double lazy_min_mb = min_env ? std::atof(min_env) : (sparse_adam ? 96.0 : 384.0);
+        const double lazy_min_mb = tune_.lazy_min_mb >= 0.0 ? tune_.lazy_min_mb : (sparse_adam ? 96.0 : 384.0);
         const double state_mb = static_cast<double>(rows) * dim * sizeof(float) * (method == NVSM_ADAM ? 2.0 : 1.0) / 1048576.0;
-        const char* tab_env = std::getenv("NVSM_LAZY_TABLES");          // experiments: bit 0 = words, bit 1 = documents
-        const int tab_mask = tab_env ? std::atoi(tab_env) : 3;
+        const int tab_mask = tune_.lazy_tables;          // experiments: bit 0 = words, bit 1 = documents
         t.lazy = lazy_enabled && decays && state_mb >= lazy_min_mb && ((tab_mask >> (&t == &ents_ ? 1 : 0)) & 1) &&
                  static_cast<double>(rows) * table_split_ratio() >= static_cast<double>(max_entries);
         t.lazy_scalar = sparse_adam || (method == NVSM_ADAGRAD && &t == &ents_);
@@ -372,7 +366,8 @@ void Model::alloc_sums(SumsBufs& b, int colgroups, int contrib_cap, int width_ca
     w.part = b.part.p; w.part2 = b.part2.p; w.arrive = b.arrive.p;
 }
 
-Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1), rng_(1) {
+Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(cfg.num_random_entities + 1), rng_(1) {
+    TuningScope tuning_scope(&tune_);      // (the only place the environment is read: the kernels' launchers see this handle's switches)
     auto bad = [](const std::string& m) { throw Error(NVSM_ERR_INVALID_ARGUMENT, m); };
     if (cfg.num_words <= 0 || cfg.num_entities <= 0) bad("num_words and num_entities must be positive");
     if (cfg.word_repr_size <= 0 || cfg.entity_repr_size <= 0) bad("representation sizes must be positive");
@@ -412,12 +407,12 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
         own_stream_ = true;
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, lo));
-        static const int aux2_prio = [] { const char* e = std::getenv("NVSM_AUX2_PRIO"); return e ? std::atoi(e) : 0; }();   // (experiments) 0 lowest, 1 middle, 2 highest
+        const int aux2_prio = tune_.aux2_prio;   // (experiments) 0 lowest, 1 middle, 2 highest
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux2_stream_, hipStreamNonBlocking, aux2_prio == 0 ? lo : (aux2_prio == 2 ? hi : (lo + hi) / 2)));
         // Four streams, not five: the runtime multiplexes streams onto four hardware queues, and with a fifth stream the
         // host-batch copies shared a queue with compute and stopped overlapping it (1.22 -> 1.7 ms per step with host
         // batches). The inputs' copies therefore ride on side stream 3 in front of the documents sort that needs them.
-        static const int aux3_prio = [] { const char* e = std::getenv("NVSM_AUX3_PRIO"); return e ? std::atoi(e) : 1; }();   // 0 lowest, 1 middle, 2 highest
+        const int aux3_prio = tune_.aux3_prio;   // 0 lowest, 1 middle, 2 highest
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux3_stream_, hipStreamNonBlocking, aux3_prio == 0 ? lo : (aux3_prio == 2 ? hi : (lo + hi) / 2)));
         copy_stream_ = aux3_stream_;
     }
@@ -427,7 +422,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     // 0.209 -> 0.203 ms per step, no effect at the NVSM shape. NVSM_EVENT_FENCE=0: default events, 2: device-scope release.
     // (Data parallel handles keep the default events: memory that peers write over xGMI is in play there, the gain is
     //  confined to launch-latency-bound shapes, and a multi-GPU node has not been available to measure on.)
-    static const int ev_fence_env = [] { const char* e = std::getenv("NVSM_EVENT_FENCE"); return e ? std::atoi(e) : -1; }();
+    const int ev_fence_env = tune_.event_fence;
     const int ev_fence = ev_fence_env >= 0 ? ev_fence_env : (cfg.world_size > 1 ? 0 : 1);
     const unsigned dev_flags = hipEventDisableTiming | (ev_fence == 1 ? hipEventDisableSystemFence : 0u) | (ev_fence == 2 ? hipEventReleaseToDevice : 0u);
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_ents_, dev_flags));
@@ -440,8 +435,8 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&err_host_), sizeof(int), hipHostMallocDefault));
     *err_host_ = 0;
-    { const char* d = std::getenv("NVSM_DEBUG"); debug_ = d && d[0] && d[0] != '0'; }
-    { const char* d = std::getenv("NVSM_DP_T_ON_MAIN"); dp_single_stream_ = d && d[0] && d[0] != '0'; }
+    debug_ = tune_.debug;
+    dp_single_stream_ = tune_.dp_t_on_main;
     if (exact_) dp_single_stream_ = true;      // (every collective of that mode is issued on the main stream)
 
     const int dw = cfg.word_repr_size, de = cfg.entity_repr_size, w = cfg.window_size;
@@ -496,8 +491,7 @@ Model::Model(const nvsm_config& cfg) : cfg_(cfg), R_(cfg.num_random_entities + 1
     // with 32-48, 0.926 with 16, 1.000 with 8; batch 12 800: 0.442 with 100 slabs, 0.417 with 50, 0.405 with 8-24; interleaved
     // A/B). NVSM_DT_SLABS overrides.
     {
-        const char* e = std::getenv("NVSM_DT_SLABS");
-        gemm_slabs_want_ = e ? std::atoi(e) : (B > gemm_rows_max_m() ? 16 : static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, B / 128))));
+        gemm_slabs_want_ = tune_.dt_slabs > 0 ? tune_.dt_slabs : (B > gemm_rows_max_m() ? 16 : static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, B / 128))));
     }
     // the split-K dT kernel (gemm_dt.hip): at most a slab per two CUs (two workgroups per slab)
     dt_ok_ = gemm_dt_covers(dw, de, static_cast<int>(B));
@@ -909,7 +903,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             // already: this copy is queued behind the previous step's documents sort, which waited for that step's prologue,
             // i.e. for everything the step before it had on the main stream — no event, and no record packet in front of
             // the prologue on the critical stream.
-            static const bool csr_at_start = [] { const char* a = std::getenv("NVSM_CSR_AFTER"); return !a || std::atoi(a) == 0; }();
+            const bool csr_at_start = tune_.csr_after == 0;
             // (the layout follows the batch size: the argument needs the previous step's documents sort on the copy stream)
             const bool copies_behind_sort = csr_at_start && csr_stream_layout() == 4 && last_csr_layout_ == 4;
             if (!(copies_behind_sort && copy_stream_ == aux3_stream_ && aux3_stream_)) {
@@ -921,7 +915,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             // The runtime's copy call occupied this thread for most of a step even for page-locked sources (kernels.h HostPull).
             HostPull pull{};
             auto bring = [&](void* dst, const void* src, size_t bytes) {
-                static const bool use_pull = [] { const char* e = std::getenv("NVSM_HOST_PULL"); return !(e && e[0] == '0'); }();
+                const bool use_pull = tune_.host_pull;
                 void* dev_view = nullptr;
                 hipPointerAttribute_t at{};
                 // (the pull kernel reads 16 bytes per lane: a source that is only element-aligned — a slice of a page-locked
@@ -1000,7 +994,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     const int* csr_widx = exact_ ? xg_widx_.p : widx_.p;
 
     // Row-order (CSR) of both tables for the update, on the side streams: needs only the indices.
-    static const int csr_after = [] { const char* e = std::getenv("NVSM_CSR_AFTER"); return e ? std::atoi(e) : 0; }();
+    const int csr_after = tune_.csr_after;
     if (!fused_prologue || exact_) NVSM_HIP_CHECK(hipEventRecord(ev_inputs_, stream_));
     inputs_recorded_ = true;
     // two side streams: the sorts are latency-bound chains of small launches, so the two tables' builds run next to
@@ -1040,7 +1034,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // NVSM_WORDS_CSR_LATE=1 (experiment): the words table's build behind the loss kernel instead of at the step's start — it is
     // needed only behind the dx and dT products, whose MFMA-bound 0.18 ms it then runs next to, instead of next to the
     // HBM-bound loss kernel
-    static const bool words_csr_late_env = [] { const char* e = std::getenv("NVSM_WORDS_CSR_LATE"); return e && e[0] == '1'; }();
+    const bool words_csr_late_env = tune_.words_csr_late;
     const bool words_csr_late = words_csr_late_env && csr_after == 0 && !any_lazy;
     if (csr_first) launch_csr_builds(ev_inputs_, words_csr_late ? 1 : 3);
     // (lazy dense decay: the gathers below bring the rows they read up to date on the fly — LazyView — and the row passes of
@@ -1051,7 +1045,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     if (T_pending_) phrase_p_ = (phrase_p_ == phrase_.p) ? phrase_alt_.p : phrase_.p;
     // NVSM_JOIN_E (experiments): where the main stream waits for the previous step's documents update — 0 = right before
     // the loss kernel (its first reader), 1 = before the projection GEMM, 2 = before the word gather
-    static const int join_e_at = [] { const char* e = std::getenv("NVSM_JOIN_E"); return e ? std::atoi(e) : 0; }();
+    const int join_e_at = tune_.join_e;
     if (join_e_at == 2) join_E();
     if (words_tail_pending_) { join_T(); words_tail_pending_ = false; }      // the previous step's streaming decay of the words table (step())
     {
@@ -1193,7 +1187,7 @@ void Model::backward_dx() {
     const bool sync_bn_order = !dp || cfg_.sync_batch_norm;       // (per-shard batch-norm under DP reduces AFTER bn_dx: separate launches)
     // Large batches: the same fusion in the split-bf16 kernel (gemm_split.hip). Its launch carries ev_bwdx_, so the planes of T
     // must not be cut by a launch of their own between the two: cut here if they are stale.
-    static const bool split_fuse = [] { const char* e = std::getenv("NVSM_SPLIT_FUSE"); return !(e && e[0] == '0'); }();      // A/B runs
+    const bool split_fuse = tune_.split_fuse;      // A/B runs
     const bool big = B > gemm_rows_max_m();
     auto split_ready = [&] {
         if (!split_bwd_.ready) { launch_gemm_split_planes(1, T_.p, dw, de, de, split_bwd_.planes, stream_); split_bwd_.ready = true; }
@@ -1414,8 +1408,7 @@ static void fill_adam_consts(RowPassArgs& a, float bc, float sl);
 // rows they gather (each read 10-17 times) from the caches: 1 = documents moments, 2 = documents rows, 4 = word moments,
 // 8 = word rows. Interleaved A/B at the bench shape: 0: 1.134, 1: 1.128, 3: 1.125, 5: 1.136, 9: 1.134, 15: 1.144 ms.
 static int nt_mask() {
-    static const int m = [] { const char* e = std::getenv("NVSM_NT"); return e ? std::atoi(e) : 3; }();
-    return m;
+    return tuning().nt_mask;
 }
 
 // ---- lazy dense decay (kernels.h) ---------------------------------------------------------------------------------
@@ -1633,9 +1626,43 @@ void Model::update_transform(float lr, float sl, hipStream_t strm) {
     cut_transform_planes(strm);
 }
 
+// The dispatch of a step at `batch` windows in one place, as text (nvsm_describe): the three projection products' kernels, where
+// the dT product and the CSR builds run, the tables' decay mode, and every switch that is off its default. Mirrors launch_gemm's
+// order of preference (gather_gemm.hip) and the rules of step(); tests/test_gpu_switches.py holds it against the profiler's notes.
+std::string Model::describe(int64_t batch) const {
+    TuningScope scope(&tune_);
+    const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size;
+    const int B = static_cast<int>(std::min<int64_t>(std::max<int64_t>(batch, 1), cfg_.max_batch_size));
+    const bool need_msq = cfg_.update_method == NVSM_ADAGRAD || (cfg_.update_method == NVSM_ADAM && cfg_.adam_mode != NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE);
+    const bool bn = cfg_.batch_normalization != 0, l2p = cfg_.l2_normalize_phrase_reprs != 0;
+    auto product = [&](int b_layout, int N, int K, bool stats, bool rowsq, bool fused_bn) -> std::string {
+        const int rows_max = gemm_rows_max_m();
+        if (B >= 512 && B <= rows_max && gemm_rows_covers(b_layout, B, N, K, stats, rowsq, fused_bn)) return "gemm_rows (exact fp32 MFMA, 32-row panels)";
+        if (B > rows_max && gemm_split_covers(b_layout, B, N, K, fused_bn))
+            return "gemm_split (3 bf16 planes, " + std::to_string(gemm_split_products()) + " of 9 products)";
+        if (B >= 1024 && K % 4 == 0 && N % 4 == 0) return "gemm_tstat (exact fp32 MFMA, projection stationary in LDS) or tiled";
+        return "gemm_f32_mfma (exact fp32 MFMA, 128 x 128 tiles)";
+    };
+    std::string out = "batch " + std::to_string(B) + ": forward " + product(0, de, dw, bn, false, false);
+    const bool fuse = !l2p && B >= 512 && (B <= gemm_rows_max_m() || tune_.split_fuse);
+    out += " | backward " + product(1, dw, de, false, need_msq && !l2p, fuse) + (fuse ? " with the batch-norm backward / bias gradient inside" : "");
+    // (B_ decides use_dt() / dt_on_main() at run time: evaluated here for `B`)
+    const bool dt = dt_ok_ && gemm_split_products() != 0 && B >= 40960;
+    const bool lazy = words_.lazy || ents_.lazy;
+    const bool dt_main = (tune_.dt_on_main >= 0 ? tune_.dt_on_main != 0 : (B >= 40960 && !lazy)) && cfg_.world_size <= 1 && dt;
+    out += std::string(" | dT ") + (dt ? "gemm_dt (3 bf16 planes, split-K)" : "gemm_f32_mfma / gemm_panel split-K (exact fp32 MFMA)") +
+           (dt_main ? " on the main stream" : " on side stream 2");
+    out += std::string(" | tables: words ") + (words_.lazy ? "lazy" : "eager") + " decay, documents " + (ents_.lazy ? "lazy" : "eager") + " decay";
+    out += " | CSR stream layout " + std::to_string(tune_.sort_layout >= 0 ? tune_.sort_layout : (dt_main ? 2 : 4));
+    char buf[512];
+    const char* sw = tuning_describe(tune_, buf, sizeof(buf));
+    out += std::string(" | switches: ") + (sw[0] ? sw : "defaults");
+    return out;
+}
+
 // which side streams build the two tables' CSRs this step (compute_cost: NVSM_SORT_LAYOUT)
 int Model::csr_stream_layout() const {
-    static const int sort_layout_env = [] { const char* e = std::getenv("NVSM_SORT_LAYOUT"); return e ? std::atoi(e) : -1; }();
+    const int sort_layout_env = tune_.sort_layout;
     return sort_layout_env >= 0 ? sort_layout_env : (dt_on_main() ? 2 : 4);
 }
 
@@ -1649,7 +1676,7 @@ bool Model::use_dt() const { return dt_ok_ && gemm_split_products() != 0 && B_ >
 
 // the fused step's dT product on the main stream (see step()): large batches of eager tables
 bool Model::dt_on_main() const {
-    static const int dt_main_env = [] { const char* e = std::getenv("NVSM_DT_ON_MAIN"); return e ? std::atoi(e) : -1; }();
+    const int dt_main_env = tune_.dt_on_main;
     return (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy)) && cfg_.world_size <= 1 && use_dt();
 }
 
@@ -1700,8 +1727,8 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         if (cost) *cost = get_cost();
         return;
     }
-    static const bool fewer_events = [] { const char* e = std::getenv("NVSM_FEWER_EVENTS"); return !(e && e[0] == '0'); }();
-    static const int docs_after_dx_env = [] { const char* e = std::getenv("NVSM_DOCS_AFTER_DX"); return e ? std::atoi(e) : -1; }();
+    const bool fewer_events = tune_.fewer_events;
+    const int docs_after_dx_env = tune_.docs_after_dx;
     const bool docs_after_dx = docs_after_dx_env >= 0 ? docs_after_dx_env != 0 : batch.num_instances >= 16384;
     const bool loss_event = !(docs_after_dx && fewer_events);      // (see below)
     loss_stop_event_ = loss_event ? ev_loss_ : nullptr;
@@ -1737,7 +1764,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     if (loss_event) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_loss_, 0));      // (recorded with the loss kernel)
     // NVSM_DOCS_ON_MAIN (experiments): 1 = the documents update on the main stream in front of the words update, 2 = behind
     // it (two HBM-bound passes one after the other instead of next to each other)
-    static const int docs_on_main = [] { const char* e = std::getenv("NVSM_DOCS_ON_MAIN"); return e ? std::atoi(e) : 0; }();
+    const int docs_on_main = tune_.docs_on_main;
     dx_follower_ = dp ? nullptr : aux2_stream_;      // side stream 2 runs the dT GEMM as soon as dx is final
     if (docs_after_dx || docs_on_main) backward_dx();
     if (docs_on_main == 1) {
@@ -1790,7 +1817,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     // streaming decay of the rows WITHOUT entries does not belong on the critical stream between the passes over the rows
     // with entries — disjoint rows — but behind the projection update on side stream 2, which built this CSR and is idle by
     // then; the next step's word gather joins that stream (LSE batch 4096: 14-17 us of a 0.2 ms step). NVSM_UNTOUCHED_ASIDE=0: off.
-    static const bool untouched_aside = [] { const char* e = std::getenv("NVSM_UNTOUCHED_ASIDE"); return !(e && e[0] == '0'); }();
+    const bool untouched_aside = tune_.untouched_aside;
     // (only when side stream 2 is the stream that built the words CSR: the untouched pass reads its row bounds, and the next
     //  step's sort on that stream clears them — a pass queued on any other stream would have neither order)
     const bool words_aside = untouched_aside && !dp && !words_.lazy && words_csr_stream_ == aux2_stream_ &&

@@ -27,7 +27,7 @@ namespace cunvsm {
             throw ::cunvsm::Error(NVSM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-inline bool devbuf_poison() { const char* e = std::getenv("NVSM_POISON"); return e && e[0] == '1'; }
+inline bool devbuf_poison() { return tuning().poison; }
 
 template <typename T>
 struct DevBuf {
@@ -162,6 +162,8 @@ class Model {
 
     Profiler prof;
     const nvsm_config& config() const { return cfg_; }
+    const Tuning& tune() const { return tune_; }
+    std::string describe(int64_t batch) const;      // which kernel each product of a step takes at `batch` windows, table modes, switches off their defaults
 
  private:
     struct ParamRef { float* p; int64_t n; };
@@ -186,6 +188,7 @@ class Model {
     void alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entries);
     float adam_bc(uint64_t t) const;
 
+    Tuning tune_;                     // the switches of this handle: read from the environment once, by the constructor (tuning.h)
     nvsm_config cfg_;
     int R_;
     hipStream_t stream_ = nullptr;

@@ -1,0 +1,73 @@
+// Every switch of the engine in ONE place, read from the environment ONCE per handle (nvsm_create) — never on a launch path.
+//   * the documented switches (each one exercised by a test) are read by every build;
+//   * the experiment switches — launch shapes, stream placement, kernel choice: what A/B runs turn — are read only by builds
+//     with -DNVSM_EXPERIMENTS (`make dbg` → libcunvsm_amd_dbg.so); the shipped library runs their defaults, so a stray
+//     variable in a user's environment cannot change what it does.
+#pragma once
+
+namespace cunvsm {
+
+struct Tuning {
+    // ---- documented --------------------------------------------------------------------------------------------------------
+    bool debug = false;                 // NVSM_DEBUG=1            finite checks of every intermediate + a sync per call
+    bool poison = false;                // NVSM_POISON=1           uncleared device buffers start as 0xFF bytes
+    bool roctx = true;                  // NVSM_ROCTX=0            no roctx ranges (process-wide: read at the first use)
+    int gemm_split = 6;                 // NVSM_GEMM_SPLIT=0|6|9   partial products of the split-bf16 projection kernels (0: exact-fp32 MFMA kernels)
+    int gemm_rows_max = 8192;           // NVSM_GEMM_ROWS_MAX=n    largest batch of the row-panel projection kernel
+    bool lazy_decay = true;             // NVSM_LAZY_DECAY=0       eager dense decay for every table
+    double lazy_min_mb = -1.0;          // NVSM_LAZY_MIN_MB=x      table state from which decay is lazy (< 0: 96 MB sparse Adam, 384 MB otherwise)
+    bool dp_t_on_main = false;          // NVSM_DP_T_ON_MAIN=1     data parallel: all three collectives of a step on the main stream
+    bool host_pull = true;              // NVSM_HOST_PULL=0        page-locked batches through hipMemcpyAsync instead of the pull kernel
+    bool stop_events = true;            // NVSM_STOP_EVENTS=0      plain event records instead of events riding on kernel launches
+    int sort_layout = -1;               // NVSM_SORT_LAYOUT=0..4   which side streams build the two CSRs (< 0: by batch size)
+    long long entry_walk_min = 64ll * 4096;      // NVSM_ENTRY_WALK_MIN=n   entries from which a split table pass walks the sorted entries
+    // ---- experiments (-DNVSM_EXPERIMENTS) ------------------------------------------------------------------------------------
+    int csr_grid_cap = -1;              // NVSM_CSR_GRID_CAP
+    double split_ratio = 2.0;           // NVSM_SPLIT_RATIO
+    int chunk_grid_cap = 0;             // NVSM_CHUNK_GRID_CAP
+    bool merged_pass = true;            // NVSM_MERGED_PASS
+    int chunk_blocks = 2048;            // NVSM_CHUNK_BLOCKS
+    int row_blocks_cap = 256 * 32;      // NVSM_ROW_BLOCKS_CAP
+    bool entry_walk = true;             // NVSM_ENTRY_WALK
+    long long entry_walk_min_words = -1, entry_walk_min_docs = -1;      // NVSM_ENTRY_WALK_MIN_WORDS / _DOCS
+    bool gemm_panel = true;             // NVSM_GEMM_PANEL
+    int pull_blocks = 8;                // NVSM_PULL_BLOCKS
+    int rows_tpw = 0;                   // NVSM_ROWS_TPW
+    int rows_dbg = 0;                   // NVSM_ROWS_DBG
+    int split_nt = 0;                   // NVSM_SPLIT_NT
+    int split_deal = 0;                 // NVSM_SPLIT_DEAL
+    int gemm_tstat = 3;                 // NVSM_GEMM_TSTAT
+    int gemm_tstat_fwd_any = -1;        // NVSM_GEMM_TSTAT_FWD_ANY
+    int loss_epw = 0;                   // NVSM_LOSS_EPW
+    int csr_after = 0;                  // NVSM_CSR_AFTER
+    bool words_csr_late = false;        // NVSM_WORDS_CSR_LATE
+    int join_e = 0;                     // NVSM_JOIN_E
+    bool split_fuse = true;             // NVSM_SPLIT_FUSE
+    int nt_mask = 3;                    // NVSM_NT
+    int dt_on_main = -1;                // NVSM_DT_ON_MAIN
+    bool fewer_events = true;           // NVSM_FEWER_EVENTS
+    int docs_after_dx = -1;             // NVSM_DOCS_AFTER_DX
+    int docs_on_main = 0;               // NVSM_DOCS_ON_MAIN
+    bool chunk_order = true;            // NVSM_CHUNK_ORDER
+    int lazy_tables = 3;                // NVSM_LAZY_TABLES
+    int aux2_prio = 0, aux3_prio = 1;   // NVSM_AUX2_PRIO / NVSM_AUX3_PRIO
+    int event_fence = -1;               // NVSM_EVENT_FENCE
+    int dt_slabs = 0;                   // NVSM_DT_SLABS (0: by batch size)
+    bool untouched_aside = true;        // NVSM_UNTOUCHED_ASIDE
+
+    static Tuning from_env();
+};
+
+// The switches in force for the calling thread: the handle's inside a call on a handle (Model's entry points install them),
+// the values of a debug hook's own from_env() inside a debug hook, otherwise the process defaults (read once).
+const Tuning& tuning();
+struct TuningScope {
+    const Tuning* prev;
+    explicit TuningScope(const Tuning* t);
+    ~TuningScope();
+    TuningScope(const TuningScope&) = delete;
+    TuningScope& operator=(const TuningScope&) = delete;
+};
+const char* tuning_describe(const Tuning& t, char* buf, int n);      // "name=value ..." of every switch that differs from its default
+
+}  // namespace cunvsm

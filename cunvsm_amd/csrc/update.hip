@@ -114,7 +114,7 @@ __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, co
 // have (configs[4]: 1.99 -> 1.93 ms per step; no effect at the NVSM shape, where the arrays live in L2).
 // NVSM_CSR_GRID_CAP overrides (experiments).
 static int csr_grid(int64_t items, bool sparse_table) {
-    static const int cap_env = [] { const char* e = std::getenv("NVSM_CSR_GRID_CAP"); return e ? std::atoi(e) : -1; }();
+    const int cap_env = tuning().csr_grid_cap;
     const int cap = cap_env >= 0 ? cap_env : (sparse_table ? 128 : 0);
     const int g = stream_grid(items, 256);
     return (cap > 0 && g > cap) ? cap : g;
@@ -925,8 +925,7 @@ void launch_lazy_refresh(const LazyRefreshArgs& a, int64_t max_rows, hipStream_t
 // (then at least 14 % of the rows are without entries for uniform ids, most of them for Zipf ids).
 // NVSM_SPLIT_RATIO overrides the factor (experiments); the lazy decay of model.cpp uses the same rule.
 double table_split_ratio() {
-    static const double r = [] { const char* e = std::getenv("NVSM_SPLIT_RATIO"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 2.0; }();
-    return r;
+    return tuning().split_ratio;
 }
 bool row_pass_split(const Csr& c) { return c.n > 0 && static_cast<double>(c.rows) * table_split_ratio() >= static_cast<double>(c.n); }
 static bool kind_is_row_local_when_untouched(int kind) { return kind != ROW_ADAM_DENSE && kind != ROW_ADAM_FULL; }
@@ -946,7 +945,7 @@ static void chunk_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
     int grid = (c.max_chunks + gpb - 1) / gpb;
     int grid2 = (c.max_chunks2 + gpb - 1) / gpb;
     // (the kernels grid-stride over the chunks actually in use) NVSM_CHUNK_GRID_CAP: experiments
-    static const int cap = [] { const char* e = std::getenv("NVSM_CHUNK_GRID_CAP"); return e ? std::atoi(e) : 0; }();
+    const int cap = tuning().chunk_grid_cap;
     if (cap > 0 && TABLE == 1) { grid = grid < cap ? grid : cap; grid2 = grid2 < cap ? grid2 : cap; }
     if (a.kind == ROW_SCALAR_ACC) {
         hipLaunchKernelGGL((chunk_pass_kernel<V, TABLE, false>), dim3(grid), dim3(256), 0, s, c, a, G, nvec);
@@ -1031,11 +1030,11 @@ void launch_row_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hipSt
 }
 
 // NVSM_MERGED_PASS=0 (A/B runs, tests): the three-launch form
-static bool& merged_pass_flag() {
-    static bool on = [] { const char* e = std::getenv("NVSM_MERGED_PASS"); return !(e && e[0] == '0'); }();
+static bool& merged_pass_flag() {      // (process-wide test hook: nvsm_debug_set_table_pass_form)
+    static bool on = true;
     return on;
 }
-static bool merged_pass_enabled() { return merged_pass_flag(); }
+static bool merged_pass_enabled() { return merged_pass_flag() && tuning().merged_pass; }
 void set_table_pass_one_launch(bool on) { merged_pass_flag() = on; }
 
 template <int V, int TABLE>
@@ -1044,13 +1043,13 @@ static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
     int chunk_blocks = (c.n > 0 && c.max_chunks > 0) ? (c.max_chunks + gpb - 1) / gpb + 8 : 0;      // (+ 8: an eighth per XCD, rounded up)
     // (at most 2048 chunk workgroups — a multiple of 8: workgroup cb runs on XCD cb % 8 —, which stride over the chunks in
     //  use; one per gpb chunk SLOTS, most of them empty, was 5300: 0.994 -> 0.989 ms per step; 256: 1.06. NVSM_CHUNK_BLOCKS overrides)
-    static const int cb_cap = [] { const char* e = std::getenv("NVSM_CHUNK_BLOCKS"); return e ? std::atoi(e) : 2048; }();
+    const int cb_cap = tuning().chunk_blocks;
     if (cb_cap > 0 && chunk_blocks > cb_cap) chunk_blocks = cb_cap;
     if (a.rows_elsewhere && chunk_blocks > 2048) chunk_blocks = 2048;      // normally there is no chunk at all: a launch that costs nothing
     int64_t row_blocks = (row_items + gpb - 1) / gpb;
     // (32 workgroups per CU, the rest by striding: 16 384 -> 8 192: NVSM shape 1.001 -> 0.991 ms per step, adagrad 0.872 ->
     //  0.851; 4 096: 1.02; 65 536: 1.018 — NVSM_ROW_BLOCKS_CAP for experiments)
-    { static const int cap = [] { const char* v = std::getenv("NVSM_ROW_BLOCKS_CAP"); return v ? std::atoi(v) : 256 * 32; }(); if (row_blocks > cap) row_blocks = cap; }
+    { const int cap = tuning().row_blocks_cap; if (row_blocks > cap) row_blocks = cap; }
     if (a.max_blocks > 0 && row_blocks > a.max_blocks) row_blocks = a.max_blocks;
     if (row_blocks < 1) row_blocks = 1;
     if (a.rows_elsewhere) row_blocks = 0;
@@ -1101,14 +1100,13 @@ void launch_chunk_order(const Csr& c, int* key_in, int* key_out, void* sort_temp
 
 // NVSM_ENTRY_WALK=0 (A/B runs, tests): the list walk for the rows of tables much larger than the batch
 static bool entry_walk_enabled() {
-    static const bool on = [] { const char* e = std::getenv("NVSM_ENTRY_WALK"); return !(e && e[0] == '0'); }();
-    return on;
+    return tuning().entry_walk;
 }
 // NVSM_ENTRY_WALK_MIN (tests: 0 sends small batches through the entry walk too)
 static int64_t entry_walk_min_entries(int table) {
-    const char* e = std::getenv("NVSM_ENTRY_WALK_MIN");      // (read per launch: tests switch it)
-    if (const char* t = std::getenv(table == 0 ? "NVSM_ENTRY_WALK_MIN_WORDS" : "NVSM_ENTRY_WALK_MIN_DOCS")) e = t;      // experiments: per table
-    return e ? std::atoll(e) : 64ll * 4096;
+    const Tuning& t = tuning();
+    const long long per_table = table == 0 ? t.entry_walk_min_words : t.entry_walk_min_docs;      // experiments: per table
+    return per_table >= 0 ? per_table : t.entry_walk_min;
 }
 static bool entry_walk_kind(int kind) { return kind == ROW_SGD || kind == ROW_ADAGRAD_ENT || kind == ROW_ADAM_MV || kind == ROW_ADAM_SPARSE_ENT; }
 

@@ -248,6 +248,12 @@ class Model:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         check(lib().nvsm_comm_init(self._h, buf))
 
+    def describe(self, batch=None):
+        """Which kernels a step of `batch` windows takes on this handle, table modes, switches off their defaults (nvsm_describe)."""
+        buf = C.create_string_buffer(2048)
+        check(lib().nvsm_describe(self._h, int(batch if batch is not None else self.cfg.max_batch_size), buf, 2048))
+        return buf.value.decode()
+
     def comm_size(self):
         """Ranks of the engine's RCCL communicator as ncclCommCount reports them (0: none built)."""
         n = C.c_int()

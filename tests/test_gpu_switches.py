@@ -53,16 +53,25 @@ for p in PARAMS:
 print("RESULT " + json.dumps({"params": h.hexdigest(), "costs": [c for c in costs if c is not None]}))
 """
 
+# the DOCUMENTED switches (tuning.h, INTEGRATION.md §5): read by the shipped library, once per handle
 VARIANTS = [
     {},
     {"NVSM_STOP_EVENTS": "0"},
-    {"NVSM_EVENT_FENCE": "0"},
     {"NVSM_HOST_PULL": "0"},
+    {"NVSM_ROCTX": "0", "NVSM_POISON": "1"},
+    {"NVSM_STOP_EVENTS": "0", "NVSM_HOST_PULL": "0"},
+]
+# the EXPERIMENT switches: read only by the experiments build (make dbg → libcunvsm_amd_dbg.so, -DNVSM_EXPERIMENTS); the shipped
+# library ignores them (test_the_shipped_library_ignores_experiment_switches)
+EXP_VARIANTS = [
+    {},
+    {"NVSM_EVENT_FENCE": "0"},
     {"NVSM_PULL_BLOCKS": "3"},
     {"NVSM_UNTOUCHED_ASIDE": "0"},
     {"NVSM_GEMM_PANEL": "0"},
     {"NVSM_STOP_EVENTS": "0", "NVSM_EVENT_FENCE": "0", "NVSM_HOST_PULL": "0", "NVSM_UNTOUCHED_ASIDE": "0"},
 ]
+DBG_LIB = os.path.join(ROOT, "cunvsm_amd", "libcunvsm_amd_dbg.so")
 
 
 def _run(shape, env_extra):
@@ -75,17 +84,20 @@ def _run(shape, env_extra):
     return json.loads(lines[-1][len("RESULT "):])
 
 
-# the large shape: where the CSR builds run, host batches copied or pulled, the words build behind the loss kernel
+# the large shape: where the CSR builds run, host batches copied or pulled
 LARGE_VARIANTS = [
     {},
     {"NVSM_SORT_LAYOUT": "4"},
     {"NVSM_SORT_LAYOUT": "2"},
     {"NVSM_SORT_LAYOUT": "1"},
     {"NVSM_STOP_EVENTS": "0", "NVSM_HOST_PULL": "0"},
+]
+LARGE_EXP_VARIANTS = [
+    {},
     {"NVSM_WORDS_CSR_LATE": "1"},
     {"NVSM_AUX2_PRIO": "2", "NVSM_SPLIT_NT": "1"},
     {"NVSM_SPLIT_FUSE": "0"},
-]
+]      # (not NVSM_DT_ON_MAIN: the dT product is cut into 48 slabs on the main stream and 16 on side stream 2 — another summation order)
 
 
 @pytest.mark.parametrize("shape", ["split", "dense", "large"])
@@ -96,3 +108,56 @@ def test_orchestration_switches_do_not_change_results(shape):
     for v in variants[1:]:
         got = _run(shape, v)
         assert got == base, (shape, v, got, base)
+
+
+@pytest.mark.skipif(not os.path.exists(DBG_LIB), reason="experiments build absent (make -C cunvsm_amd/csrc dbg)")
+@pytest.mark.parametrize("shape", ["split", "dense", "large"])
+def test_experiment_switches_do_not_change_results(shape):
+    """the experiments build reads the A/B switches; they move work between streams and kernels, never the result — and its
+    result is the shipped library's"""
+    variants = LARGE_EXP_VARIANTS if shape == "large" else EXP_VARIANTS
+    shipped = _run(shape, {})
+    for v in variants:
+        got = _run(shape, dict(v, CUNVSM_AMD_LIB=DBG_LIB))
+        assert got == shipped, (shape, v, got, shipped)
+
+
+def test_the_shipped_library_ignores_experiment_switches():
+    """tuning.h: a stray experiment variable in a user's environment cannot change what the shipped library does — nvsm_describe
+    lists the switches a handle runs with, and an experiment switch is not among them"""
+    code = ("import sys; sys.path.insert(0, %r); import cunvsm_amd as ca; from tests.helpers import gpu_model\n"
+            "m = gpu_model(dict(num_words=50, num_entities=60, word_dim=8, entity_dim=8, window=4, num_random=3, update_method='sgd', **{'lambda': 0.0}), 64)\n"
+            "print('DESC ' + m.describe())" % ROOT)
+    def desc(env_extra):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True, cwd=ROOT, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("DESC ")][-1]
+    assert desc({}).endswith("switches: defaults")
+    assert desc({"NVSM_SPLIT_FUSE": "0", "NVSM_DOCS_ON_MAIN": "1", "NVSM_GEMM_PANEL": "0"}).endswith("switches: defaults")
+    d = desc({"NVSM_STOP_EVENTS": "0", "NVSM_GEMM_SPLIT": "9"})
+    assert "stop_events=0" in d and "gemm_split=9" in d
+
+
+def test_describe_names_the_kernels_a_step_takes():
+    """nvsm_describe against the profiler's path notes: the dT product runs the split-bf16 split-K kernel from batch 40 960 on
+    (on the main stream, both CSR builds on side stream 2), the tiled fp32 kernel below"""
+    import numpy as np
+    import cunvsm_amd as ca
+    from tests.helpers import gpu_model
+    spec = dict(num_words=3000, num_entities=5000, word_dim=300, entity_dim=256, window=4, num_random=3, nonlinearity="hard_tanh",
+                batch_norm=True, bias_negative_samples=False, update_method="sparse_adam", **{"lambda": 0.01})
+    for B, want_dt in ((40960, True), (6400, False)):
+        m = gpu_model(spec, B, sampler=ca.SAMPLER_DEVICE)
+        m.initialize(3)
+        d = m.describe()
+        rs = np.random.RandomState(1)
+        words = rs.randint(0, spec["num_words"], B * spec["window"]).astype(np.int64)
+        labels = rs.randint(0, spec["num_entities"], B).astype(np.int64)
+        m.profile_enable(True)
+        m.step(ca.Batch(words, labels, np.ones(B * 4, np.float32), np.ones(B, np.float32)), 0.01)
+        m.synchronize()
+        notes = set(m.profile())
+        assert ("dt_split_bf16" in notes) == want_dt, (B, notes)
+        assert ("dT gemm_dt" in d) == want_dt and ("on the main stream" in d) == want_dt, d
+        assert ("forward gemm_split" in d) == (B > 8192) and ("forward gemm_rows" in d) == (B <= 8192), d
+        assert "CSR stream layout %d" % (2 if want_dt else 4) in d, d

@@ -1,5 +1,7 @@
 #!/bin/bash
 # as tools/ab.sh with extra bench flags in $BENCH_FLAGS
+# the experiment switches are read by the experiments build only (tuning.h): make -C cunvsm_amd/csrc dbg
+export CUNVSM_AMD_LIB=${CUNVSM_AMD_LIB:-$(cd "$(dirname "$0")/.." && pwd)/cunvsm_amd/libcunvsm_amd_dbg.so}
 cd "$(dirname "$0")/.."
 for round in 1 2 3; do
   for cfg in "$@"; do

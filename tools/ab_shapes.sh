@@ -1,5 +1,7 @@
 #!/bin/bash
 # interleaved A/B of environment settings over several shapes: tools/ab_shapes.sh "VAR=1" "VAR=2" ...   (SHAPES overrides the list)
+# the experiment switches are read by the experiments build only (tuning.h): make -C cunvsm_amd/csrc dbg
+export CUNVSM_AMD_LIB=${CUNVSM_AMD_LIB:-$(cd "$(dirname "$0")/.." && pwd)/cunvsm_amd/libcunvsm_amd_dbg.so}
 cd "$(dirname "$0")/.."
 SHAPES=${SHAPES:-"--batch=6400 --batch=12800 --batch=25600 --config=lse_small --batch=51200"}
 for round in 1 2; do for sh in $SHAPES; do for v in "$@"; do

@@ -546,6 +546,25 @@ struct Model {
     // exact data-parallel tables (test hook): every rank applies the sparse gradients of ALL ranks' windows, in rank order —
     // the update of the single process on the global batch. -1 = off (tables are updated from the rank's own windows).
     int exact_rank = -1;
+    // owner-partitioned documents table (test hook, with exact_rank >= 0; SURVEY.md §8e last bullet): row r of E
+    // and of its optimiser state belongs to rank r mod world. A rank applies, of the GLOBAL batch's sparse gradients, only the
+    // entries of its own rows — an eighth of the update's work at eight ranks — and its dense decay is only valid for those
+    // rows: the caller then replaces every rank's rows by their owners' (owned_row_exchange below is that all-gather, written
+    // as a sum with one non-zero term per row), which leaves all replicas equal to the single process's table. The optimiser
+    // state is never exchanged: a row's state is read by its own update only (the documents table has window 1). Not the
+    // words table: with a window the reference's Adagrad / sparse-Adam direction of a row averages the state of the OTHER
+    // words of the window (cpp/updates_adagrad.cu:83-97, updates_adam.cu:132-151), which belong to other ranks.
+    bool owner_rows_entities = false;
+    void owned_row_exchange() {
+        if (!(owner_rows_entities && world > 1 && allreduce && exact_rank >= 0)) return;
+        const size_t de = static_cast<size_t>(cfg.entity_dim);
+        std::vector<double> t(entities.data.size(), 0.0);
+        for (size_t r = 0; r < entities.n; ++r)
+            if (static_cast<int>(r % world) == exact_rank)
+                for (size_t k = 0; k < de; ++k) t[r * de + k] = static_cast<double>(entities.data[r * de + k]);
+        allreduce(t.data(), t.size());
+        for (size_t i = 0; i < t.size(); ++i) entities.data[i] = static_cast<F>(t[i]);
+    }
 
     // all-gather through the cross-rank sum: every rank contributes its slice at its own offset of a zeroed buffer
     // (float, double and ids below 2^53 pass through a double unchanged)
@@ -801,9 +820,24 @@ struct Model {
             std::vector<F> gp_all = all_gather(grads.grad_phrase.data(), grads.grad_phrase.size());
             std::vector<idx_t> words_all = all_gather(f.words.data(), f.words.size());
             std::vector<F> ww_all = all_gather(f.word_weights.data(), f.word_weights.size());
+            if (owner_rows_entities) {
+                // only the entries of this rank's rows, in the global batch's order (what a rank of the partitioned engine
+                // would keep after filtering the gathered ids)
+                const size_t de = static_cast<size_t>(cfg.entity_dim);
+                std::vector<F> ge_own; std::vector<idx_t> ids_own;
+                for (size_t j = 0; j < ids_all.size(); ++j)
+                    if (static_cast<int>(static_cast<size_t>(ids_all[j]) % world) == exact_rank) {
+                        ids_own.push_back(ids_all[j]);
+                        ge_own.insert(ge_own.end(), ge_all.begin() + j * de, ge_all.begin() + (j + 1) * de);
+                    }
+                std::vector<SparseGrad<F>> ge{{ge_own.data(), ids_own.size(), de, ids_own.data(), 1, static_cast<const F*>(nullptr)}};
+                entities_upd.update(&entities, &ge, lr, scaled_lambda);
+                owned_row_exchange();
+            } else {
             std::vector<SparseGrad<F>> ge{{ge_all.data(), N * world, static_cast<size_t>(cfg.entity_dim), ids_all.data(), 1,
                                            static_cast<const F*>(nullptr)}};
             entities_upd.update(&entities, &ge, lr, scaled_lambda);
+            }
             std::vector<SparseGrad<F>> gw{{gp_all.data(), f.B * world, static_cast<size_t>(cfg.word_dim), words_all.data(), f.window,
                                            ww_all.data()}};
             words_upd.update(&words, &gw, lr, scaled_lambda);

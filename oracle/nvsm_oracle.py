@@ -99,6 +99,7 @@ def lib():
         "orc_model_update": (C.c_int, [vp, dbl, dbl]), "orc_model_scaled_lambda": (dbl, [vp]),
         "orc_model_set_allreduce": (None, [vp, ALLREDUCE_FN, vp, C.c_int]),
         "orc_model_set_exact_tables": (None, [vp, C.c_int]),
+        "orc_model_set_owner_rows": (None, [vp, C.c_int]),
         "orc_model_gradcheck": (C.c_int, [vp, vp, vp, vp, vp, i64, dbl, dbl, P(dbl), P(C.c_int)]),
         "orc_num_threads": (C.c_int, []), "orc_set_num_threads": (None, [C.c_int]),
         "orc_reps_create": (vp, [i64, i64, C.c_int, C.c_int, dbl, dbl, dbl, C.c_int]), "orc_reps_free": (None, [vp]),
@@ -254,6 +255,11 @@ class Model:
         """Data-parallel test hook (after set_allreduce): update() applies every rank's sparse gradients, in rank order —
         the single-process update on the global batch. rank < 0 switches it off."""
         lib().orc_model_set_exact_tables(self.h, rank)
+
+    def set_owner_rows(self, on=True):
+        """Data-parallel test hook (after set_exact_tables): the documents table partitioned by owner, row r -> rank r mod world:
+        a rank applies only the entries of its own rows and the ranks then exchange their rows."""
+        lib().orc_model_set_owner_rows(self.h, int(bool(on)))
 
     def backward(self):
         lib().orc_model_backward(self.h)

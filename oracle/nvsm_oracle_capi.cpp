@@ -64,6 +64,7 @@ struct ModelBase {
     virtual int gradcheck(const idx_t*, const double*, const idx_t*, const double*, size_t, double, double, double*, int*) = 0;
     virtual void set_allreduce(int (*fn)(double*, int64_t, void*), void* user, int world) = 0;
     virtual void set_exact_tables(int rank) = 0;
+    virtual void set_owner_rows(int on) = 0;
 };
 
 template <typename F>
@@ -106,6 +107,7 @@ struct ModelImpl : ModelBase {
         else m.allreduce = nullptr;
     }
     void set_exact_tables(int rank) override { m.exact_rank = rank; }
+    void set_owner_rows(int on) override { m.owner_rows_entities = on != 0; }
     void backward() override { m.backward(); }
     void update(double lr, double sl) override { m.update(static_cast<F>(lr), static_cast<F>(sl)); }
     double scaled_lambda() override { return static_cast<double>(m.scaled_regularization_lambda()); }
@@ -300,6 +302,7 @@ void orc_model_set_allreduce(void* h, int (*fn)(double*, int64_t, void*), void* 
     static_cast<ModelBase*>(h)->set_allreduce(fn, user, world);
 }
 void orc_model_set_exact_tables(void* h, int rank) { static_cast<ModelBase*>(h)->set_exact_tables(rank); }
+void orc_model_set_owner_rows(void* h, int on) { static_cast<ModelBase*>(h)->set_owner_rows(on); }
 double orc_model_scaled_lambda(void* h) { return static_cast<ModelBase*>(h)->scaled_lambda(); }
 int orc_model_gradcheck(void* h, const idx_t* words, const double* ww, const idx_t* ids, const double* iw, int64_t B,
                         double eps, double thresh, double* max_rel, int* num_checked) {

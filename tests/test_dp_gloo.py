@@ -238,7 +238,7 @@ def _traj_batches(spec):
     return params, batches
 
 
-def _worker_traj(rank, port, spec, out_dir, use_gpu, exact=False, lr=None, separate_calls=False, transport="gloo"):
+def _worker_traj(rank, port, spec, out_dir, use_gpu, exact=False, lr=None, separate_calls=False, transport="gloo", owner_rows=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from cunvsm_amd import dp
@@ -257,6 +257,8 @@ def _worker_traj(rank, port, spec, out_dir, use_gpu, exact=False, lr=None, separ
         m.set_allreduce(dp.torch_allreduce(dist), WORLD)
         if exact:
             m.set_exact_tables(rank)
+        if owner_rows:
+            m.set_owner_rows(True)
     costs, tickets = [], []
     for words, ww, labels, iw, ids in batches:
         w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
@@ -355,6 +357,41 @@ def test_dp_exact_tables_oracle(tmp_path, method):
     np.testing.assert_allclose(r[0]["E"], o.get("entity_representations-representations"), rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(r[0]["W"], o.get("word_representations-representations"), rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(r[0]["T"], o.get("word_entity_mapping-transform"), rtol=1e-7, atol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------
+# owner-partitioned documents table (SURVEY.md §8e's "exact alternative"): row r of E and of its optimiser state
+# belongs to rank r mod G; every rank applies, of the global batch's gathered sparse gradients, only the entries of ITS rows
+# (1 / G of the update's work, optimiser state sharded), and the ranks then exchange their rows. CPU proof on the fp64 oracle
+# over gloo: the 20-step trajectory is the single process's — same losses, same tables — for every optimiser, and no rank
+# ever applied another rank's rows. (The HIP side is not built: there is no multi-GPU box to time the exchange on.)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("method", ["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
+def test_dp_owner_partitioned_documents_oracle(tmp_path, method):
+    import torch.multiprocessing as mp
+    from tests.helpers import load_params, oracle_model
+    spec = dict(TRAJ_SPEC, update_method=method)
+    port = _free_port()
+    mp.spawn(_worker_traj, args=(port, spec, str(tmp_path), False, True, None, False, "gloo", True), nprocs=WORLD, join=True)
+    params, batches = _traj_batches(spec)
+    o = oracle_model(spec)
+    load_params(o, params, False)
+    costs = []
+    for words, ww, labels, iw, ids in batches:
+        o.forward(words, ww, ids, iw)
+        o.backward()
+        costs.append(o.get_cost())
+        o.update(TRAJ_LR)
+    r = [np.load(os.path.join(str(tmp_path), "traj_rank%d.npz" % k)) for k in range(WORLD)]
+    for name in ("E", "W", "T"):
+        np.testing.assert_array_equal(r[0][name], r[1][name])            # replicas identical after the row exchange
+    np.testing.assert_allclose(r[0]["cost"], costs, rtol=1e-9)
+    # a row is updated by ONE rank from the same entries in the same order as the single process does; what differs is the
+    # summation order of the all-reduced batch statistics behind the gradients (1e-12 relative in fp64)
+    np.testing.assert_allclose(r[0]["E"], o.get("entity_representations-representations"), rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(r[0]["W"], o.get("word_representations-representations"), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(r[0]["T"], o.get("word_entity_mapping-transform"), rtol=1e-7, atol=1e-10)
+    assert np.linalg.norm(r[0]["E"] - params["entity_representations-representations"].astype(np.float64).ravel()) > 0      # it trained
 
 
 @pytest.mark.gpu

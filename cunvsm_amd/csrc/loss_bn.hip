@@ -360,12 +360,13 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
     if (LAZY) { dlo = a.lazyE.decay[lane]; dhi = a.lazyE.decay[lane + 64]; }
 
     float xn[4] = {0, 0, 0, 0};
-    int idn = 0;
+    int idn = 0, stampn = 0;
     float wn = 1.f;
     if (e0 < e1) {
         ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.pre + e0 * de) + coff), xn);
         idn = a.ids[e0 * R + lane_r];
         if (a.inst_w) wn = a.inst_w[e0];
+        if (LAZY) stampn = a.lazyE.stamp[static_cast<uint32_t>(idn)];
     }
     for (int64_t b = e0; b < e1; ++b) {
         float x[4];
@@ -373,8 +374,9 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
         for (int i = 0; i < 4; ++i) x[i] = xn[i];
         const int myid = idn;
         float w = wn;
-        int mystamp = 0;
-        if (LAZY) mystamp = a.lazyE.stamp[static_cast<uint32_t>(myid)];
+        // (LAZY: the stamps of this example's rows were requested at the end of the turn before — a dependent load behind the
+        //  ids, which it used to follow right here, in front of the row loads that need the ids too)
+        const int mystamp = stampn;
 
         float e[RB][4];
 #pragma unroll
@@ -467,6 +469,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
             sdyx[i] += g[i] * xhat[i];
         }
         if (valid) stv<4>(a.dy + b * de + c, g);
+        if (LAZY && b + 1 < e1) stampn = a.lazyE.stamp[static_cast<uint32_t>(idn)];      // (idn arrived long ago)
     }
     const float wave_loss = wave_sum(lane_loss);
     float* s_dy = lds; float* s_dyx = lds + 4 * de; float* s_loss = lds + 8 * de;

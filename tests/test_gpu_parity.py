@@ -49,7 +49,7 @@ def test_gemm_large_batch_kernels(M, N, K, layout, monkeypatch):
     test_gemm_layouts(M, N, K, layout)
 
 
-@pytest.mark.parametrize("M", [1024, 3333, 16390])
+@pytest.mark.parametrize("M", [1024, 3333, 16390, 51200])      # (51 200: the metric's batch — 200 rows per workgroup, 256 workgroups)
 @pytest.mark.parametrize("layout,N,K", [(0, 256, 300), (1, 300, 256), (1, 272, 64)])
 def test_gemm_split_bf16_is_fp32_accurate(M, layout, N, K, monkeypatch):
     """gemm_split.hip: fp32 operands cut exactly into three bf16 planes, nine or six bf16 MFMAs per product, fp32 accumulation.

@@ -1,6 +1,7 @@
 #include "rendezvous.hpp"
 
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -111,6 +112,10 @@ bool rendezvous_read(const std::string& path, const std::string& nonce, int64_t 
     if (std::memcmp(h.magic, kMagic, 8) != 0 || h.id_bytes != kCommIdBytes) return no("is not a rendezvous file");
     if (h.nonce_hash != fnv1a(nonce)) return no("belongs to another run (nonce)");
     if (h.created_ns < not_before_ns) return no("is older than this run");
+    // The writer (rank 0 of this launch) is alive for as long as anybody may read the file: a file whose writer is gone was left
+    // behind by a run that crashed — a relaunch from the same shell within the clock-skew window carries the same fall-back nonce
+    // (parent pid + port), and its ranks would otherwise join a communicator id nobody is waiting on. (Same host: one node.)
+    if (h.pid == 0 || (::kill(static_cast<pid_t>(h.pid), 0) != 0 && errno == ESRCH)) return no("was written by a process that no longer exists (stale)");
     std::memcpy(id, buf, kCommIdBytes);
     return true;
 }

@@ -531,6 +531,7 @@ static void test_IndriRepository_docno_lookups() {
 // ---- the RCCL id rendezvous of a data-parallel run (no reference counterpart: host/rendezvous.hpp) ----
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 static void test_Rendezvous() {
     char dir_t[] = "/tmp/nvsm_rdv_XXXXXX";
@@ -553,6 +554,17 @@ static void test_Rendezvous() {
     EXPECT_EQ(why, std::string("is older than this run"));
     EXPECT_TRUE(!rendezvous_read(path, "run:other", t0, got, &why));
     EXPECT_EQ(why, std::string("belongs to another run (nonce)"));
+    // a file whose writer has died (a crashed run relaunched from the same shell: same fall-back nonce): written by a child that
+    // has exited and been reaped — its pid names no process
+    rendezvous_clear(path);
+    {
+        const pid_t child = ::fork();
+        if (child == 0) { rendezvous_publish(path, nonce, id); ::_exit(0); }
+        int status = 0;
+        EXPECT_TRUE(child > 0 && ::waitpid(child, &status, 0) == child);
+        EXPECT_TRUE(!rendezvous_read(path, nonce, t0, got, &why));
+        EXPECT_EQ(why, std::string("was written by a process that no longer exists (stale)"));
+    }
     // what the old protocol wrote (the bare 128 bytes) is not taken for an id
     rendezvous_clear(path);
     { const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT, 0600); EXPECT_TRUE(fd >= 0 && ::write(fd, id, kCommIdBytes) == kCommIdBytes); ::close(fd); }

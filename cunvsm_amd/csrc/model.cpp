@@ -1672,12 +1672,12 @@ int Model::csr_stream_layout() const {
 // for 18 us alone, exactly as long as the 128 x 128-tiled fp32 kernel takes there, whose small workgroups slip in between the
 // passes' and leave the step shorter: batch 6 400 / 12 800 / 25 600: 0.291 / 0.403 / 0.584 ms tiled against 0.312 / 0.426 /
 // 0.610 (0.340 / 0.438 / 0.593 with this kernel on the main stream). Interleaved A/B, tools/ab_shapes.sh.
-bool Model::use_dt() const { return dt_ok_ && gemm_split_products() != 0 && B_ >= 40960; }
+bool Model::use_dt() const { return dt_ok_ && gemm_split_products() != 0 && B_ >= tune_.dt_min_batch; }
 
 // the fused step's dT product on the main stream (see step()): large batches of eager tables
 bool Model::dt_on_main() const {
     const int dt_main_env = tune_.dt_on_main;
-    return (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy)) && cfg_.world_size <= 1 && use_dt();
+    return (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy && use_dt())) && cfg_.world_size <= 1;
 }
 
 // T changed: its bf16 planes for the next two projection products, behind the writer on the writer's stream (off the critical

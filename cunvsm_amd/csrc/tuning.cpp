@@ -67,6 +67,7 @@ Tuning Tuning::from_env() {
     t.aux3_prio = env_int("NVSM_AUX3_PRIO", t.aux3_prio);
     t.event_fence = env_int("NVSM_EVENT_FENCE", t.event_fence);
     t.dt_slabs = env_int("NVSM_DT_SLABS", t.dt_slabs);
+    t.dt_min_batch = env_int("NVSM_DT_MIN_B", t.dt_min_batch);
     t.untouched_aside = env_flag("NVSM_UNTOUCHED_ASIDE", t.untouched_aside);
 #endif
     return t;

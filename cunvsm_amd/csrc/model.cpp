@@ -1315,7 +1315,7 @@ void Model::backward_T(hipStream_t strm) {
             // the main stream 48 slabs (96 workgroups, 15 MB of partials) — 0.891 ms per step against 0.90 with 128 and 0.899 with
             // 32; full_adam 0.764 / 0.79 / 0.763 —; on side stream 2 next to both table passes of a lazily decayed pair of tables
             // 16 (|D| = 2 M: 1.61 ms against 1.65 with 128). Interleaved A/B, tools/ab_shapes.sh.
-            const int want = std::min(strm == stream_ ? 48 : 16, gemm_dt_default_slabs(static_cast<int>(B), num_cus_));
+            const int want = std::min(tune_.dt_slabs > 0 ? tune_.dt_slabs : (strm == stream_ ? 48 : 16), gemm_dt_default_slabs(static_cast<int>(B), num_cus_));
             const int dslabs = gemm_dt_slabs(static_cast<int>(B), want);
             bool ok = true;
             timed_launch(prof, "gemm_bwd_T", strm, true, [&] {
@@ -1772,6 +1772,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         update_entities(lr, sl, stream_, nullptr);
     } else if (docs_on_main == 0) {
         if (!loss_event) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_bwdx_, 0));
+        if (tune_.docs_delay_us > 0) launch_delay(tune_.docs_delay_us, aux_stream_);      // (experiments)
         update_entities(lr, sl, aux_stream_, (docs_after_dx && loss_event) ? ev_bwdx_ : nullptr);
         NVSM_HIP_CHECK(hipEventRecord(ev_E_done_, aux_stream_));
         E_pending_ = true;

@@ -68,6 +68,7 @@ Tuning Tuning::from_env() {
     t.event_fence = env_int("NVSM_EVENT_FENCE", t.event_fence);
     t.dt_slabs = env_int("NVSM_DT_SLABS", t.dt_slabs);
     t.dt_min_batch = env_int("NVSM_DT_MIN_B", t.dt_min_batch);
+    t.docs_delay_us = env_int("NVSM_DOCS_DELAY_US", t.docs_delay_us);
     t.untouched_aside = env_flag("NVSM_UNTOUCHED_ASIDE", t.untouched_aside);
 #endif
     return t;

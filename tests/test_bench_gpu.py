@@ -58,9 +58,12 @@ def test_bench_single_gpu_line():
     lt, ls = d["secondary"]["large_tables"], d["secondary"]["lse_small"]
     assert lt["batch"] == 51200 and lt["ms_per_step"] > d["ms_per_step"] and 0.2 < lt["roofline"]["frac"] < 1.0
     assert ls["batch"] == 4096 and ls["update_method"] == "adagrad" and 0 < ls["ms_per_step"] < 1.0
-    # the dT product is timed by its own launch: a kernel time, below the backward product's + the loss kernel's
-    assert not d["kernel_breakdown"]["gemm_bwd_T"].get("overlapped")
-    assert d["kernel_breakdown"]["gemm_bwd_T"]["avg_ms"] < d["kernel_breakdown"]["loss_fused"]["avg_ms"]
+    # the dT product is timed by events riding on its own launch: a kernel time (0.10-0.19 ms depending on whether it or the
+    # documents pass wins the CUs both want at the same instant — DESIGN 5.5 item 7), not the 0.3 ms a record pair around it on
+    # a busy stream once reported; the figure of a pass with no other records rides along
+    dt = d["kernel_breakdown"]["gemm_bwd_T"]
+    assert not dt.get("overlapped") and 0.03 < dt["avg_ms"] < 0.26 and 0.03 < dt["avg_ms_no_other_records"] < 0.26
+    assert "TFLOPs" not in d["kernel_breakdown"]["gemm_bwd_T_reduce"]
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.3 < roof["frac"] < 1.0

@@ -408,16 +408,6 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
         own_stream_ = true;
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, lo));
         const int aux2_prio = tune_.aux2_prio;   // (experiments) 0 lowest, 1 middle, 2 highest
-        if (tune_.aux2_cu_eighths >= 1 && tune_.aux2_cu_eighths <= 7) {
-            // (experiments) side stream 2 — the CSR builds where the dT product runs on the main stream — on a fixed share of the
-            // CUs, spread evenly whatever the order of the mask's bits
-            hipDeviceProp_t prop{};
-            NVSM_HIP_CHECK(hipGetDeviceProperties(&prop, cfg.device));
-            std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
-            for (int i = 0; i < prop.multiProcessorCount; ++i)
-                if ((i & 7) < tune_.aux2_cu_eighths) mask[i >> 5] |= 1u << (i & 31);
-            NVSM_HIP_CHECK(hipExtStreamCreateWithCUMask(&aux2_stream_, static_cast<uint32_t>(mask.size()), mask.data()));
-        } else
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux2_stream_, hipStreamNonBlocking, aux2_prio == 0 ? lo : (aux2_prio == 2 ? hi : (lo + hi) / 2)));
         // Four streams, not five: the runtime multiplexes streams onto four hardware queues, and with a fifth stream the
         // host-batch copies shared a queue with compute and stopped overlapping it (1.22 -> 1.7 ms per step with host

@@ -69,7 +69,6 @@ Tuning Tuning::from_env() {
     t.dt_slabs = env_int("NVSM_DT_SLABS", t.dt_slabs);
     t.dt_min_batch = env_int("NVSM_DT_MIN_B", t.dt_min_batch);
     t.docs_delay_us = env_int("NVSM_DOCS_DELAY_US", t.docs_delay_us);
-    t.aux2_cu_eighths = env_int("NVSM_AUX2_CUS", t.aux2_cu_eighths);
     t.untouched_aside = env_flag("NVSM_UNTOUCHED_ASIDE", t.untouched_aside);
 #endif
     return t;

@@ -53,7 +53,6 @@ struct Tuning {
     int aux2_prio = 0, aux3_prio = 1;   // NVSM_AUX2_PRIO / NVSM_AUX3_PRIO
     int event_fence = -1;               // NVSM_EVENT_FENCE
     int dt_slabs = 0;                   // NVSM_DT_SLABS (0: by batch size)
-    int aux2_cu_eighths = 0;            // NVSM_AUX2_CUS (1..7: side stream 2 confined to that many of every eight CUs)
     int docs_delay_us = 0;              // NVSM_DOCS_DELAY_US (a spin kernel in front of the documents update on its side stream)
     int dt_min_batch = 40960;           // NVSM_DT_MIN_B (the split-bf16 dT kernel from this batch size up)
     bool untouched_aside = true;        // NVSM_UNTOUCHED_ASIDE

@@ -164,6 +164,7 @@ struct LossArgs {
     float* bn_inv_std;        // [de] (bn) OUT
     const float* bias;        // [de] (bn: β)
     const float* E;           // [nD][de]
+    int64_t E_rows;           // nD (0: unknown) — which loop the gather runs depends on whether E fits the Infinity Cache
     LazyView lazyE;           // pending decay of E's rows, applied as they are gathered (stamp null: none)
     const int* ids;           // [B*R]
     const float* inst_w;      // [B] or null
@@ -189,6 +190,7 @@ struct LossArgs {
 void launch_loss(const LossArgs& a, hipStream_t s);
 // true: the kernel launch_loss picks for these shapes applies LossArgs::lazyE itself; false: the rows must be current
 bool loss_reads_lazily(int de, int R, bool l2_entity);
+bool loss_two_row_sets(int64_t table_rows, int de);      // the row-gathering loss kernel keeps two sets of rows in flight per wave (tables beyond the Infinity Cache)
 
 // per-row mean of squares: out[b] = Σ_t G[b][t]² · inv_dim  (cpp/updates_adam.cu:232-240)
 void launch_row_meansq(const float* G, int64_t rows, int dim, float inv_dim, float* out, hipStream_t s);

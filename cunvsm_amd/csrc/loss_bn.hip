@@ -330,7 +330,11 @@ __device__ __forceinline__ void loss_refresh_row(int from, int now, float dlo, f
     }
 }
 
-template <int RB, bool LAZY = false>
+// PIPE (R <= RB, the whole example's rows in one set): two register sets — the rows of example b + 1 are requested BEFORE the
+// arithmetic of example b, so a wave always has a set in flight (up to 2 RB rows) instead of alternating between "RB rows
+// requested" and "none while it computes"; two waves per SIMD instead of three. The arithmetic and its order are the same
+// statements (finish()): results are bit-identical to the single-set form.
+template <int RB, bool LAZY = false, bool PIPE = false>
 __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_wave) {
     // Floating-point contraction by the language rule (a product and a sum in ONE expression fuse, nothing else does),
     // not by the optimiser's choice: the LAZY and the eager instantiation — different loop structures around the same
@@ -359,39 +363,19 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
     float dlo = 1.f, dhi = 1.f;
     if (LAZY) { dlo = a.lazyE.decay[lane]; dhi = a.lazyE.decay[lane + 64]; }
 
-    float xn[4] = {0, 0, 0, 0};
-    int idn = 0, stampn = 0;
-    float wn = 1.f;
-    if (e0 < e1) {
-        ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.pre + e0 * de) + coff), xn);
-        idn = a.ids[e0 * R + lane_r];
-        if (a.inst_w) wn = a.inst_w[e0];
-        if (LAZY) stampn = a.lazyE.stamp[static_cast<uint32_t>(idn)];
-    }
-    for (int64_t b = e0; b < e1; ++b) {
-        float x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = xn[i];
-        const int myid = idn;
-        float w = wn;
-        // (LAZY: the stamps of this example's rows were requested at the end of the turn before — a dependent load behind the
-        //  ids, which it used to follow right here, in front of the row loads that need the ids too)
-        const int mystamp = stampn;
-
-        float e[RB][4];
+    // rows r0 .. r0 + RB - 1 of the example whose ids the lanes hold in `ids_lane`, one 16 B column slice per lane
+    auto issue_rows = [&](float (&e)[RB][4], int ids_lane, int r0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const int r = min(u, R - 1);
-            const size_t id = static_cast<size_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(myid, r)));
+            const int r = min(r0 + u, R - 1);
+            const size_t id = static_cast<size_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(ids_lane, r)));
             const char* rowp = reinterpret_cast<const char*>(a.E + id * de);
             ldv<4>(reinterpret_cast<const float*>(rowp + coff), e[u]);
         }
-        if (b + 1 < e1) {
-            ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.pre + (b + 1) * de) + coff), xn);
-            idn = a.ids[(b + 1) * R + lane_r];
-            if (a.inst_w) wn = a.inst_w[b + 1];
-        }
-
+    };
+    // everything of example b behind its loads: projection row, the R dot products, loss, multipliers, dy and the column sums
+    // (`e` holds rows 0 .. RB - 1 on entry; further sets of RB rows are fetched here)
+    auto finish = [&](int64_t b, const float (&x)[4], int myid, float w, int mystamp, float (&e)[RB][4]) __attribute__((always_inline)) {
         float out[4], xhat[4] = {0, 0, 0, 0}, gp[4] = {0, 0, 0, 0};
         float ssq = 0.f;
 #pragma unroll
@@ -411,15 +395,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
         const float w_pos = a.rebalance ? w * static_cast<float>(a.k) : w;
 
         for (int r0 = 0; r0 < R; r0 += RB) {
-            if (r0 > 0) {
-#pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    const int r = min(r0 + u, R - 1);
-                    const size_t id = static_cast<size_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(myid, r)));
-                    const char* rowp = reinterpret_cast<const char*>(a.E + id * de);
-                    ldv<4>(reinterpret_cast<const float*>(rowp + coff), e[u]);
-                }
-            }
+            if (r0 > 0) issue_rows(e, myid, r0);
             if (LAZY) {
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
@@ -469,7 +445,63 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
             sdyx[i] += g[i] * xhat[i];
         }
         if (valid) stv<4>(a.dy + b * de + c, g);
-        if (LAZY && b + 1 < e1) stampn = a.lazyE.stamp[static_cast<uint32_t>(idn)];      // (idn arrived long ago)
+    };
+    auto load_inputs = [&](int64_t b, float (&x)[4], int& id, float& w) __attribute__((always_inline)) {
+        ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.pre + b * de) + coff), x);
+        id = a.ids[b * R + lane_r];
+        if (a.inst_w) w = a.inst_w[b];
+    };
+
+    if constexpr (!PIPE) {
+        float xn[4] = {0, 0, 0, 0};
+        int idn = 0, stampn = 0;
+        float wn = 1.f;
+        if (e0 < e1) {
+            load_inputs(e0, xn, idn, wn);
+            if (LAZY) stampn = a.lazyE.stamp[static_cast<uint32_t>(idn)];
+        }
+        for (int64_t b = e0; b < e1; ++b) {
+            float x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = xn[i];
+            const int myid = idn;
+            const float w = wn;
+            // (LAZY: the stamps of this example's rows were requested at the end of the turn before — a dependent load behind the
+            //  ids, which it used to follow right here, in front of the row loads that need the ids too)
+            const int mystamp = stampn;
+            float e[RB][4];
+            issue_rows(e, myid, 0);
+            if (b + 1 < e1) load_inputs(b + 1, xn, idn, wn);
+            finish(b, x, myid, w, mystamp, e);
+            if (LAZY && b + 1 < e1) stampn = a.lazyE.stamp[static_cast<uint32_t>(idn)];      // (idn arrived long ago)
+        }
+    } else {
+        // inputs run two examples ahead (the ids of b + 1 must have arrived when its rows are requested, at the start of turn b)
+        float xc[4] = {0, 0, 0, 0}, x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+        int idc = 0, id1 = 0, id2 = 0, stampc = 0, stamp1 = 0;
+        float wc = 1.f, w1 = 1.f, w2 = 1.f;
+        float eA[RB][4], eB[RB][4];
+        if (e0 < e1) {
+            load_inputs(e0, xc, idc, wc);
+            if (LAZY) stampc = a.lazyE.stamp[static_cast<uint32_t>(idc)];
+            issue_rows(eA, idc, 0);
+            if (e0 + 1 < e1) load_inputs(e0 + 1, x1, id1, w1);
+        }
+        auto turn = [&](int64_t b, float (&cur)[RB][4], float (&nxt)[RB][4]) __attribute__((always_inline)) {
+            if (b + 1 < e1) {
+                issue_rows(nxt, id1, 0);
+                if (LAZY) stamp1 = a.lazyE.stamp[static_cast<uint32_t>(id1)];
+            }
+            if (b + 2 < e1) load_inputs(b + 2, x2, id2, w2);
+            finish(b, xc, idc, wc, stampc, cur);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xc[i] = x1[i]; x1[i] = x2[i]; }
+            idc = id1; id1 = id2; wc = w1; w1 = w2; stampc = stamp1;
+        };
+        for (int64_t b = e0; b < e1; b += 2) {
+            turn(b, eA, eB);
+            if (b + 1 < e1) turn(b + 1, eB, eA);
+        }
     }
     const float wave_loss = wave_sum(lane_loss);
     float* s_dy = lds; float* s_dyx = lds + 4 * de; float* s_loss = lds + 8 * de;
@@ -511,13 +543,30 @@ static void launch_loss_rows(const LossArgs& a_in, hipStream_t s) {
     if (a.B >= 40960) epw = 20;
     // (batch 4096: two examples per wave, 512 workgroups — half as many fp64 atomics per column: 44 -> 33 us)
     if (epw < 2 && a.B >= 2048) epw = 2;
+    // Two row sets per wave (PIPE; two workgroups per CU — one round of 512 from 40 k examples) where the documents table does
+    // not fit the 256 MB Infinity Cache and every row comes out of HBM at 1 800 cycles: |D| = 2 M, batch 51 200: 295 -> 244 us
+    // in the step (0.44 -> 0.54 of peak), step 1.725 -> 1.697 ms. Where the table is cache-resident (|D| = 100 k) the kernel
+    // gains 6 us (179 -> 173) and the STEP loses 8 (0.894 -> 0.902: the CSR builds next to it finish later): single set.
+    // Interleaved A/B, tools/ab_roof.sh; NVSM_LOSS_PIPE=0/1 (experiments build) overrides.
+    const bool pipe = a.R <= RB && loss_two_row_sets(a.E_rows, a.de);
+    if (pipe && a.B >= 40960) epw = static_cast<int>((a.B + 4 * 512 - 1) / (4 * 512));
     const int epw_env = tuning().loss_epw;      // experiments
     if (epw_env > 0) epw = epw_env;
     const int grid = ceil_div(a.B, 4 * epw);
     a.sums.fan = grid_sum_fan(grid);
     const size_t shmem = (8 * static_cast<size_t>(a.de) + 8) * sizeof(float);
+    if (pipe) {
+        if (a.lazyE.stamp) NVSM_LAUNCH((loss_rows_kernel<RB, true, true>), dim3(grid), dim3(256), shmem, s, a, epw);
+        else NVSM_LAUNCH((loss_rows_kernel<RB, false, true>), dim3(grid), dim3(256), shmem, s, a, epw);
+        return;
+    }
     if (a.lazyE.stamp) NVSM_LAUNCH((loss_rows_kernel<RB, true>), dim3(grid), dim3(256), shmem, s, a, epw);
     else NVSM_LAUNCH((loss_rows_kernel<RB, false>), dim3(grid), dim3(256), shmem, s, a, epw);
+}
+
+bool loss_two_row_sets(int64_t table_rows, int de) {
+    const int pipe_env = tuning().loss_pipe;
+    return pipe_env >= 0 ? pipe_env != 0 : table_rows * static_cast<int64_t>(de) * 4 > (static_cast<int64_t>(256) << 20);
 }
 
 bool loss_reads_lazily(int de, int R, bool l2_entity) { return de % 4 == 0 && de <= 256 && R <= 64 && !l2_entity; }

@@ -1097,7 +1097,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         LossArgs a{};
         a.pre = pre_.p; a.bn_mean = bn_mean_.p; a.bn_inv_std = bn_inv_std_.p; a.bias = b_.p;
         a.bn_sums = stats_fwd_; a.bn_n = bn_n; a.bn_eps = 1e-4f;
-        a.E = ents_.P.p; a.ids = ids_p_; a.inst_w = instw_;
+        a.E = ents_.P.p; a.E_rows = ents_.rows; a.ids = ids_p_; a.inst_w = instw_;
         a.proj = proj_.p; a.dy = dy_.p; a.coef = coef_.p; a.probs = probs_.p; a.pp = pp_.p;
         a.loss_acc = stats_bwd_; a.colstats = stats_bwd_ + 1; a.sums = sums_bwd_.ws;
         a.B = B; a.de = de; a.R = R_; a.k = k;
@@ -1124,6 +1124,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
                 lazy_refresh(ents_, &ce, stream_);
             }
         }
+        if (loss_reads_lazily(a.de, a.R, a.l2_entity != 0) && a.R <= 17 && loss_two_row_sets(a.E_rows, a.de)) prof.note("loss_two_row_sets");
         // (the fused step at small batches starts the documents update behind the loss kernel: ev_loss_ rides on the kernel)
         if (loss_stop_event_) { launch_and_record(loss_stop_event_, stream_, [&] { launch_loss(a, stream_); }); loss_stop_event_ = nullptr; }
         else if (prof_bound) {
@@ -1647,11 +1648,14 @@ std::string Model::describe(int64_t batch) const {
     const bool fuse = !l2p && B >= 512 && (B <= gemm_rows_max_m() || tune_.split_fuse);
     out += " | backward " + product(1, dw, de, false, need_msq && !l2p, fuse) + (fuse ? " with the batch-norm backward / bias gradient inside" : "");
     // (B_ decides use_dt() / dt_on_main() at run time: evaluated here for `B`)
-    const bool dt = dt_ok_ && gemm_split_products() != 0 && B >= 40960;
+    const bool dt = dt_ok_ && gemm_split_products() != 0 && B >= tune_.dt_min_batch;
     const bool lazy = words_.lazy || ents_.lazy;
     const bool dt_main = (tune_.dt_on_main >= 0 ? tune_.dt_on_main != 0 : (B >= 40960 && !lazy)) && cfg_.world_size <= 1 && dt;
     out += std::string(" | dT ") + (dt ? "gemm_dt (3 bf16 planes, split-K)" : "gemm_f32_mfma / gemm_panel split-K (exact fp32 MFMA)") +
            (dt_main ? " on the main stream" : " on side stream 2");
+    if (loss_reads_lazily(de, static_cast<int>(R_), cfg_.l2_normalize_entity_reprs != 0))      // (= the row-gathering kernel covers the shape)
+        out += std::string(" | loss loss_rows (") + (R_ <= 17 && loss_two_row_sets(ents_.rows, de) ? "two row sets per wave: documents table beyond the Infinity Cache" : "one row set per wave") + ")";
+    else out += " | loss loss_kernel (generic)";
     out += std::string(" | tables: words ") + (words_.lazy ? "lazy" : "eager") + " decay, documents " + (ents_.lazy ? "lazy" : "eager") + " decay";
     out += " | CSR stream layout " + std::to_string(tune_.sort_layout >= 0 ? tune_.sort_layout : (dt_main ? 2 : 4));
     char buf[512];

@@ -52,6 +52,7 @@ Tuning Tuning::from_env() {
     t.gemm_tstat = env_int("NVSM_GEMM_TSTAT", t.gemm_tstat);
     t.gemm_tstat_fwd_any = env_int("NVSM_GEMM_TSTAT_FWD_ANY", t.gemm_tstat_fwd_any);
     t.loss_epw = env_int("NVSM_LOSS_EPW", t.loss_epw);
+    t.loss_pipe = env_int("NVSM_LOSS_PIPE", t.loss_pipe);
     t.csr_after = env_int("NVSM_CSR_AFTER", t.csr_after);
     t.words_csr_late = env_int("NVSM_WORDS_CSR_LATE", 0) == 1;
     t.join_e = env_int("NVSM_JOIN_E", t.join_e);

@@ -39,6 +39,7 @@ struct Tuning {
     int gemm_tstat = 3;                 // NVSM_GEMM_TSTAT
     int gemm_tstat_fwd_any = -1;        // NVSM_GEMM_TSTAT_FWD_ANY
     int loss_epw = 0;                   // NVSM_LOSS_EPW
+    int loss_pipe = -1;                 // NVSM_LOSS_PIPE (two row sets per wave in the loss kernel: -1 by rule, 0 off, 1 on)
     int csr_after = 0;                  // NVSM_CSR_AFTER
     bool words_csr_late = false;        // NVSM_WORDS_CSR_LATE
     int join_e = 0;                     // NVSM_JOIN_E

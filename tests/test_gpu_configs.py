@@ -131,6 +131,8 @@ def test_large_tables_rows_evolve_as_compacted_oracle(method, B, steps, word_ids
     # both tables and decay lazily; full_adam touches every row of a table on every update whatever the batch
     walked = {t for t in ("entities", "words") if prof.get("entry_walk_" + t, (0, 0))[1] == steps}
     lazy = {t for t in ("entities", "words") if prof.get("lazy_stamp_" + t, (0, 0))[1] == steps}
+    # (|D| = 2 M x 256 floats is 2 GB, beyond the Infinity Cache: the loss kernel keeps two sets of document rows in flight per wave)
+    assert prof.get("loss_two_row_sets", (0, 0))[1] == steps, prof.keys()
     if B >= 51200 and method == "sparse_adam":
         assert walked == {"entities", "words"} and lazy == {"entities", "words"}, prof.keys()
     elif method == "full_adam":

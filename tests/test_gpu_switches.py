@@ -69,6 +69,8 @@ EXP_VARIANTS = [
     {"NVSM_PULL_BLOCKS": "3"},
     {"NVSM_UNTOUCHED_ASIDE": "0"},
     {"NVSM_GEMM_PANEL": "0"},
+    {"NVSM_LOSS_PIPE": "1"},
+    {"NVSM_LOSS_PIPE": "0"},
     {"NVSM_STOP_EVENTS": "0", "NVSM_EVENT_FENCE": "0", "NVSM_HOST_PULL": "0", "NVSM_UNTOUCHED_ASIDE": "0"},
 ]
 DBG_LIB = os.path.join(ROOT, "cunvsm_amd", "libcunvsm_amd_dbg.so")
@@ -97,6 +99,8 @@ LARGE_EXP_VARIANTS = [
     {"NVSM_WORDS_CSR_LATE": "1"},
     {"NVSM_AUX2_PRIO": "2", "NVSM_SPLIT_NT": "1"},
     {"NVSM_SPLIT_FUSE": "0"},
+    {"NVSM_LOSS_PIPE": "1"},
+    {"NVSM_LOSS_PIPE": "0"},
 ]      # (not NVSM_DT_ON_MAIN: the dT product is cut into 48 slabs on the main stream and 16 on side stream 2 — another summation order)
 
 
@@ -161,3 +165,7 @@ def test_describe_names_the_kernels_a_step_takes():
         assert ("dT gemm_dt" in d) == want_dt and ("on the main stream" in d) == want_dt, d
         assert ("forward gemm_split" in d) == (B > 8192) and ("forward gemm_rows" in d) == (B <= 8192), d
         assert "CSR stream layout %d" % (2 if want_dt else 4) in d, d
+        assert "loss loss_rows (one row set per wave)" in d, d
+    # a documents table beyond the 256 MB Infinity Cache: the loss kernel keeps two sets of rows in flight per wave
+    big = gpu_model(dict(spec, num_entities=300000), 2048, sampler=ca.SAMPLER_DEVICE)
+    assert "two row sets per wave" in big.describe(), big.describe()

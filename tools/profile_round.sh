@@ -12,12 +12,12 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
 BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs $*"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- $BENCH > $OUT/bench_stats.json 2> $OUT/bench_stats.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o bench -- $BENCH --steps 6 > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o bench -- $BENCH --steps 6 > $OUT/bench_write.json 2> $OUT/bench_write.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace -d $OUT/mfma -o bench -- $BENCH --steps 6 > $OUT/bench_mfma.json 2> $OUT/bench_mfma.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- $BENCH > $OUT/bench_stats.json 2> $OUT/bench_stats.err
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o bench -- $BENCH --steps 6 > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o bench -- $BENCH --steps 6 > $OUT/bench_write.json 2> $OUT/bench_write.err
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace -d $OUT/mfma -o bench -- $BENCH --steps 6 > $OUT/bench_mfma.json 2> $OUT/bench_mfma.err
 # the GPU-side schedule of one steady-state step: a spin kernel in front of every step lets the host queue it first
-rocprofv3 --kernel-trace -d $OUT/tl -o bench -- $BENCH --steps 8 --gate-us 4000 --no-profile > $OUT/bench_tl.json 2> $OUT/bench_tl.err
+timeout 400 rocprofv3 --kernel-trace -d $OUT/tl -o bench -- $BENCH --steps 8 --gate-us 4000 --no-profile > $OUT/bench_tl.json 2> $OUT/bench_tl.err
 cd $ROOT
 S=$(find $OUT/stats -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | head -1); W=$(find $OUT/write -name "*.db" | head -1)
 M=$(find $OUT/mfma -name "*.db" | head -1); T=$(find $OUT/tl -name "*.db" | head -1)

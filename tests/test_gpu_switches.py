@@ -93,6 +93,7 @@ LARGE_VARIANTS = [
     {"NVSM_SORT_LAYOUT": "2"},
     {"NVSM_SORT_LAYOUT": "1"},
     {"NVSM_STOP_EVENTS": "0", "NVSM_HOST_PULL": "0"},
+    {"NVSM_POISON": "1"},      # (uncleared device buffers start as 0xFF bytes: the dT product's partials, the loss kernel's sums)
 ]
 LARGE_EXP_VARIANTS = [
     {},

@@ -1314,9 +1314,11 @@ void Model::backward_T(hipStream_t strm) {
             // Slabs: the kernel ALONE is fastest with a workgroup on every CU (128 slabs: 55 us at batch 51 200), but in a step it
             // runs next to the documents pass, which wants the CUs it leaves free and the bandwidth its partials do not take: on
             // the main stream 48 slabs (96 workgroups, 15 MB of partials) — 0.891 ms per step against 0.90 with 128 and 0.899 with
-            // 32; full_adam 0.764 / 0.79 / 0.763 —; on side stream 2 next to both table passes of a lazily decayed pair of tables
-            // 16 (|D| = 2 M: 1.61 ms against 1.65 with 128). Interleaved A/B, tools/ab_shapes.sh.
-            const int want = std::min(tune_.dt_slabs > 0 ? tune_.dt_slabs : (strm == stream_ ? 48 : 16), gemm_dt_default_slabs(static_cast<int>(B), num_cus_));
+            // 32; full_adam 0.764 / 0.79 / 0.763 —; on side stream 2 next to both table passes of lazily decayed tables the same 48
+            // (|V| = 500 k, |D| = 2 M: 1.696 ms against 1.739 with 16 slabs, 1.704 with 32 / 64, 1.717 with 128, 1.86 with 8 — with few
+            // slabs the product, trickling onto CUs as they fall empty, is what the next step waits for; |V| = 50 k, |D| = 2 M:
+            // 1.497 against 1.486 with 16). Interleaved A/B, tools/ab_shapes.sh; NVSM_DT_SLABS (experiments build) overrides.
+            const int want = std::min(tune_.dt_slabs > 0 ? tune_.dt_slabs : 48, gemm_dt_default_slabs(static_cast<int>(B), num_cus_));
             const int dslabs = gemm_dt_slabs(static_cast<int>(B), want);
             bool ok = true;
             timed_launch(prof, "gemm_bwd_T", strm, true, [&] {

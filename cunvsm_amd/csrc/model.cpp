@@ -301,6 +301,18 @@ static int bits_for(int64_t n) {
     return b;
 }
 
+// whether a table of this size, updated from at most `max_entries` entries per step, decays lazily (see alloc_table)
+bool Model::table_decays_lazily(bool documents, int64_t rows, int dim, int64_t max_entries) const {
+    const int method = cfg_.update_method, mode = cfg_.adam_mode;
+    const bool sparse_adam = method == NVSM_ADAM && mode <= NVSM_ADAM_SPARSE;
+    const bool decays = sparse_adam || (method != NVSM_ADAM && cfg_.regularization_lambda > 0.f);
+    const double lazy_min_mb = tune_.lazy_min_mb >= 0.0 ? tune_.lazy_min_mb : (sparse_adam ? 96.0 : 384.0);
+    const double state_mb = static_cast<double>(rows) * dim * sizeof(float) * (method == NVSM_ADAM ? 2.0 : 1.0) / 1048576.0;
+    const int tab_mask = tune_.lazy_tables;          // experiments: bit 0 = words, bit 1 = documents
+    return tune_.lazy_decay && decays && state_mb >= lazy_min_mb && ((tab_mask >> (documents ? 1 : 0)) & 1) &&
+           static_cast<double>(rows) * table_split_ratio() >= static_cast<double>(max_entries);
+}
+
 void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entries) {
     t.rows = rows; t.dim = dim; t.max_entries = max_entries;
     t.P.alloc(rows * dim, true);
@@ -332,20 +344,15 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
     t.partial2_q.alloc(t.max_chunks2, true);
     t.arrive_row.alloc(rows, true); t.arrive2.alloc(t.max_chunks2, true);      // zero once: the last arriver resets its counter
     {
-        const bool lazy_enabled = tune_.lazy_decay;        // (per handle: tests build an eager twin)
         const bool sparse_adam = method == NVSM_ADAM && mode <= NVSM_ADAM_SPARSE;
-        const bool decays = sparse_adam || (method != NVSM_ADAM && cfg_.regularization_lambda > 0.f);
         // When lazy decay pays. The dense passes it saves must cost more than what it adds (a snapshot and a stamp launch per
         // update on the table's stream, a stamp load per gathered row): tables of hundreds of MB (configs[4]) always; with
         // sparse Adam — two dense arrays per table, P and m — from about a hundred MB of state, which is what makes the
         // per-rank share of the 8-GPU metric (6 400 windows against 50 k / 100 k rows) lazy for both tables: 0.335 -> 0.292 ms
         // per step (words alone 0.299, documents alone 0.322; interleaved A/B). Not the LSE shape (Adagrad, batch 4096, a
         // 100 MB words table): 0.182 -> 0.193 ms with a lazy words table. NVSM_LAZY_MIN_MB overrides (tests use small tables).
-        const double lazy_min_mb = tune_.lazy_min_mb >= 0.0 ? tune_.lazy_min_mb : (sparse_adam ? 96.0 : 384.0);
-        const double state_mb = static_cast<double>(rows) * dim * sizeof(float) * (method == NVSM_ADAM ? 2.0 : 1.0) / 1048576.0;
-        const int tab_mask = tune_.lazy_tables;          // experiments: bit 0 = words, bit 1 = documents
-        t.lazy = lazy_enabled && decays && state_mb >= lazy_min_mb && ((tab_mask >> (&t == &ents_ ? 1 : 0)) & 1) &&
-                 static_cast<double>(rows) * table_split_ratio() >= static_cast<double>(max_entries);
+        // (tune_.lazy_decay is per handle: tests build an eager twin)
+        t.lazy = table_decays_lazily(&t == &ents_, rows, dim, max_entries);
         t.lazy_scalar = sparse_adam || (method == NVSM_ADAGRAD && &t == &ents_);
         if (t.lazy) t.stamp.alloc(rows, true);
         for (float& d : t.decay_hist) d = 1.f;
@@ -407,7 +414,17 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
         own_stream_ = true;
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, lo));
-        const int aux2_prio = tune_.aux2_prio;   // (experiments) 0 lowest, 1 middle, 2 highest
+        // Side stream 2: the CSR builds, the projection update and — except for large batches of eagerly decayed tables — the dT
+        // product. Lowest priority, like side stream 1, except where the dT product of a large batch runs there next to the two
+        // table passes of lazily decayed tables: its workgroups (a whole CU each) then get the CUs that fall empty before the passes'
+        // next workgroups do, and the next step's projection product waits less (|V| = 500 k, |D| = 2 M, batch 51 200: 1.665 ->
+        // 1.638 ms; |V| = 50 k, |D| = 2 M 1.474 -> 1.465; every other shape within +-0.3 %: interleaved A/B, tools/ab_shapes.sh).
+        // NVSM_AUX2_PRIO (experiments build): 0 lowest, 1 middle, 2 highest.
+        // (The streams are created in THIS order, all four here: the runtime maps them onto its hardware queues in order of
+        //  creation, and with side stream 2 created last — behind the tables — every shape ran 1.2 to 3.5 times as long.)
+        const bool any_lazy = table_decays_lazily(false, cfg.num_words, cfg.word_repr_size, Bu * cfg.window_size) ||
+                              table_decays_lazily(true, cfg.num_entities, cfg.entity_repr_size, Bu * R_);
+        const int aux2_prio = tune_.aux2_prio >= 0 ? tune_.aux2_prio : ((any_lazy && cfg.max_batch_size >= 40960) ? 2 : 0);
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux2_stream_, hipStreamNonBlocking, aux2_prio == 0 ? lo : (aux2_prio == 2 ? hi : (lo + hi) / 2)));
         // Four streams, not five: the runtime multiplexes streams onto four hardware queues, and with a fifth stream the
         // host-batch copies shared a queue with compute and stopped overlapping it (1.22 -> 1.7 ms per step with host

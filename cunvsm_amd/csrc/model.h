@@ -269,6 +269,7 @@ class Model {
     int gemm_slabs_want_ = 128;        // split-K slabs of the exact-fp32 dT product (shapes / settings gemm_dt.hip does not cover)
     bool dt_ok_ = false;               // the split-K dT kernel (gemm_dt.hip) covers this model's shapes
     int num_cus_ = 256;
+    bool table_decays_lazily(bool documents, int64_t rows, int dim, int64_t max_entries) const;
     bool use_dt() const;               // this step's dT product runs on it (else: the exact-fp32 tiled / panel kernels)
 
     bool have_forward_ = false, have_grads_ = false;

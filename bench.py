@@ -505,6 +505,7 @@ def main():
 
     # ---- secondary legs: no events ----------------------------------------------------------------------------------
     extra = {}
+    main_transport, main_comm_ranks = main_leg.transport, main_leg.comm_ranks
     if not quick:
         if world == 1:
             # (a) loss read back after EVERY step, as iterate_data does (cpp/main.cu:427-444; SURVEY §8d "with the loss read
@@ -529,12 +530,19 @@ def main():
                 main_leg.run_steps(3, upool)
                 med, st = leg_value(main_leg, upool)
                 secondary["uniform_words"] = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), **st)
+            # The legs below run on engines of their own. The main engine is closed first: a second handle in a process whose
+            # first is still alive shares hardware queues with it (the runtime has few per priority level) and runs 2-25 %
+            # slower than the same handle alone in a process — which is how a user runs one.
+            main_transport, main_comm_ranks = main_leg.transport, main_leg.comm_ranks
+            main_leg.pool = None
+            main_leg.model.close()
             # (d) the reference recipe's optimiser (scripts/functions.sh:395: --update_method full_adam) on an engine of its own
             if args.config == "nvsm" and method != "full_adam":
                 leg = Leg(env, wl, "full_adam", B)
                 leg.run_steps(max(3, args.warmup))
                 med, st = leg_value(leg)
                 secondary["full_adam"] = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), **st)
+                leg.model.close()
                 del leg
             # (e') the other BASELINE configs that fit one GPU, on engines of their own: configs[4]'s tables at the metric's batch
             #      (|V| = 500 k, |D| = 2 M: E is 2 GB, i.e. the document gather comes out of HBM proper, not the Infinity Cache —
@@ -565,6 +573,7 @@ def main():
                                            "avg_launch_ms": round(avg2, 4), "algorithmic_bytes_per_launch": ab2, "traffic": None,
                                            "note": "in-step time of the kernel (events riding on its launch), from a pass of its own behind the timed regions"}
                     secondary[name] = ent
+                    leg.model.close()
                     del leg
             if secondary:
                 extra["secondary"] = secondary
@@ -577,6 +586,7 @@ def main():
                     leg.run_steps(max(10, args.warmup))
                     med, st = leg_value(leg, repeats=3)
                     shapes[str(Bg // n)] = dict(ms_per_step=round(med, 4), ranks=n, **st)
+                    leg.model.close()
                     del leg
                 extra["per_rank_shapes"] = shapes
         else:
@@ -593,6 +603,7 @@ def main():
                            scaling="weak" if headline_strong else "strong", global_batch=total, batch_per_rank=other_B,
                            steps=args.steps, **st)
                 extra["weak" if headline_strong else "strong"] = fig
+                leg.model.close()
                 del leg
             if args.exact_tables_leg and strong_ok:
                 # the strong split again with exact data-parallel tables: what the single-GPU trajectory costs
@@ -603,6 +614,7 @@ def main():
                 extra["exact_tables"] = dict(value=round(Bg * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), scaling="strong",
                                              global_batch=Bg, batch_per_rank=Bg // world, steps=args.steps,
                                              note="nvsm_config.dp_exact_tables: every rank applies the table updates of all ranks' windows", **st)
+                leg.model.close()
                 del leg
 
     if rank == 0:
@@ -717,7 +729,7 @@ def main():
                                       "uniform" if args.uniform_words else "Zipf(1)",
                                       "handed over as page-locked host buffers" if args.host_batches else "resident in HBM"),
                        "global_batch": global_batch, "batch_per_rank": B, "parallelism": "dp%d" % world, "update_method": method,
-                       "collectives": main_leg.transport, "comm_ranks": main_leg.comm_ranks,
+                       "collectives": main_transport, "comm_ranks": main_comm_ranks,
                        # per step and rank under data parallelism: [Σx | Σx²] (f64, forward, batch-norm only), [loss | Σdy | Σdy·x̂]
                        # (f64, backward), dT (f32, 307 KB) — DESIGN.md §6
                        "collectives_per_step": 0 if world == 1 else (3 if wl["batch_norm"] else 2),

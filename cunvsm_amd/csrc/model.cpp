@@ -414,17 +414,14 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
         own_stream_ = true;
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, lo));
-        // Side stream 2: the CSR builds, the projection update and — except for large batches of eagerly decayed tables — the dT
-        // product. Lowest priority, like side stream 1, except where the dT product of a large batch runs there next to the two
-        // table passes of lazily decayed tables: its workgroups (a whole CU each) then get the CUs that fall empty before the passes'
-        // next workgroups do, and the next step's projection product waits less (|V| = 500 k, |D| = 2 M, batch 51 200: 1.665 ->
-        // 1.638 ms; |V| = 50 k, |D| = 2 M 1.474 -> 1.465; every other shape within +-0.3 %: interleaved A/B, tools/ab_shapes.sh).
-        // NVSM_AUX2_PRIO (experiments build): 0 lowest, 1 middle, 2 highest.
-        // (The streams are created in THIS order, all four here: the runtime maps them onto its hardware queues in order of
-        //  creation, and with side stream 2 created last — behind the tables — every shape ran 1.2 to 3.5 times as long.)
-        const bool any_lazy = table_decays_lazily(false, cfg.num_words, cfg.word_repr_size, Bu * cfg.window_size) ||
-                              table_decays_lazily(true, cfg.num_entities, cfg.entity_repr_size, Bu * R_);
-        const int aux2_prio = tune_.aux2_prio >= 0 ? tune_.aux2_prio : ((any_lazy && cfg.max_batch_size >= 40960) ? 2 : 0);
+        // Side stream 2 (CSR builds, projection update, the dT product except for large batches of eagerly decayed tables): lowest
+        // priority, like side stream 1. (Highest priority where it carries the dT product of a large batch next to lazily decayed
+        // tables was worth 2 % there — |V| = 500 k, |D| = 2 M 1.703 -> 1.670 ms — as the only handle of its process, and cost 25 %
+        // — 1.64 -> 2.03 — as the second handle of a process whose first was still alive: the runtime has few hardware queues per
+        // priority level, and a handle's main stream and side stream 2 then shared one. Not done. NVSM_AUX2_PRIO, experiments build.)
+        // The four streams are created HERE, in THIS order: with side stream 2 created later (behind the tables) every shape ran
+        // 1.2 to 3.5 times as long — streams are mapped onto hardware queues in order of creation.
+        const int aux2_prio = tune_.aux2_prio;   // 0 lowest, 1 middle, 2 highest
         NVSM_HIP_CHECK(hipStreamCreateWithPriority(&aux2_stream_, hipStreamNonBlocking, aux2_prio == 0 ? lo : (aux2_prio == 2 ? hi : (lo + hi) / 2)));
         // Four streams, not five: the runtime multiplexes streams onto four hardware queues, and with a fifth stream the
         // host-batch copies shared a queue with compute and stopped overlapping it (1.22 -> 1.7 ms per step with host

@@ -51,7 +51,7 @@ struct Tuning {
     int docs_on_main = 0;               // NVSM_DOCS_ON_MAIN
     bool chunk_order = true;            // NVSM_CHUNK_ORDER
     int lazy_tables = 3;                // NVSM_LAZY_TABLES
-    int aux2_prio = -1, aux3_prio = 1;  // NVSM_AUX2_PRIO (-1: by rule) / NVSM_AUX3_PRIO
+    int aux2_prio = 0, aux3_prio = 1;   // NVSM_AUX2_PRIO / NVSM_AUX3_PRIO
     int event_fence = -1;               // NVSM_EVENT_FENCE
     int dt_slabs = 0;                   // NVSM_DT_SLABS (0: by batch size)
     int docs_delay_us = 0;              // NVSM_DOCS_DELAY_US (a spin kernel in front of the documents update on its side stream)

@@ -111,11 +111,14 @@ __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, co
 // Workgroups per CSR kernel (they grid-stride). For a table much larger than the batch the bounds / chunk kernels are
 // scattered 4-byte accesses into row-indexed arrays of many MB; spread over every CU they sit next to the loss kernel and
 // slow its row gathers (378 vs 217 us at |D| = 2 M) — a few waves per CU on half the CUs do the same work in the time they
-// have (configs[4]: 1.99 -> 1.93 ms per step; no effect at the NVSM shape, where the arrays live in L2).
-// NVSM_CSR_GRID_CAP overrides (experiments).
+// have (configs[4]: 1.99 -> 1.93 ms per step; no effect at the NVSM shape, where the arrays live in L2). Round 4: 64 instead of
+// 128 — these workgroups live as long as their kernel (150 us next to the loss kernel at |D| = 2 M), and every CU one of them
+// sits on is closed to the backward projection product behind the loss kernel, whose workgroups need a CU's whole register file
+// (173 us there for 65 alone): |V| = 500 k, |D| = 2 M 1.717 -> 1.668 ms (96: 1.675, 48: 1.647, 32: 1.61-1.65, 16: 1.79, 8: 2.19,
+// uncapped: 1.71), batch 6 400 0.298 -> 0.292, LSE 0.168 -> 0.164. NVSM_CSR_GRID_CAP overrides for every table (experiments).
 static int csr_grid(int64_t items, bool sparse_table) {
     const int cap_env = tuning().csr_grid_cap;
-    const int cap = cap_env >= 0 ? cap_env : (sparse_table ? 128 : 0);
+    const int cap = cap_env >= 0 ? cap_env : (sparse_table ? 64 : 0);
     const int g = stream_grid(items, 256);
     return (cap > 0 && g > cap) ? cap : g;
 }

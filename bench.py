@@ -356,6 +356,47 @@ class Env:
             self.dist.barrier()
 
 
+def secondary_leg(env, args, wl, method):
+    """One configuration on an engine of its own: ms per step with no events in the timed regions, then the loss kernel's
+    in-step time from a pass of its own with events riding on its launch."""
+    B = wl["batch"]
+    leg = Leg(env, wl, method, B, uniform_words=args.uniform_words)
+    leg.run_steps(max(5, args.warmup))
+    med, st = ms_stats(leg.timed_repeats(args.steps, min(args.repeats, 3)), args.steps)
+    ent = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), batch=B, update_method=method,
+               workload="|V|=%d |D|=%d d_word=%d d_doc=%d" % (wl["num_words"], wl["num_entities"], wl["word_dim"], wl["entity_dim"]), **st)
+    kernel = "loss_fused"
+    leg.model.profile_enable(True)
+    leg.model.profile_select(kernel)
+    leg.model.profile_reset()
+    leg.run_steps(min(args.steps, 50))
+    env.sync_all(leg.model)
+    pr = leg.model.profile()
+    leg.model.profile_enable(False)
+    if pr.get(kernel, (0, 0))[1] > 0:
+        avg = pr[kernel][0] / pr[kernel][1]
+        ab = algorithmic_bytes(kernel, wl, method, B)
+        ent["roofline"] = {"kernel": kernel, "bound": "hbm", "achieved": round(ab / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(ab / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg, 4),
+                           "algorithmic_bytes_per_launch": ab, "traffic": None,
+                           "note": "in-step time of the kernel (events riding on its launch), from a pass of its own behind the timed regions"}
+    leg.model.close()
+    return ent
+
+
+def run_secondary_leg(args, flags):
+    """A secondary leg in a fresh process, as a user would run that configuration: a second engine in a process whose first has
+    lived (streams created and destroyed) is mapped onto the runtime's hardware queues differently and runs 2-10 % slower."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--secondary-leg", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--repeats", str(min(args.repeats, 3))] + flags
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise SystemExit("secondary leg %s failed: %s" % (flags, r.stderr[-2000:]))
+    return json.loads(lines[-1])
+
+
 def ms_stats(times, steps):
     ms = sorted(t * 1e3 / steps for t in times)
     med = statistics.median(ms)
@@ -386,6 +427,9 @@ def main():
     ap.add_argument("--launch-check", action="store_true", help="rendezvous only (gloo, no GPU): proves that the N-rank launch works")
     ap.add_argument("--uniform-words", action="store_true", help="uniform instead of Zipf(1) word ids (worst case for caches)")
     ap.add_argument("--host-batches", action="store_true", help="hand host buffers over each step in the MAIN timed region too")
+    ap.add_argument("--secondary-leg", action="store_true", help="child mode of the secondary legs: this configuration on an engine of "
+                    "its own in a process of its own — timed with no events, then the loss kernel's roofline from a pass with events; "
+                    "one compact JSON line")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the read-back / host-batch / per-rank-shape / secondary legs")
     ap.add_argument("--cpu-steps", type=int, default=30, help="full-size steps of the CPU oracle timed for cpu_baseline (≈0.3 s each on the "
                     "16 CPUs the GPU box grants the process)")
@@ -440,6 +484,11 @@ def main():
 
     wl = workload(args)
     method = args.update_method
+    if args.secondary_leg:
+        if world != 1:
+            raise SystemExit("--secondary-leg is a single-GPU child mode")
+        print(json.dumps(secondary_leg(env, args, wl, method)), flush=True)
+        return
     Bg = wl["batch"]                          # the metric's batch: per GPU at N = 1 / weak, global for the strong split
     w = wl["window"]
     quick = args.no_extra_legs or args.sequential or bool(args.gate_us)
@@ -530,51 +579,22 @@ def main():
                 main_leg.run_steps(3, upool)
                 med, st = leg_value(main_leg, upool)
                 secondary["uniform_words"] = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), **st)
-            # The legs below run on engines of their own. The main engine is closed first: a second handle in a process whose
-            # first is still alive shares hardware queues with it (the runtime has few per priority level) and runs 2-25 %
-            # slower than the same handle alone in a process — which is how a user runs one.
-            main_transport, main_comm_ranks = main_leg.transport, main_leg.comm_ranks
+            # The legs below run on engines of their own, each in a process of its own (run_secondary_leg), as a user would run that
+            # configuration. The main engine is closed first so that the GPU is theirs.
             main_leg.pool = None
             main_leg.model.close()
-            # (d) the reference recipe's optimiser (scripts/functions.sh:395: --update_method full_adam) on an engine of its own
+            torch.cuda.empty_cache()
+            base = (["--uniform-words"] if args.uniform_words else [])
+            # (d) the reference recipe's optimiser (scripts/functions.sh:395: --update_method full_adam)
             if args.config == "nvsm" and method != "full_adam":
-                leg = Leg(env, wl, "full_adam", B)
-                leg.run_steps(max(3, args.warmup))
-                med, st = leg_value(leg)
-                secondary["full_adam"] = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), **st)
-                leg.model.close()
-                del leg
-            # (e') the other BASELINE configs that fit one GPU, on engines of their own: configs[4]'s tables at the metric's batch
-            #      (|V| = 500 k, |D| = 2 M: E is 2 GB, i.e. the document gather comes out of HBM proper, not the Infinity Cache —
-            #      its loss-kernel roofline is reported here) and configs[3] (LSE, batch 4 096, Adagrad)
+                ent = run_secondary_leg(args, base + ["--config", "nvsm", "--batch", str(B), "--update-method", "full_adam"])
+                secondary["full_adam"] = {k: ent[k] for k in ("value", "unit", "ms_per_step", "repeats", "ms_per_step_all", "spread")}
+            # (e') the other BASELINE configs that fit one GPU: configs[4]'s tables at the metric's batch (|V| = 500 k, |D| = 2 M: E is
+            #      2 GB, i.e. the document gather comes out of HBM proper, not the Infinity Cache — its loss-kernel roofline is
+            #      reported here) and configs[3] (LSE, batch 4 096, Adagrad)
             if args.config == "nvsm" and Bg == 51200 and method == "sparse_adam":
                 for name in ("large_tables", "lse_small"):
-                    wl2 = dict(num_words=50000, num_entities=100000, word_dim=300, entity_dim=256, window=10, num_random=16, batch=51200,
-                               nonlinearity="hard_tanh", batch_norm=1, bias_negative_samples=0, lr=1e-3, update_method="sparse_adam")
-                    wl2.update(PRESETS[name])
-                    m2, B2 = wl2.pop("update_method"), wl2["batch"]
-                    leg = Leg(env, wl2, m2, B2)
-                    leg.run_steps(max(5, args.warmup))
-                    med, st = leg_value(leg, repeats=3)        # (no events: they cost the LSE step 12 %)
-                    leg.model.profile_enable(True)
-                    leg.model.profile_select(ROOFLINE_KERNEL)
-                    leg.model.profile_reset()
-                    leg.run_steps(min(args.steps, 50))
-                    env.sync_all(leg.model)
-                    pr = leg.model.profile()
-                    leg.model.profile_enable(False)
-                    ent = dict(value=round(B2 * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), batch=B2, update_method=m2,
-                               workload="|V|=%d |D|=%d d_word=%d d_doc=%d" % (wl2["num_words"], wl2["num_entities"], wl2["word_dim"], wl2["entity_dim"]), **st)
-                    if pr.get(ROOFLINE_KERNEL, (0, 0))[1] > 0:
-                        avg2 = pr[ROOFLINE_KERNEL][0] / pr[ROOFLINE_KERNEL][1]
-                        ab2 = algorithmic_bytes(ROOFLINE_KERNEL, wl2, m2, B2)
-                        ent["roofline"] = {"kernel": ROOFLINE_KERNEL, "bound": "hbm", "achieved": round(ab2 / (avg2 * 1e-3) / 1e9, 1),
-                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab2 / (avg2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                           "avg_launch_ms": round(avg2, 4), "algorithmic_bytes_per_launch": ab2, "traffic": None,
-                                           "note": "in-step time of the kernel (events riding on its launch), from a pass of its own behind the timed regions"}
-                    secondary[name] = ent
-                    leg.model.close()
-                    del leg
+                    secondary[name] = run_secondary_leg(args, ["--config", name])
             if secondary:
                 extra["secondary"] = secondary
             # (e) the per-rank share of the N-GPU metric (51 200 / N windows per rank) on this one GPU, each
@@ -582,12 +602,9 @@ def main():
             if args.config == "nvsm" and Bg == 51200:
                 shapes = {}
                 for n in (8, 4, 2):
-                    leg = Leg(env, wl, method, Bg // n)
-                    leg.run_steps(max(10, args.warmup))
-                    med, st = leg_value(leg, repeats=3)
-                    shapes[str(Bg // n)] = dict(ms_per_step=round(med, 4), ranks=n, **st)
-                    leg.model.close()
-                    del leg
+                    ent = run_secondary_leg(args, base + ["--config", "nvsm", "--batch", str(Bg // n), "--update-method", method])
+                    shapes[str(Bg // n)] = dict(ms_per_step=ent["ms_per_step"], ranks=n,
+                                                **{k: ent[k] for k in ("repeats", "ms_per_step_all", "spread")})
                 extra["per_rank_shapes"] = shapes
         else:
             # the other scaling figure of the same run: weak (51 200 windows per rank) beside a strong headline, or the

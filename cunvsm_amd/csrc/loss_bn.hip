@@ -543,13 +543,16 @@ static void launch_loss_rows(const LossArgs& a_in, hipStream_t s) {
     if (a.B >= 40960) epw = 20;
     // (batch 4096: two examples per wave, 512 workgroups — half as many fp64 atomics per column: 44 -> 33 us)
     if (epw < 2 && a.B >= 2048) epw = 2;
-    // Two row sets per wave (PIPE; two workgroups per CU — one round of 512 from 40 k examples) where the documents table does
-    // not fit the 256 MB Infinity Cache and every row comes out of HBM at 1 800 cycles: |D| = 2 M, batch 51 200: 295 -> 244 us
-    // in the step (0.44 -> 0.54 of peak), step 1.725 -> 1.697 ms. Where the table is cache-resident (|D| = 100 k) the kernel
-    // gains 6 us (179 -> 173) and the STEP loses 8 (0.894 -> 0.902: the CSR builds next to it finish later): single set.
-    // Interleaved A/B, tools/ab_roof.sh; NVSM_LOSS_PIPE=0/1 (experiments build) overrides.
+    // Two row sets per wave (PIPE; two workgroups fit a CU) where the documents table does not fit the 256 MB Infinity Cache and
+    // every row comes out of HBM at 1 800 cycles: |D| = 2 M, batch 51 200: 295 -> 244 us in the step (0.44 -> 0.54 of peak) with
+    // one round of 512 workgroups. But two such workgroups leave a CU no registers for anything else, and what runs next to this
+    // kernel is the documents CSR build, which the documents update — the longest kernel of that step — waits for: with ~380
+    // workgroups (one and a half per CU; 34 examples per wave at batch 51 200) the kernel takes 270 us and the STEP 1.611 -> 1.548
+    // ms (30 examples per wave: 1.567, 32: 1.572, 36: 1.557, 38: 1.567, 40: 1.60, 50: 1.63). Where the table is cache-resident
+    // (|D| = 100 k) the two-set kernel gains 6 us (179 -> 173) and the STEP loses 8 (0.894 -> 0.902) for the same reason: single
+    // set. Interleaved A/B, tools/ab_roof.sh; NVSM_LOSS_PIPE=0/1, NVSM_LOSS_EPW (experiments build) override.
     const bool pipe = a.R <= RB && loss_two_row_sets(a.E_rows, a.de);
-    if (pipe && a.B >= 40960) epw = static_cast<int>((a.B + 4 * 512 - 1) / (4 * 512));
+    if (pipe && a.B >= 40960) epw = static_cast<int>((a.B + 4 * 380 - 1) / (4 * 380));
     const int epw_env = tuning().loss_epw;      // experiments
     if (epw_env > 0) epw = epw_env;
     const int grid = ceil_div(a.B, 4 * epw);

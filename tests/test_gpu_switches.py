@@ -100,7 +100,10 @@ LARGE_EXP_VARIANTS = [
     {"NVSM_WORDS_CSR_LATE": "1"},
     {"NVSM_AUX2_PRIO": "2", "NVSM_SPLIT_NT": "1"},
     {"NVSM_SPLIT_FUSE": "0"},
-    {"NVSM_LOSS_PIPE": "1"},
+    # the loss kernel with two sets of rows in flight per wave, at the single-set form's examples per wave (20 from batch 40 960 on:
+    # left to its own rule the two-set form takes ~380 workgroups, and a wave that sums more examples rounds its fp32 partial sums
+    # differently — the last bits of the loss, not the kernel's arithmetic)
+    {"NVSM_LOSS_PIPE": "1", "NVSM_LOSS_EPW": "20"},
     {"NVSM_LOSS_PIPE": "0"},
 ]      # (not NVSM_DT_ON_MAIN: the dT product is cut into 48 slabs on the main stream and 16 on side stream 2 — another summation order)
 

@@ -266,7 +266,7 @@ class Leg:
             return
         for s in range(n):
             want = read_every > 0 and (s + 1) % read_every == 0
-            if args.gate_us:
+            if args.gate_us and s % max(1, args.gate_every) == 0:
                 model.debug_delay(args.gate_us)
             if args.sequential:
                 model.compute_cost(batches[s % len(batches)])
@@ -440,6 +440,8 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="events around every kernel group inside the timed region (≈5 %% slower)")
     ap.add_argument("--gate-us", type=int, default=0, help="profiling aid: a spin kernel of this many microseconds in front of every "
                     "step, so that the host has queued the step before the GPU starts it (the timeline then shows the GPU-side schedule)")
+    ap.add_argument("--gate-every", type=int, default=1, help="with --gate-us: the spin kernel in front of every n-th step only, so that "
+                    "the steps behind it run back to back as in steady state")
     ap.add_argument("--read-cost-every", type=int, default=0, help="read the loss back every n steps (0 = never inside the timed region)")
     args = ap.parse_args()
 

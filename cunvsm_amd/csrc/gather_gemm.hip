@@ -693,10 +693,14 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 __global__ void step_prologue_kernel(const int64_t* __restrict__ words64, int* __restrict__ widx, int64_t nW,
                                      const int64_t* __restrict__ labels, int64_t N, int R, uint64_t num_words,
                                      uint64_t num_entities, uint64_t seed, uint64_t step, int* __restrict__ ids,
-                                     double* __restrict__ stats, int nstats, int* __restrict__ err_flag) {
+                                     double* __restrict__ stats, int nstats, int* __restrict__ err_flag, StampJob sj) {
     const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     if (tid < nstats) stats[tid] = 0.0;
+    if (sj.list) {      // the previous words update's stamps (model.cpp lazy_end_update)
+        const int64_t limit = *sj.count;
+        for (int64_t i = tid; i < limit; i += stride) sj.stamp[sj.list[i]] = sj.value;
+    }
     for (int64_t i = tid; i < nW; i += stride) {
         int64_t v = words64[i];
         if (static_cast<uint64_t>(v) >= num_words) { *err_flag = NVSM_BAD_WORD_ID; v = 0; }      // see narrow_i64_kernel
@@ -717,14 +721,14 @@ __global__ void step_prologue_kernel(const int64_t* __restrict__ words64, int* _
 }
 void launch_step_prologue(const int64_t* words64, int* widx, int64_t nW, const int64_t* labels, int64_t B, int R,
                           int64_t num_words, int64_t num_entities, uint64_t seed, uint64_t step, int* ids, double* stats,
-                          int nstats, int* err_flag, hipStream_t s) {
+                          int nstats, int* err_flag, hipStream_t s, StampJob stamps) {
     const int64_t N = B * R;
     int grid = stream_grid(N > nW ? N : nW, 256);
     const int need = (nstats + 255) / 256;
     if (grid < need) grid = need;
     NVSM_LAUNCH(step_prologue_kernel, dim3(grid), dim3(256), 0, s, words64, widx, nW, labels, N, R,
                        static_cast<uint64_t>(num_words), static_cast<uint64_t>(num_entities), seed, step, ids, stats, nstats,
-                       err_flag);
+                       err_flag, stamps);
 }
 
 }  // namespace cunvsm

@@ -139,9 +139,11 @@ void launch_colsum_finalize(const double* sums, int dim, float* out, hipStream_t
 enum { NVSM_BAD_WORD_ID = 1, NVSM_BAD_ENTITY_ID = 2, NVSM_SORT_TIMEOUT = 3, NVSM_NONFINITE_BASE = 16 };
 // ids outside [0, limit) become row 0 and raise `code` in *err_flag (err_flag may be null: tests of single kernels)
 void launch_narrow_i64(const int64_t* src, int* dst, int64_t n, int64_t limit, int* err_flag, int code, hipStream_t s);
+// stamp[list[i]] = value for i < *count (launch_stamp_rows' job, riding on the prologue: list == null: none)
+struct StampJob { const int* list; const int* count; int* stamp; int value; };
 void launch_step_prologue(const int64_t* words64, int* widx, int64_t nW, const int64_t* labels, int64_t B, int R,
                           int64_t num_words, int64_t num_entities, uint64_t seed, uint64_t step, int* ids, double* stats,
-                          int nstats, int* err_flag, hipStream_t s);
+                          int nstats, int* err_flag, hipStream_t s, StampJob stamps = StampJob{nullptr, nullptr, nullptr, 0});
 void launch_check_finite(const float* x, int64_t n, int* err_flag, int code, hipStream_t s);   // NVSM_DEBUG (CHECK_MATRIX)
 void launch_scale(float* x, int64_t n, float a, hipStream_t s);      // x *= a (replica averaging)
 // Host batch → HBM by a kernel that READS page-locked host memory over PCIe (up to four arrays in one launch) instead of

@@ -566,10 +566,17 @@ void Model::raise_device_error() {
     *err_host_ = 0;
     // The arrival counters of the ordered sums and of the one-launch table passes return to zero at the end of every launch
     // that runs to completion; a launch that flagged an error may have left some behind, and every later sum would silently
-    // add the wrong partials: clear them before the caller goes on (all streams are quiet when an error is raised).
+    // add the wrong partials: clear them before the caller goes on. The callers have waited for much less than the whole
+    // step (step(cost): the copy of the loss word; get_cost(): the main stream; deferred_cost(): one event) — the table passes
+    // and ordered sums of the same step may still be running on the side streams, and a counter zeroed under a running
+    // kernel loses its last arriver: every stream of the handle is quiet BEFORE the counters are touched.
+    for (hipStream_t s : {stream_, aux_stream_, aux2_stream_, aux3_stream_})
+        if (s) (void)hipStreamSynchronize(s);
+    E_pending_ = T_pending_ = false;
+    words_tail_pending_ = false;
     for (DevBuf<int>* b : {&sums_fwd_.arrive, &sums_bwd_.arrive, &words_.arrive_row, &words_.arrive2, &ents_.arrive_row, &ents_.arrive2})
         if (b->p) (void)hipMemset(b->p, 0, b->n * sizeof(int));
-    (void)hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();      // (the fills are queued on the null stream, which the handle's streams do not follow)
     if (code == NVSM_BAD_WORD_ID) throw Error(NVSM_ERR_INVALID_ARGUMENT, "a word id of the batch is outside [0, num_words)");
     if (code == NVSM_BAD_ENTITY_ID) throw Error(NVSM_ERR_INVALID_ARGUMENT, "a document id of the batch is outside [0, num_entities)");
     if (code == NVSM_SORT_TIMEOUT) throw Error(NVSM_ERR_DEVICE, "the row sort's grid-wide wait timed out (workgroups not co-resident?)");
@@ -894,8 +901,10 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     ids_p_ = (ids_p_ == ids_buf_[0].p) ? ids_buf_[1].p : ids_buf_[0].p;
     // device-sampler mode: zeroing the statistics, narrowing the word ids and drawing the document ids are one launch
     const bool fused_prologue = !entity_ids && cfg_.sampler != NVSM_SAMPLER_HOST_MINSTD;
-    if (!fused_prologue)
+    if (!fused_prologue) {
+        settle_words_stamp();      // (the fused prologue sets the previous words update's stamps itself)
         NVSM_HIP_CHECK(hipMemsetAsync(stats_.p, 0, stats_.n * sizeof(double), stream_));   // Σx Σx² | loss Σdy Σdy·x̂
+    }
 
     // F1: batch → HBM (objective.cu:36-61)
     const int64_t* words_dev;
@@ -986,10 +995,16 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             launch_narrow_i64(in_ids64_.p, ids_p_, N, cfg_.num_entities, err_host_, NVSM_BAD_ENTITY_ID, stream_);
         } else {
             // (the prologue carries "inputs consumed, ids final" as its completion event: no packet between it and the gather)
+            StampJob sj{};
+            if (words_stamp_pending_) {
+                words_stamp_pending_ = false;
+                const Csr cw = csr_of(words_, words_stamp_n_);
+                sj.list = cw.touched; sj.count = cw.num_touched; sj.stamp = words_.stamp.p; sj.value = words_.updates_done;
+            }
             launch_and_record(ev_inputs_, stream_, [&] {
                 launch_step_prologue(words_dev, widx_.p, B * w, labels_dev_, B, R_, cfg_.num_words, cfg_.num_entities,
                                      device_seed_ + 0x9E37u * cfg_.rank, step_count_, ids_p_, stats_.p, static_cast<int>(stats_.n),
-                                     err_host_, stream_);
+                                     err_host_, stream_, sj);
             });
         }
     }
@@ -1038,7 +1053,14 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         if (which & 1) csr_joined_ents_ = false;
         if (which & 2) { csr_joined_words_ = false; words_csr_stream_ = sw; }
         auto ents = [&] { { PROF_ON("csr_entities", se); build_csr(ents_, csr_ids, Bu * R_, se); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_ents_, se)); };
-        auto wrds = [&] { { PROF_ON("csr_words", sw); build_csr(words_, csr_widx, Bu * w, sw); } NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw)); };
+        // (lazily decayed words table with a per-row scalar: the scalars of the rows this batch touches are brought up to date
+        //  into the snapshot the moments pass reads right here, behind the build that lists those rows — it needs nothing the
+        //  step computes, and in front of the words update it was a launch of 7 us on the critical stream)
+        auto wrds = [&] {
+            { PROF_ON("csr_words", sw); build_csr(words_, csr_widx, Bu * w, sw); }
+            if (words_.lazy && words_.lazy_scalar && tune_.early_snapshot) { lazy_scalar_snapshot(words_, csr_of(words_, Bu * w), sw); words_snapshot_early_ = true; }
+            NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw));
+        };
         if (layout == 1) { if (which & 2) wrds(); if (which & 1) ents(); } else { if (which & 1) ents(); if (which & 2) wrds(); }
         if ((which & 1) && se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
     };
@@ -1470,6 +1492,7 @@ void Model::lazy_scalar_snapshot(TableState& t, const Csr& c, hipStream_t s) {
 
 void Model::lazy_flush_all() {
     if (!words_.lazy && !ents_.lazy) return;
+    settle_words_stamp();
     synchronize();
     lazy_refresh(words_, nullptr, stream_);
     lazy_refresh(ents_, nullptr, stream_);
@@ -1486,10 +1509,26 @@ void Model::lazy_begin_update(TableState& t, RowPassArgs& a, bool scalar_pingpon
     a.pending = lazy_view(t);                                        // what the rows this pass visits sat out
     t.decay_hist[t.updates_done % kLazyHistory] = a.decay;           // factor of update number updates_done + 1 on P
 }
+// The words update ends the step's critical stream, and its stamps are first looked at by the next step's word gather: they are
+// set by that step's prologue kernel (one launch less at the end of the chain; the touched-row list lives until the next CSR
+// build, which follows the prologue), or by settle_words_stamp() when something else comes first.
+void Model::settle_words_stamp() {
+    if (!words_stamp_pending_) return;
+    words_stamp_pending_ = false;
+    TableState& t = words_;
+    Csr c = csr_of(t, words_stamp_n_);
+    PROF("lazy_stamp_words");
+    launch_stamp_rows(c, t.stamp.p, t.updates_done, std::min<int64_t>(c.n, t.rows), stream_);
+}
+
 void Model::lazy_end_update(TableState& t, const Csr& c, hipStream_t s) {
     if (!t.lazy) return;
     t.updates_done += 1;
-    {   // the touched rows carry this update
+    if (&t == &words_ && s == stream_ && tune_.stamp_in_prologue && t.updates_done % kLazyHistory != 0) {
+        words_stamp_pending_ = true;
+        words_stamp_n_ = c.n;
+        prof.note("lazy_stamp_words");
+    } else {   // the touched rows carry this update
         PROF_ON(&t == &words_ ? "lazy_stamp_words" : "lazy_stamp_entities", s);
         launch_stamp_rows(c, t.stamp.p, t.updates_done, std::min<int64_t>(c.n, t.rows), s);
     }
@@ -1612,7 +1651,8 @@ void Model::update_words(float lr, float sl) {
     a.kind = ROW_ADAM_MV;
     a.nt_m = (nt_mask() >> 2) & 1;
     lazy_begin_update(t, a, true);
-    lazy_scalar_snapshot(t, c, stream_);
+    if (!words_snapshot_early_) lazy_scalar_snapshot(t, c, stream_);      // (else: done behind the CSR build, compute_cost)
+    words_snapshot_early_ = false;
     int path;
     { PROF("row_pass_words_mv"); path = launch_table_pass(c, a, stream_, words_untouched_stream_); }
     if (path == TABLE_PASS_ENTRY_WALK) prof.note("entry_walk_words");

@@ -183,6 +183,10 @@ class Model {
     void lazy_scalar_snapshot(TableState& t, const Csr& c, hipStream_t s);   // the touched rows' scalar state, before an update's passes
     void lazy_begin_update(TableState& t, RowPassArgs& a, bool scalar_pingpong);
     void lazy_end_update(TableState& t, const Csr& c, hipStream_t s);
+    void settle_words_stamp();            // the words table's pending stamps, now (see lazy_end_update)
+    bool words_stamp_pending_ = false;    // the last words update's stamps have not been set yet
+    int64_t words_stamp_n_ = 0;           //   ... entries of that update's CSR
+    bool words_snapshot_early_ = false;   // this step's words scalar snapshot was taken behind the CSR build
     void raise_device_error();             // throws when a kernel has flagged bad ids / non-finite values since the last check
     void debug_check(const float* x, int64_t n, int which);
     void alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entries);

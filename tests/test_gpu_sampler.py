@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import cunvsm_amd as ca
-from tests.helpers import gpu_model, random_batch
+from tests.helpers import PARAMS, gpu_model, random_batch, random_params
 
 pytestmark = pytest.mark.gpu
 
@@ -166,6 +166,47 @@ def test_out_of_range_explicit_entity_ids_and_fused_step():
         m.compute_cost(ca.Batch(words[:-1], labels, ww[:-1], iw))          # wrong element count: caught by the binding
     with pytest.raises(ValueError):
         m.compute_cost(ca.Batch(words, labels, ww, iw), entity_ids=ids[:-1])
+
+
+@pytest.mark.parametrize("method", ["sparse_adam", "adagrad"])
+def test_good_steps_after_a_bad_id_in_a_fused_step_equal_a_fresh_handle(method):
+    """A bad id reported by nvsm_step(cost) — whose host wait covers the loss word only, while the table passes and ordered
+    sums of the same step still run on the side streams — must leave the handle as good as new: the hand-over counters of the
+    ordered sums and of the one-launch table passes are cleared only once every stream is quiet (a counter zeroed under a
+    running kernel loses its last arriver, and every later sum silently adds the wrong partials). Hot rows (Zipf word ids:
+    both levels of the chunk tree) and a batch-norm model, so that every counter family is in use."""
+    spec = dict(num_words=300, num_entities=200, word_dim=64, entity_dim=32, window=8, num_random=4, batch_norm=True,
+                nonlinearity="hard_tanh", update_method=method)
+    spec["lambda"] = 0.01
+    B = 8192
+    rs = np.random.RandomState(5)
+    params = random_params(spec, rs)
+    batches = [random_batch(spec, rs, B, zipf=True) for _ in range(4)]
+    a, b = gpu_model(spec, B, sampler=ca.SAMPLER_DEVICE), gpu_model(spec, B, sampler=ca.SAMPLER_DEVICE)
+    for m in (a, b):
+        m.initialize(3)
+    words, ww, labels, iw, ids = batches[0]
+    for bad_what in ("word", "id"):
+        w2, i2 = words.copy(), ids.copy()
+        if bad_what == "word":
+            w2[1234] = spec["num_words"] + 7
+        else:
+            i2[4321] = -3
+        with pytest.raises(ca.NvsmError) as e:
+            a.step(ca.Batch(w2, labels, ww, iw), 1e-3, entity_ids=i2, want_cost=True)
+        assert e.value.status == 1
+    # the broken steps did update `a` (bad ids are clamped to row 0): both handles start over from the same parameters and
+    # optimiser state cannot be reset through the ABI, so the comparison handle replays the same (clamped) steps without error
+    w2 = words.copy(); w2[1234] = 0
+    i2 = ids.copy(); i2[4321] = 0
+    b.step(ca.Batch(w2, labels, ww, iw), 1e-3, entity_ids=ids, want_cost=True)
+    b.step(ca.Batch(words, labels, ww, iw), 1e-3, entity_ids=i2, want_cost=True)
+    for (w, wwt, l, iwt, i) in batches[1:] * 3:
+        ca_ = a.step(ca.Batch(w, l, wwt, iwt), 1e-3, entity_ids=i, want_cost=True)
+        cb_ = b.step(ca.Batch(w, l, wwt, iwt), 1e-3, entity_ids=i, want_cost=True)
+        assert ca_ == cb_
+    for n in PARAMS:
+        np.testing.assert_array_equal(a.get_param(n), b.get_param(n))
 
 
 def test_debug_mode_reports_non_finite_values(monkeypatch):

@@ -235,9 +235,10 @@ int nvsm_debug_gemm(int variant, int M, int N, int K, const float* hostA, const 
             cunvsm::launch_gemm(al, bl, A.p, B.p, P.p, M, N, K, lda, ldb, N, 1.f, nullptr, split, static_cast<size_t>(M) * N, nullptr);
             cunvsm::launch_splitk_reduce(P.p, slabs, static_cast<size_t>(M) * N, C.p, static_cast<int64_t>(M) * N, nullptr);
         } else {
-            cunvsm::DevBuf<char> planes;
+            cunvsm::DevBuf<char> planes, rplanes;
             planes.alloc(cunvsm::gemm_split_planes_bytes(N, K));
-            cunvsm::GemmSplitWs sws{planes.p, planes.n, false};
+            rplanes.alloc(cunvsm::gemm_rsplit_planes_bytes(N, K));
+            cunvsm::GemmSplitWs sws{planes.p, planes.n, false, rplanes.p, rplanes.n, false};
             cunvsm::launch_gemm(al, bl, A.p, B.p, C.p, M, N, K, lda, ldb, N, 1.f, nullptr, 1, 0, nullptr, nullptr, nullptr, 0.f, nullptr, false,
                                 nullptr, &sws);
             NVSM_HIP_CHECK(hipDeviceSynchronize());
@@ -281,11 +282,13 @@ int nvsm_debug_gemm_time(int b_layout, int M, int N, int K, int extras, int repe
         NVSM_HIP_CHECK(hipEventCreate(&e0)); NVSM_HIP_CHECK(hipEventCreate(&e1));
         const int ldb = b_layout ? K : N;
         int parts = 0;
-        cunvsm::DevBuf<char> planes;
+        cunvsm::DevBuf<char> planes, rplanes;
         planes.alloc(cunvsm::gemm_split_planes_bytes(N, K));
-        cunvsm::GemmSplitWs sws{planes.p, planes.n, false};
+        rplanes.alloc(cunvsm::gemm_rsplit_planes_bytes(N, K));
+        cunvsm::GemmSplitWs sws{planes.p, planes.n, false, rplanes.p, rplanes.n, false};
         auto go = [&] {
             sws.ready = (extras & 4) != 0 && sws.ready;          // extras bit 2: the planes of B stay valid between launches
+            sws.rready = (extras & 4) != 0 && sws.rready;
             cunvsm::launch_gemm(0, b_layout, A.p, B.p, C.p, M, N, K, K, ldb, N, 1.f, nullptr, 1, 0, s, (extras & 1) ? stats.p : nullptr,
                                 (extras & 2) ? rowsq.p : nullptr, 1.f, &parts, false, (extras & 1) ? &ws : nullptr, &sws);
         };

@@ -462,6 +462,11 @@ void launch_gemm(int a_layout, int b_layout, const float* A, const float* B, flo
     if (rowsq_parts) *rowsq_parts = rowsq ? tiled_rowsq_parts(N) : 0;
     // per-rank batch sizes: a workgroup per 32 rows and all columns (gemm_rows.hip); its row sums of squares are complete: one part
     if (split_k <= 1 && a_layout == 0 && M >= 512 && M <= gemm_rows_max_m() &&
+        launch_gemm_rsplit(b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, s, colstats, sums, rowsq, rowsq_scale, split_ws, nullptr)) {
+        if (rowsq_parts) *rowsq_parts = rowsq ? 1 : 0;
+        return;
+    }
+    if (split_k <= 1 && a_layout == 0 && M >= 512 && M <= gemm_rows_max_m() &&
         launch_gemm_rows(b_layout, A, B, C, M, N, K, lda, ldb, ldc, alpha, bias_n, s, colstats, sums, rowsq, rowsq_scale, nullptr)) {
         if (rowsq_parts) *rowsq_parts = rowsq ? 1 : 0;
         return;

@@ -532,6 +532,10 @@ size_t gemm_split_planes_bytes(int N, int K) {
     // away), and behind the last block of the last tile of the last plane that reaches past the planes
     return static_cast<size_t>(3) * ((K + 31) / 32) * (16 * ((N + 15) / 16)) * 64 + 2048;
 }
+PlaneTarget gemm_split_plane_target(int N, int K, void* planes, int transposed) {
+    const int np = 16 * ((N + 15) / 16), KT = (K + 31) / 32;
+    return PlaneTarget{static_cast<unsigned char*>(planes), static_cast<size_t>(KT) * np * 64, 1, np, transposed};
+}
 void launch_gemm_split_planes(int b_layout, const float* B, int N, int K, int ldb, void* planes, hipStream_t s) {
     const int np = 16 * ((N + 15) / 16), total = ((K + 31) / 32) * np * 8;
     const int grid = (total + 255) / 256;

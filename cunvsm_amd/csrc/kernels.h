@@ -58,11 +58,17 @@ struct GridSumWs {
     int* arrive;        // [colgroups][groups_cap + 1], zero between launches
     int colgroups, contrib_cap, groups_cap, width_cap, fan;
 };
+// The bf16 planes of the new T for the next step's projection products, written by the update itself (a thread holds the new
+// element anyway: two launches of 5 us less behind the update, on the stream the next forward product waits for).
+// kind 0: none; 1: gemm_split.hip's layout (dim = padded columns np); 2: gemm_rsplit.hip's (dim = 32-column tiles).
+// transposed 0: the forward product's B (k = row of the stored T = word dimension, n = entity dimension); 1: the backward one's.
+struct PlaneTarget { unsigned char* planes; size_t plane_stride; int kind; int dim; int transposed; };
 // batch-norm backward (or, pre == null, the bias gradient alone) riding on the backward projection product: see launch_gemm_rows
 struct BnDxFused { float* dy; const float* pre; const float* mean; const float* inv_std; const double* sums;
                    float* dbeta; float* dgamma; float* grad_bias; double n_global; };
 // planes of the small operand for the split-bf16 GEMM (gemm_split.hip; see launch_gemm_split)
-struct GemmSplitWs { void* planes; size_t bytes; bool ready; };
+// ... and for the split-bf16 row-panel kernel of the per-rank batch sizes (gemm_rsplit.hip), which wants them in another order
+struct GemmSplitWs { void* planes; size_t bytes; bool ready; void* rplanes; size_t rbytes; bool rready; };
 inline int grid_sum_fan(int contributions) { return contributions > 256 ? 32 : 16; }
 
 // ---- gather-mean (F3/F9; replaces average_repr_kernel, cpp/params.cu:75-95) ------------------
@@ -101,11 +107,22 @@ bool launch_gemm_rows(int b_layout, const float* A, const float* B, float* C, in
                       float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
                       float rowsq_scale, const BnDxFused* bn);
 bool gemm_rows_covers(int b_layout, int M, int N, int K, bool colstats, bool rowsq, bool bn);      // what launch_gemm_rows accepts
+// The same decomposition on the bf16 matrix pipe (gemm_rsplit.hip; arithmetic of launch_gemm_split below): the workgroup's whole
+// 32 x K panel of A cut into bf16 planes in LDS at once, B as planes in MFMA fragment order from L2 (GemmSplitWs::rplanes,
+// gemm_rsplit_planes_bytes(N, K) bytes, cut here unless `rready`), a barrier-free K loop. Arguments as launch_gemm_rows.
+size_t gemm_rsplit_planes_bytes(int N, int K);
+void launch_gemm_rsplit_planes(int b_layout, const float* B, int N, int K, int ldb, void* planes, hipStream_t s);
+bool launch_gemm_rsplit(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                        float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
+                        float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn);
+bool gemm_rsplit_covers(int b_layout, int M, int N, int K, bool colstats, bool rowsq, bool bn);
 // Split-bf16 kernel for large batches (gemm_split.hip): fp32 operands cut exactly into three bf16 planes, nine (or six) bf16
 // MFMAs per product with fp32 accumulation. rowsq [M]: COMPLETE rowsq_scale · Σ_cols C² per row. false: not covered / switched off.
 // B travels as its three bf16 planes (GemmSplitWs::planes, gemm_split_planes_bytes(N, K) bytes, owned by the caller): cut by a
 // small launch in front of the product unless `ready` says they are current — the caller clears `ready` whenever B changes.
 size_t gemm_split_planes_bytes(int N, int K);
+PlaneTarget gemm_split_plane_target(int N, int K, void* planes, int transposed);       // for TransformUpdateArgs::pt
+PlaneTarget gemm_rsplit_plane_target(int N, int K, void* planes, int transposed);
 void launch_gemm_split_planes(int b_layout, const float* B, int N, int K, int ldb, void* planes, hipStream_t s);
 bool launch_gemm_split(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                        float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
@@ -342,6 +359,8 @@ void launch_adam_u(const float* m, const float* v, int dim, const int* idx, int 
 
 // ---- dense projection optimiser (U4; cpp/updates.cu:24-34, updates_adagrad.cu:33-70, updates_adam.cu:46-105)
 struct TransformUpdateArgs {
+    PlaneTarget pt[2];
+    int de;                          // entity dimension: T is stored [dw][de]
     float* T; float* b;              // parameters (nT = de*dw, nb = de)
     float* gT; float* gb;            // gradients (overwritten with the applied direction, as the reference does)
     float* s0T; float* s0b; float* s1T; float* s1b;

@@ -493,8 +493,9 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
     }
     bn_mean_.alloc(de, true); bn_inv_std_.alloc(de, true); dbeta_.alloc(de, true); dgamma_.alloc(de, true);
     planes_fwd_.alloc(gemm_split_planes_bytes(de, dw), true); planes_bwd_.alloc(gemm_split_planes_bytes(dw, de), true);
-    split_fwd_ = GemmSplitWs{planes_fwd_.p, planes_fwd_.n, false};
-    split_bwd_ = GemmSplitWs{planes_bwd_.p, planes_bwd_.n, false};
+    rplanes_fwd_.alloc(gemm_rsplit_planes_bytes(de, dw), true); rplanes_bwd_.alloc(gemm_rsplit_planes_bytes(dw, de), true);
+    split_fwd_ = GemmSplitWs{planes_fwd_.p, planes_fwd_.n, false, rplanes_fwd_.p, rplanes_fwd_.n, false};
+    split_bwd_ = GemmSplitWs{planes_bwd_.p, planes_bwd_.n, false, rplanes_bwd_.p, rplanes_bwd_.n, false};
     gT_.alloc(static_cast<size_t>(de) * dw, true); gb_.alloc(de, true);
     // split-K slabs of the dT product: 128 at the 51 200-window batch (400 rows each); a per-rank batch of a few thousand
     // windows cut 128 ways is 600 workgroups of two 32-deep K tiles each — all prologue, epilogue and 39 MB of partials
@@ -633,7 +634,7 @@ void Model::initialize_from_rng_state() {
     glorot(words_.P, cfg_.word_repr_size, cfg_.num_words);
     glorot(ents_.P, cfg_.entity_repr_size, cfg_.num_entities);
     glorot(T_, cfg_.entity_repr_size, cfg_.word_repr_size);
-    split_fwd_.ready = split_bwd_.ready = false;      // (T rewritten: its bf16 planes are stale)
+    planes_stale();      // (T rewritten: its bf16 planes are stale)
     NVSM_HIP_CHECK(hipMemset(b_.p, 0, b_.n * sizeof(float)));                                   // params.cu:368-369
     NVSM_HIP_CHECK(hipStreamSynchronize(nullptr));      // (queued on the null stream, which the handle's streams do not wait for)
 }
@@ -1229,9 +1230,18 @@ void Model::backward_dx() {
     auto split_ready = [&] {
         if (!split_bwd_.ready) { launch_gemm_split_planes(1, T_.p, dw, de, de, split_bwd_.planes, stream_); split_bwd_.ready = true; }
     };
+    // (the same for the row-panel kernel of the per-rank batch sizes, gemm_rsplit.hip)
+    auto rsplit_ready = [&] {
+        if (!split_bwd_.rready && B >= 512 && gemm_rsplit_covers(1, static_cast<int>(B), dw, de, false, need_msq, false)) {
+            launch_gemm_rsplit_planes(1, T_.p, dw, de, de, split_bwd_.rplanes, stream_);
+            split_bwd_.rready = true;
+        }
+    };
     auto dx_product = [&](const BnDxFused* fused) {
         if (big) return launch_gemm_split(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
                                           nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &split_bwd_, fused);
+        if (launch_gemm_rsplit(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
+                               nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, &split_bwd_, fused)) return true;
         return launch_gemm_rows(1, dy_.p, T_.p, gphrase_.p, static_cast<int>(B), dw, de, de, de, dw, inv_w, nullptr, stream_, nullptr,
                                 nullptr, need_msq ? msq_w_.p : nullptr, inv_dw, fused);
     };
@@ -1241,7 +1251,7 @@ void Model::backward_dx() {
     };
     if (cfg_.batch_normalization && sync_bn_order && !l2p && fused_covers(true)) {
         if (dp) allreduce_f64(stats_bwd_, 1 + 2 * de);
-        if (big) split_ready();
+        if (big) split_ready(); else rsplit_ready();
         BnDxFused bn{dy_.p, pre_.p, bn_mean_.p, bn_inv_std_.p, stats_bwd_ + 1, dbeta_.p, dgamma_.p, gb_.p, dp ? B_global : static_cast<double>(B)};
         bool launched = false;
         {
@@ -1264,7 +1274,7 @@ void Model::backward_dx() {
     // colsum_finalize + GEMM + sum_parts as one launch
     if (!cfg_.batch_normalization && !l2p && fused_covers(false)) {
         if (dp) allreduce_f64(stats_bwd_, 1 + de);
-        if (big) split_ready();
+        if (big) split_ready(); else rsplit_ready();
         BnDxFused bias_only{nullptr, nullptr, nullptr, nullptr, stats_bwd_ + 1, nullptr, nullptr, gb_.p, 1.0};
         bool launched = false;
         {
@@ -1679,8 +1689,27 @@ void Model::update_transform(float lr, float sl, hipStream_t strm) {
     a.s_v = static_cast<float>(1.0 - 1.0 * static_cast<double>(a.one_m_b2));
     a.bc = adam_bc(t_transform_);
     if (cfg_.update_method == NVSM_ADAM) t_transform_ += 1;
+    // T changes: its bf16 planes for the next step's two projection products are written by the update kernel itself (off the
+    // critical path in the fused step: side stream 2, which the next projection GEMM joins anyway). Which layout: the kernels
+    // this step's batch size runs on (a step of another size finds its planes stale and cuts them itself).
+    planes_stale();
+    a.de = cfg_.entity_repr_size;
+    const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size, B = static_cast<int>(B_);
+    if (gemm_split_products() && tune_.planes_in_update) {
+        if (B_ > gemm_rows_max_m()) {
+            if (gemm_split_covers(0, B, de, dw, false)) { a.pt[0] = gemm_split_plane_target(de, dw, split_fwd_.planes, 0); split_fwd_.ready = true; }
+            if (gemm_split_covers(1, B, dw, de, false)) { a.pt[1] = gemm_split_plane_target(dw, de, split_bwd_.planes, 1); split_bwd_.ready = true; }
+        } else if (B >= 512) {
+            if (gemm_rsplit_covers(0, B, de, dw, cfg_.batch_normalization != 0, false, false)) {
+                a.pt[0] = gemm_rsplit_plane_target(de, dw, split_fwd_.rplanes, 0); split_fwd_.rready = true;
+            }
+            if (gemm_rsplit_covers(1, B, dw, de, false, false, false)) {
+                a.pt[1] = gemm_rsplit_plane_target(dw, de, split_bwd_.rplanes, 1); split_bwd_.rready = true;
+            }
+        }
+    }
     launch_transform_update(a, strm);
-    cut_transform_planes(strm);
+    if (!tune_.planes_in_update) cut_transform_planes(strm);
 }
 
 // The dispatch of a step at `batch` windows in one place, as text (nvsm_describe): the three projection products' kernels, where
@@ -1694,6 +1723,8 @@ std::string Model::describe(int64_t batch) const {
     const bool bn = cfg_.batch_normalization != 0, l2p = cfg_.l2_normalize_phrase_reprs != 0;
     auto product = [&](int b_layout, int N, int K, bool stats, bool rowsq, bool fused_bn) -> std::string {
         const int rows_max = gemm_rows_max_m();
+        if (B >= 512 && B <= rows_max && gemm_rsplit_covers(b_layout, B, N, K, stats, rowsq, fused_bn))
+            return "gemm_rsplit (3 bf16 planes, " + std::to_string(gemm_split_products()) + " of 9 products, 32-row panels)";
         if (B >= 512 && B <= rows_max && gemm_rows_covers(b_layout, B, N, K, stats, rowsq, fused_bn)) return "gemm_rows (exact fp32 MFMA, 32-row panels)";
         if (B > rows_max && gemm_split_covers(b_layout, B, N, K, fused_bn))
             return "gemm_split (3 bf16 planes, " + std::to_string(gemm_split_products()) + " of 9 products)";
@@ -1742,10 +1773,25 @@ bool Model::dt_on_main() const {
 
 // T changed: its bf16 planes for the next two projection products, behind the writer on the writer's stream (off the critical
 // path in the fused step: side stream 2, which the next projection GEMM joins anyway)
+void Model::planes_stale() { split_fwd_.ready = split_bwd_.ready = split_fwd_.rready = split_bwd_.rready = false; }
+
 void Model::cut_transform_planes(hipStream_t strm) {
-    split_fwd_.ready = split_bwd_.ready = false;
-    if (!gemm_split_products() || B_ <= gemm_rows_max_m()) return;       // (the exact-fp32 kernels are in use)
+    planes_stale();
+    if (!gemm_split_products()) return;                                   // (the exact-fp32 kernels are in use)
     const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size;
+    if (B_ <= gemm_rows_max_m()) {
+        // per-rank batch sizes: the planes in the row-panel kernel's fragment order (gemm_rsplit.hip), where it covers the shapes
+        const int B = static_cast<int>(B_);
+        if (B >= 512 && gemm_rsplit_covers(0, B, de, dw, cfg_.batch_normalization != 0, false, false)) {
+            launch_gemm_rsplit_planes(0, T_.p, de, dw, de, split_fwd_.rplanes, strm);
+            split_fwd_.rready = true;
+        }
+        if (B >= 512 && gemm_rsplit_covers(1, B, dw, de, false, false, false)) {
+            launch_gemm_rsplit_planes(1, T_.p, dw, de, de, split_bwd_.rplanes, strm);
+            split_bwd_.rready = true;
+        }
+        return;
+    }
     launch_gemm_split_planes(0, T_.p, de, dw, de, split_fwd_.planes, strm);      // forward: B = T as [K = dw][N = de]
     launch_gemm_split_planes(1, T_.p, dw, de, de, split_bwd_.planes, strm);      // backward: B stored [N = dw][K = de]
     split_fwd_.ready = split_bwd_.ready = true;
@@ -1989,7 +2035,7 @@ void Model::set_param(const std::string& name, const float* src, int64_t count) 
     synchronize();
     lazy_flush_all();
     NVSM_HIP_CHECK(hipMemcpy(r.p, src, count * sizeof(float), hipMemcpyHostToDevice));
-    split_fwd_.ready = split_bwd_.ready = false;
+    planes_stale();
 }
 
 void Model::increment_param(const std::string& name, int64_t index, float delta) {
@@ -2002,7 +2048,7 @@ void Model::increment_param(const std::string& name, int64_t index, float delta)
     NVSM_HIP_CHECK(hipMemcpy(&v, r.p + index, sizeof(float), hipMemcpyDeviceToHost));
     v += delta;
     NVSM_HIP_CHECK(hipMemcpy(r.p + index, &v, sizeof(float), hipMemcpyHostToDevice));
-    split_fwd_.ready = split_bwd_.ready = false;
+    planes_stale();
 }
 
 int64_t Model::tensor_size(const std::string& name) {

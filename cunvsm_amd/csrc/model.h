@@ -258,7 +258,8 @@ class Model {
     SumsBufs sums_fwd_, sums_bwd_;
     // the projection matrix cut into bf16 planes for the split-bf16 GEMM (gemm_split.hip), in the forward and the backward
     // product's layout; `ready` is cleared by everything that writes T
-    DevBuf<char> planes_fwd_, planes_bwd_;
+    DevBuf<char> planes_fwd_, planes_bwd_, rplanes_fwd_, rplanes_bwd_;
+    void planes_stale();                 // T changed: every set of planes is out of date
     GemmSplitWs split_fwd_{}, split_bwd_{};
     void cut_transform_planes(hipStream_t strm);
     bool dt_on_main() const;

@@ -1268,14 +1268,25 @@ void launch_adam_u(const float* m, const float* v, int dim, const int* idx, int 
 // (include/cuNVSM/updates.h:39-62); the bias slot of every TransformStorage::update hard-codes λ = 0
 // (cpp/storage.cu:223-227) so the Adam bias moments never decay; SGD/Adagrad decay T by (1 − λ·lr).
 // =============================================================================================
-__global__ void transform_update_kernel(TransformUpdateArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.nT + a.nb) return;
-    const bool is_bias = i >= a.nT;
-    float* P = is_bias ? a.b + (i - a.nT) : a.T + i;
-    float* G = is_bias ? a.gb + (i - a.nT) : a.gT + i;
-    float g = *G;
-    float p = *P;
+// the three bf16 pieces of x (gemm_split.hip split_pair: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round to nearest)
+// stored where the projection products' kernels expect the element (k, n) of their B operand
+__device__ __forceinline__ void store_plane_pieces(const PlaneTarget& t, int kw, int ne, float x) {
+    if (!t.kind) return;
+    const int k = t.transposed ? ne : kw, n = t.transposed ? kw : ne;
+    size_t off;
+    if (t.kind == 1) off = (static_cast<size_t>(k >> 5) * t.dim + n) * 64 + (k & 31) * 2;
+    else off = ((static_cast<size_t>(k >> 4) * t.dim + (n >> 5)) * 64 + (n & 31) + 32 * ((k >> 3) & 1)) * 16 + (k & 7) * 2;
+    const __bf16 h = static_cast<__bf16>(x);
+    const float r = x - static_cast<float>(h);
+    const __bf16 m = static_cast<__bf16>(r);
+    const float s = r - static_cast<float>(m);
+    const __bf16 l = static_cast<__bf16>(s);
+    *reinterpret_cast<__bf16*>(t.planes + off) = h;
+    *reinterpret_cast<__bf16*>(t.planes + off + t.plane_stride) = m;
+    *reinterpret_cast<__bf16*>(t.planes + off + 2 * t.plane_stride) = l;
+}
+
+__device__ __forceinline__ void transform_update_element(const TransformUpdateArgs& a, bool is_bias, int i, float* P, float* G, float g, float p) {
     if (a.method == 0) {                                             // SGD  (updates.cu:24-34)
         const float dec = is_bias ? 1.f : static_cast<float>(1.0 - static_cast<double>(a.lambda) * static_cast<double>(a.lr));
         *P = p * dec + g * a.lr;
@@ -1298,6 +1309,23 @@ __global__ void transform_update_kernel(TransformUpdateArgs a) {
         g = (m * a.bc) / (sqrtf(v) + a.eps);
         *G = g;
         *P = p * 1.f + g * a.lr;
+    }
+}
+
+__global__ void transform_update_kernel(TransformUpdateArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nT + a.nb) return;
+    const bool is_bias = i >= a.nT;
+    float* P = is_bias ? a.b + (i - a.nT) : a.T + i;
+    float* G = is_bias ? a.gb + (i - a.nT) : a.gT + i;
+    float g = *G;
+    float p = *P;
+    transform_update_element(a, is_bias, i, P, G, g, p);
+    if (!is_bias && (a.pt[0].kind | a.pt[1].kind)) {
+        const float x = *P;                                          // (the value just stored: same thread)
+        const int kw = i / a.de, ne = i - kw * a.de;
+        store_plane_pieces(a.pt[0], kw, ne, x);
+        store_plane_pieces(a.pt[1], kw, ne, x);
     }
 }
 

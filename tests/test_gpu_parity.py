@@ -76,6 +76,32 @@ def test_gemm_split_bf16_is_fp32_accurate(M, layout, N, K, monkeypatch):
     assert rel_err(out["6"], out["9"].astype(np.float64)) < 3e-7
 
 
+@pytest.mark.parametrize("M", [512, 1031, 4096, 6400, 8192])
+@pytest.mark.parametrize("layout,N,K", [(0, 256, 300), (1, 300, 256), (0, 256, 128), (1, 128, 256), (1, 272, 64), (0, 64, 20)])
+def test_gemm_rsplit_bf16_is_fp32_accurate(M, layout, N, K, monkeypatch):
+    """gemm_rsplit.hip — the same arithmetic for the per-rank batch sizes (32-row panels, the panel's planes in LDS at once): held
+    against the exact-fp32 row-panel kernel (gemm_rows.hip, NVSM_GEMM_SPLIT=0) exactly as the large-batch kernel is above; ragged
+    row counts (a last workgroup of 7 rows), K not a multiple of 16, fewer column tiles than waves."""
+    rs = np.random.RandomState(M + N + K)
+    A = (rs.standard_normal((M, K)) * np.exp2(rs.randint(-12, 4, (M, K)))).astype(np.float32)
+    Bm = (rs.standard_normal((K, N)) * 0.1 * np.exp2(rs.randint(-6, 3, (K, N))) + np.arange(N)[None, :] * 1e-3).astype(np.float32)
+    Bh = np.ascontiguousarray(Bm.T if layout else Bm)
+    ref = A.astype(np.float64) @ Bm.astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64)
+    out, err = {}, {}
+    for mode in ("0", "9", "6"):
+        monkeypatch.setenv("NVSM_GEMM_SPLIT", mode)
+        out[mode] = np.empty((M, N), np.float32)
+        ca._lib.check(ca.lib().nvsm_debug_gemm(layout, M, N, K, A.ctypes.data, Bh.ctypes.data, out[mode].ctypes.data))
+        e = (out[mode].astype(np.float64) - ref) / scale
+        err[mode] = (np.abs(e).max(), np.sqrt((e ** 2).mean()))
+    assert not np.array_equal(out["0"], out["9"])                      # (the split kernel did run)
+    for mode in ("9", "6"):
+        assert err[mode][0] < 1.5 * err["0"][0] + 1e-8, err            # largest error, relative to Σ|a b|
+        assert err[mode][1] < 1.1 * err["0"][1] + 1e-9, err            # root mean square
+    assert rel_err(out["6"], out["9"].astype(np.float64)) < 3e-7
+
+
 @pytest.mark.parametrize("split", [2, 7, 128])
 @pytest.mark.parametrize("exact", [0, 1])
 def test_gemm_split_k(split, exact):

@@ -361,6 +361,9 @@ void launch_adam_u(const float* m, const float* v, int dim, const int* idx, int 
 struct TransformUpdateArgs {
     PlaneTarget pt[2];
     int de;                          // entity dimension: T is stored [dw][de]
+    // the split-K slabs of the dT product, added up here instead of by launch_splitk_reduce in front of the update (null: gT holds
+    // the gradient): the same sums in the same order — 16 interleaved groups of slabs, then the groups in order — one launch less
+    const float* partial; int slabs; size_t slab_stride;
     float* T; float* b;              // parameters (nT = de*dw, nb = de)
     float* gT; float* gb;            // gradients (overwritten with the applied direction, as the reference does)
     float* s0T; float* s0b; float* s1T; float* s1b;

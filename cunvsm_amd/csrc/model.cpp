@@ -506,7 +506,10 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
     // with 32-48, 0.926 with 16, 1.000 with 8; batch 12 800: 0.442 with 100 slabs, 0.417 with 50, 0.405 with 8-24; interleaved
     // A/B). NVSM_DT_SLABS overrides.
     {
-        gemm_slabs_want_ = tune_.dt_slabs > 0 ? tune_.dt_slabs : (B > gemm_rows_max_m() ? 16 : static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, B / 128))));
+        // Round 5: per-rank batches in slabs of ~400 rows (16 at batch 6 400; was 50): the projection update now adds the slabs up
+        // itself (TransformUpdateArgs::partial — every thread walks them), and the product sits on the chain the next forward
+        // product waits for: batch 6 400 0.2746 ms with 50 slabs, 0.2655 with 25, 0.2635 with 16, 0.2706 with 8 (interleaved A/B).
+        gemm_slabs_want_ = tune_.dt_slabs > 0 ? tune_.dt_slabs : (B > gemm_rows_max_m() ? 16 : static_cast<int>(std::min<int64_t>(24, std::max<int64_t>(8, B / 400))));
     }
     // the split-K dT kernel (gemm_dt.hip): at most a slab per two CUs (two workgroups per slab)
     dt_ok_ = gemm_dt_covers(dw, de, static_cast<int>(B));
@@ -1353,8 +1356,11 @@ void Model::backward_T(hipStream_t strm) {
         const int slabs = gemm_split_k_slabs(static_cast<int>(B), gemm_slabs_want_);
         const size_t stride = static_cast<size_t>(de) * dw;
         auto reduce = [&](int n) {
+            // (the fused step without collectives: the projection update that follows on this stream adds the slabs up itself)
+            if (fuse_slab_sum_) { pending_slabs_ = n; prof.note("slab_sum_in_update"); return; }
             timed_launch(prof, "gemm_bwd_T_reduce", strm, true, [&] { launch_splitk_reduce(gT_partial_.p, n, stride, gT_.p, static_cast<int64_t>(stride), strm); });
         };
+        pending_slabs_ = 0;
         if (use_dt()) {
             // the split-K product on the bf16 matrix pipe (gemm_dt.hip): two workgroups per slab.
             // Slabs: the kernel ALONE is fastest with a workgroup on every CU (128 slabs: 55 us at batch 51 200), but in a step it
@@ -1694,6 +1700,7 @@ void Model::update_transform(float lr, float sl, hipStream_t strm) {
     // this step's batch size runs on (a step of another size finds its planes stale and cuts them itself).
     planes_stale();
     a.de = cfg_.entity_repr_size;
+    if (pending_slabs_ > 0) { a.partial = gT_partial_.p; a.slabs = pending_slabs_; a.slab_stride = static_cast<size_t>(a.nT); pending_slabs_ = 0; }
     const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size, B = static_cast<int>(B_);
     if (gemm_split_products() && tune_.planes_in_update) {
         if (B_ > gemm_rows_max_m()) {
@@ -1905,7 +1912,10 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
             NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_));
             NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_gathered_, 0));
         } else {
-            backward_T(aux2_stream_);
+            // (the slabs of the split-K product are added up by the projection update behind it on the same stream)
+            fuse_slab_sum_ = tune_.slab_sum_in_update;
+            try { backward_T(aux2_stream_); } catch (...) { fuse_slab_sum_ = false; throw; }
+            fuse_slab_sum_ = false;
         }
         NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_bwdx_, 0));      // the dx GEMM is the last reader of T
         update_transform(lr, sl, aux2_stream_);

@@ -259,6 +259,8 @@ class Model {
     // the projection matrix cut into bf16 planes for the split-bf16 GEMM (gemm_split.hip), in the forward and the backward
     // product's layout; `ready` is cleared by everything that writes T
     DevBuf<char> planes_fwd_, planes_bwd_, rplanes_fwd_, rplanes_bwd_;
+    bool fuse_slab_sum_ = false;         // step(): backward_T leaves the slab sum to the projection update behind it
+    int pending_slabs_ = 0;              //   ... that many slabs in gT_partial_
     void planes_stale();                 // T changed: every set of planes is out of date
     GemmSplitWs split_fwd_{}, split_bwd_{};
     void cut_transform_planes(hipStream_t strm);

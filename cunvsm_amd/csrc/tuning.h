@@ -57,6 +57,7 @@ struct Tuning {
     int docs_delay_us = 0;              // NVSM_DOCS_DELAY_US (a spin kernel in front of the documents update on its side stream)
     int dt_min_batch = 40960;           // NVSM_DT_MIN_B (the split-bf16 dT kernel from this batch size up)
     bool untouched_aside = true;        // NVSM_UNTOUCHED_ASIDE
+    bool slab_sum_in_update = true;     // NVSM_SLAB_SUM_IN_UPDATE (fused step: the projection update adds up the dT product's slabs; 0: launch_splitk_reduce)
     bool planes_in_update = true;       // NVSM_PLANES_IN_UPDATE (the projection update writes T's bf16 planes itself; 0: two launches behind it)
     bool gemm_rsplit = true;            // NVSM_GEMM_RSPLIT (the split-bf16 row-panel kernel at per-rank batch sizes; 0: gemm_rows)
     bool early_snapshot = true;         // NVSM_EARLY_SNAPSHOT (words scalar snapshot behind the CSR build)

@@ -1289,6 +1289,7 @@ __device__ __forceinline__ void store_plane_pieces(const PlaneTarget& t, int kw,
 __device__ __forceinline__ void transform_update_element(const TransformUpdateArgs& a, bool is_bias, int i, float* P, float* G, float g, float p) {
     if (a.method == 0) {                                             // SGD  (updates.cu:24-34)
         const float dec = is_bias ? 1.f : static_cast<float>(1.0 - static_cast<double>(a.lambda) * static_cast<double>(a.lr));
+        if (a.partial && !is_bias) *G = g;                           // (the slabs' sum: what launch_splitk_reduce would have left in gT)
         *P = p * dec + g * a.lr;
     } else if (a.method == 1) {                                      // Adagrad (updates_adagrad.cu:33-70)
         float* A = is_bias ? a.s0b + (i - a.nT) : a.s0T + i;
@@ -1318,7 +1319,24 @@ __global__ void transform_update_kernel(TransformUpdateArgs a) {
     const bool is_bias = i >= a.nT;
     float* P = is_bias ? a.b + (i - a.nT) : a.T + i;
     float* G = is_bias ? a.gb + (i - a.nT) : a.gT + i;
-    float g = *G;
+    float g;
+    if (a.partial && !is_bias) {
+        // splitk_reduce_kernel's sum (gather_gemm.hip): group j adds slabs j, j + 16, j + 32, ... in that order, then the sixteen
+        // group sums are added in group order
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int z0 = 0; z0 < a.slabs; z0 += 16) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (z0 + j < a.slabs) acc[j] += a.partial[static_cast<size_t>(z0 + j) * a.slab_stride + i];
+        }
+        g = acc[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) g += acc[j];
+    } else {
+        g = *G;
+    }
     float p = *P;
     transform_update_element(a, is_bias, i, P, G, g, p);
     if (!is_bias && (a.pt[0].kind | a.pt[1].kind)) {

@@ -306,6 +306,7 @@ struct RowPassArgs {
     int shallow;               // set by launch_row_pass: two entries in flight per lane instead of eight (rows >= entries)
     int lazy;                  // lazy dense decay (below): rows without entries are NOT visited, their decay stays pending
     int rows_elsewhere;        // set by launch_table_pass: the rows of at most a chunk's entries are done by entry_walk_kernel
+    int untouched_done;        // the streaming pass over the rows WITHOUT entries of a split dense pass has been queued already (launch_untouched_rows)
     LazyView pending;          // lazy: the row's P (and m, by s_m) first get the factors of the updates (stamp[row], now] the
                                //   row sat out, one by one (pending.stamp null: the rows are current)
 };
@@ -347,6 +348,11 @@ void launch_chunk_pass(const Csr& c, const RowPassArgs& a, hipStream_t s);
 // Those rows and the rows with entries are disjoint, so the two launches need no order between them — only the CSR bounds
 // in front of both and the table's next reader behind both.
 void launch_row_pass(const Csr& c, const RowPassArgs& a, hipStream_t s, hipStream_t untouched_s = nullptr);
+// The streaming half of a split dense pass on its own: the rows WITHOUT entries of a table much larger than the batch get the
+// row formula with g = 0 (the decay). It needs the CSR's row bounds and nothing else of the step, so the fused step queues it
+// right behind the CSR build, under the forward pass, instead of in the update's tail; the pass proper is then launched with
+// RowPassArgs::untouched_done. true: launched (the pass is split, dense, not lazy, its kind row-local for untouched rows).
+bool launch_untouched_rows(const Csr& c, const RowPassArgs& a, hipStream_t s);
 // both, in one launch (update.hip). Returns how the rows with entries were walked (tests assert which path a shape took).
 enum TablePassPath { TABLE_PASS_DENSE = 0, TABLE_PASS_LIST_WALK = 1, TABLE_PASS_ENTRY_WALK = 2 };
 int launch_table_pass(const Csr& c, const RowPassArgs& a, hipStream_t s, hipStream_t untouched_s = nullptr);

@@ -353,15 +353,29 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
 
     float sdy[4] = {0, 0, 0, 0}, sdyx[4] = {0, 0, 0, 0};
     float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1}, beta[4] = {0, 0, 0, 0};
-    if (a.bn) {
-        bn_stats_from_sums<4>(a.bn_sums, de, valid ? c : 0, a.bn_n, a.bn_eps, mu, is);
-        if (blockIdx.x == 0 && wid == 0 && valid) { stv<4>(a.bn_mean + c, mu); stv<4>(a.bn_inv_std + c, is); }       // for bn_dx
-        ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.bias) + coff), beta);
-    }
     float lane_loss = 0.f;
     const int lane_r = lane < R ? lane : R - 1;
     float dlo = 1.f, dhi = 1.f;
     if (LAZY) { dlo = a.lazyE.decay[lane]; dhi = a.lazyE.decay[lane + 64]; }
+    // The batch statistics μ, 1/sqrt(σ² + ε) of the columns: a few dozen fp64 operations per column (two divisions, a square
+    // root, a reciprocal). Every wave used to evaluate its own four columns — the same 256 values four times per workgroup, a
+    // microsecond and a half of each wave's life in front of its first load, which shows at per-rank batch sizes where a wave
+    // lives for two or three examples. Now wave w evaluates columns 64 w .. 64 w + 63, one per lane, and the workgroup shares them
+    // through LDS (the same function on the same inputs: the same bits); the first example's inputs are requested before that.
+    auto bn_setup = [&]() __attribute__((always_inline)) {
+        if (!a.bn) return;
+        float* s_mu = lds + 8 * de + 8;       // [de] | [de] behind the column-sum scratch of the epilogue
+        float* s_is = s_mu + de;
+        for (int col = threadIdx.x; col < de; col += 256) {
+            float m1[1], i1[1];
+            bn_stats_from_sums<1>(a.bn_sums, de, col, a.bn_n, a.bn_eps, m1, i1);
+            s_mu[col] = m1[0]; s_is[col] = i1[0];
+            if (blockIdx.x == 0) { a.bn_mean[col] = m1[0]; a.bn_inv_std[col] = i1[0]; }       // for bn_dx
+        }
+        ldv<4>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.bias) + coff), beta);
+        __syncthreads();
+        if (valid) { ldv<4>(s_mu + c, mu); ldv<4>(s_is + c, is); }
+    };
 
     // rows r0 .. r0 + RB - 1 of the example whose ids the lanes hold in `ids_lane`, one 16 B column slice per lane
     auto issue_rows = [&](float (&e)[RB][4], int ids_lane, int r0) __attribute__((always_inline)) {
@@ -456,8 +470,9 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
         float xn[4] = {0, 0, 0, 0};
         int idn = 0, stampn = 0;
         float wn = 1.f;
+        if (e0 < e1) load_inputs(e0, xn, idn, wn);
+        bn_setup();
         if (e0 < e1) {
-            load_inputs(e0, xn, idn, wn);
             if (LAZY) stampn = a.lazyE.stamp[static_cast<uint32_t>(idn)];
         }
         for (int64_t b = e0; b < e1; ++b) {
@@ -481,8 +496,9 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a, int ex_per_w
         int idc = 0, id1 = 0, id2 = 0, stampc = 0, stamp1 = 0;
         float wc = 1.f, w1 = 1.f, w2 = 1.f;
         float eA[RB][4], eB[RB][4];
+        if (e0 < e1) load_inputs(e0, xc, idc, wc);
+        bn_setup();
         if (e0 < e1) {
-            load_inputs(e0, xc, idc, wc);
             if (LAZY) stampc = a.lazyE.stamp[static_cast<uint32_t>(idc)];
             issue_rows(eA, idc, 0);
             if (e0 + 1 < e1) load_inputs(e0 + 1, x1, id1, w1);
@@ -543,6 +559,10 @@ static void launch_loss_rows(const LossArgs& a_in, hipStream_t s) {
     if (a.B >= 40960) epw = 20;
     // (batch 4096: two examples per wave, 512 workgroups — half as many fp64 atomics per column: 44 -> 33 us)
     if (epw < 2 && a.B >= 2048) epw = 2;
+    // per-rank batches (round 5): about 400-500 workgroups — ONE round of workgroups with room to spare (768 fit) instead of a
+    // round and a bit (batch 6 400: 800 workgroups of two examples per wave; the stragglers of the second round cost a whole
+    // workgroup's latency): alone 47.9 -> 42.8 us, step 0.2637 -> 0.2569 ms with four examples per wave (3: 0.2604; 5, 6: slower)
+    if (a.B > 4096 && a.B <= 8192) epw = static_cast<int>((a.B + 4 * 512 - 1) / (4 * 512));
     // Two row sets per wave (PIPE; two workgroups fit a CU) where the documents table does not fit the 256 MB Infinity Cache and
     // every row comes out of HBM at 1 800 cycles: |D| = 2 M, batch 51 200: 295 -> 244 us in the step (0.44 -> 0.54 of peak) with
     // one round of 512 workgroups. But two such workgroups leave a CU no registers for anything else, and what runs next to this
@@ -557,7 +577,7 @@ static void launch_loss_rows(const LossArgs& a_in, hipStream_t s) {
     if (epw_env > 0) epw = epw_env;
     const int grid = ceil_div(a.B, 4 * epw);
     a.sums.fan = grid_sum_fan(grid);
-    const size_t shmem = (8 * static_cast<size_t>(a.de) + 8) * sizeof(float);
+    const size_t shmem = (10 * static_cast<size_t>(a.de) + 8) * sizeof(float);      // column-sum scratch [2][4][de] | loss [4] | flag | μ [de] | 1/σ [de]
     if (pipe) {
         if (a.lazyE.stamp) NVSM_LAUNCH((loss_rows_kernel<RB, true, true>), dim3(grid), dim3(256), shmem, s, a, epw);
         else NVSM_LAUNCH((loss_rows_kernel<RB, false, true>), dim3(grid), dim3(256), shmem, s, a, epw);

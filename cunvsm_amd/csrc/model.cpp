@@ -443,7 +443,7 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_inputs_, dev_flags));
     NVSM_HIP_CHECK(hipEventCreateWithFlags(&ev_csr_, dev_flags));
     NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&cost_host_), sizeof(double), hipHostMallocDefault));
-    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_step_begin_[0], &ev_step_begin_[1], &ev_gathered_, &ev_words_late_, &ev_cost_ready_})
+    for (hipEvent_t* e : {&ev_loss_, &ev_dx_, &ev_bwdx_, &ev_E_done_, &ev_T_done_, &ev_step_begin_[0], &ev_step_begin_[1], &ev_gathered_, &ev_words_late_, &ev_cost_ready_, &ev_untouched_})
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, dev_flags));
     for (hipEvent_t* e : {&ev_copied_, &ev_host_ids_[0], &ev_host_ids_[1], &ev_cost_copied_})      // (the host waits on these)
         NVSM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -529,7 +529,7 @@ Model::~Model() {
     if (ev_inputs_) (void)hipEventDestroy(ev_inputs_);
     if (ev_csr_) (void)hipEventDestroy(ev_csr_);
     for (hipEvent_t e : {ev_loss_, ev_dx_, ev_bwdx_, ev_E_done_, ev_T_done_, ev_copied_, ev_step_begin_[0], ev_step_begin_[1],
-                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_, ev_words_late_, ev_cost_ready_, ev_cost_copied_}) if (e) (void)hipEventDestroy(e);
+                         ev_host_ids_[0], ev_host_ids_[1], ev_gathered_, ev_words_late_, ev_cost_ready_, ev_cost_copied_, ev_untouched_}) if (e) (void)hipEventDestroy(e);
     if (cost_host_) (void)hipHostFree(cost_host_);
     for (int p = 0; p < 2; ++p) if (host_ids_pin_[p]) (void)hipHostFree(host_ids_pin_[p]);
     if (err_host_) (void)hipHostFree(err_host_);
@@ -1063,7 +1063,28 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         auto wrds = [&] {
             { PROF_ON("csr_words", sw); build_csr(words_, csr_widx, Bu * w, sw); }
             if (words_.lazy && words_.lazy_scalar && tune_.early_snapshot) { lazy_scalar_snapshot(words_, csr_of(words_, Bu * w), sw); words_snapshot_early_ = true; }
+            // The fused step knows lr and λ already: the decay of the words rows WITHOUT entries (SGD / Adagrad, λ > 0, a table
+            // much larger than the batch: launch_untouched_rows) goes here, under the forward pass, instead of into the update's
+            // tail where the next step's word gather waited for it (LSE batch 4096: 16-22 us per step). Nothing of this step
+            // reads those rows; the NEXT word gather may. NVSM_HOIST_UNTOUCHED=1 (default): in front of the event the words update
+            // waits for — the main stream is then behind the pass without a wait of its own (a wait is a packet the stream
+            // stops at for 6-10 us even when the event has long fired); 2: behind that event, with an event of its own that
+            // the next word gather follows (the build is not lengthened by the pass's 11 us).
+            words_untouched_hoisted_ = false;
+            const bool hoist = hoist_untouched_ && !words_.lazy && (cfg_.update_method == NVSM_SGD || cfg_.update_method == NVSM_ADAGRAD);
+            auto hoisted_pass = [&] {
+                RowPassArgs ua = final_words_pass_args(hoist_lr_, hoist_sl_);
+                if (!launch_untouched_rows(csr_of(words_, Bu * w), ua, sw)) return false;
+                words_untouched_hoisted_ = true;
+                prof.note("untouched_words_hoisted");
+                return true;
+            };
+            if (hoist && tune_.hoist_untouched == 1) (void)hoisted_pass();
             NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw));
+            if (hoist && tune_.hoist_untouched == 2 && hoisted_pass()) {
+                NVSM_HIP_CHECK(hipEventRecord(ev_untouched_, sw));
+                words_untouched_pending_ = true;
+            }
         };
         if (layout == 1) { if (which & 2) wrds(); if (which & 1) ents(); } else { if (which & 1) ents(); if (which & 2) wrds(); }
         if ((which & 1) && se != aux_stream_) NVSM_HIP_CHECK(hipStreamWaitEvent(aux_stream_, ev_csr_ents_, 0));     // the documents update follows its CSR
@@ -1076,6 +1097,9 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     // HBM-bound loss kernel
     const bool words_csr_late_env = tune_.words_csr_late;
     const bool words_csr_late = words_csr_late_env && csr_after == 0 && !any_lazy;
+    // (the previous step's hoisted decay of the words rows without entries — see `wrds` above — wrote rows this step's word gather
+    //  may read: the main stream follows its event; issued here, in front of the builds that record the event anew)
+    if (words_untouched_pending_) { NVSM_HIP_CHECK(hipStreamWaitEvent(stream_, ev_untouched_, 0)); words_untouched_pending_ = false; }
     if (csr_first) launch_csr_builds(ev_inputs_, words_csr_late ? 1 : 3);
     // (lazy dense decay: the gathers below bring the rows they read up to date on the fly — LazyView — and the row passes of
     //  the update do it for real; nothing waits for the sorts here)
@@ -1088,6 +1112,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     const int join_e_at = tune_.join_e;
     if (join_e_at == 2) join_E();
     if (words_tail_pending_) { join_T(); words_tail_pending_ = false; }      // the previous step's streaming decay of the words table (step())
+
     {
         const bool l2p = cfg_.l2_normalize_phrase_reprs != 0;
         const LazyView lv = lazy_view(words_);
@@ -1612,6 +1637,18 @@ void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row
     lazy_end_update(t, c, strm);
 }
 
+// what the LAST pass of an SGD / Adagrad words update looks like to the rows without entries (launch_untouched_rows): P *= decay
+RowPassArgs Model::final_words_pass_args(float lr, float sl) {
+    RowPassArgs a{};
+    a.table = 0; a.kind = ROW_SGD; a.div = static_cast<uint32_t>(cfg_.window_size);
+    a.div_magic = (uint64_t(1) << 37) / a.div + 1;
+    a.P = words_.P.p; a.m = words_.m.p; a.v = words_.vfull.p; a.dim = cfg_.word_repr_size;
+    a.lr = lr; a.lambda = sl; a.eps = 1e-6f;
+    a.decay = sl > 0.f ? static_cast<float>(1.0 - static_cast<double>(sl) * static_cast<double>(lr)) : 1.f;
+    a.dense = sl > 0.f;
+    return a;
+}
+
 void Model::update_words(float lr, float sl) {
     const int dw = cfg_.word_repr_size, w = cfg_.window_size;
     const UpdateInputs u = update_inputs();
@@ -1625,9 +1662,13 @@ void Model::update_words(float lr, float sl) {
     a.lr = lr; a.lambda = sl; a.eps = 1e-6f;
     a.decay = sl > 0.f ? static_cast<float>(1.0 - static_cast<double>(sl) * static_cast<double>(lr)) : 1.f;
     const int method = cfg_.update_method, mode = cfg_.adam_mode;
+    // (the fused step queued the decay of the rows without entries behind the CSR build already — with these very lr and λ)
+    const bool hoisted = words_untouched_hoisted_ && lr == hoist_lr_ && sl == hoist_sl_;
+    if (words_untouched_hoisted_ && !hoisted) throw Error(NVSM_ERR_STATE, "the hoisted words decay was queued with another learning rate / lambda");
+    words_untouched_hoisted_ = false;
 
     if (method == NVSM_SGD) {
-        a.kind = ROW_SGD; a.dense = sl > 0.f;
+        a.kind = ROW_SGD; a.dense = sl > 0.f; a.untouched_done = hoisted;
         lazy_begin_update(t, a, false);
         { PROF("row_pass_words"); launch_table_pass(c, a, stream_, words_untouched_stream_); }
         lazy_end_update(t, c, stream_);
@@ -1641,7 +1682,7 @@ void Model::update_words(float lr, float sl) {
         s.sc_in = t.sc[t.sc_cur].p; s.sc_out = t.sc[t.sc_cur].p;
         { PROF("adagrad_acc_words"); launch_table_pass(c, s, stream_, words_untouched_stream_); }
         { PROF("adagrad_scale_words"); launch_adagrad_scale(t.sc[t.sc_cur].p, u.widx, w, u.B, 1e-6f, scale_w_.p, stream_); }
-        a.kind = ROW_SGD; a.src_scale = scale_w_.p; a.dense = sl > 0.f;
+        a.kind = ROW_SGD; a.src_scale = scale_w_.p; a.dense = sl > 0.f; a.untouched_done = hoisted;
         lazy_begin_update(t, a, false);
         { PROF("row_pass_words"); launch_table_pass(c, a, stream_, words_untouched_stream_); }
         lazy_end_update(t, c, stream_);
@@ -1845,8 +1886,15 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     const bool docs_after_dx = docs_after_dx_env >= 0 ? docs_after_dx_env != 0 : batch.num_instances >= 16384;
     const bool loss_event = !(docs_after_dx && fewer_events);      // (see below)
     loss_stop_event_ = loss_event ? ev_loss_ : nullptr;
-    try { compute_cost(batch, entity_ids); } catch (...) { loss_stop_event_ = nullptr; throw; }
+    {
+        // lr and λ are known before the forward pass: parts of the update that depend on nothing else can be queued early (compute_cost)
+        const double Bg = static_cast<double>(batch.num_instances > 0 ? batch.num_instances : 1) * (cfg_.world_size > 1 ? cfg_.world_size : 1);
+        hoist_lr_ = lr; hoist_sl_ = cfg_.regularization_lambda / static_cast<float>(Bg);      // = scaled_regularization_lambda() behind compute_cost
+        hoist_untouched_ = tune_.hoist_untouched != 0 && lr >= 0.f && hoist_sl_ > 0.f;
+    }
+    try { compute_cost(batch, entity_ids); } catch (...) { loss_stop_event_ = nullptr; hoist_untouched_ = false; throw; }
     loss_stop_event_ = nullptr;
+    hoist_untouched_ = false;
     // The caller wants this step's loss: the loss word is final behind the loss kernel, 0.3 ms into a 0.9 ms step. A copy on side
     // stream 3 behind an event recorded here lets the host read it while the backward pass and the updates still run, and
     // queue the next step in the meantime (waiting for the whole step instead — get_cost() — left the GPU idle while the host
@@ -1913,7 +1961,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
             NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_gathered_, 0));
         } else {
             // (the slabs of the split-K product are added up by the projection update behind it on the same stream)
-            fuse_slab_sum_ = tune_.slab_sum_in_update;
+            fuse_slab_sum_ = tune_.slab_sum_in_update && cfg_.world_size <= 1;      // (data parallel: the summed gradient is all-reduced first)
             try { backward_T(aux2_stream_); } catch (...) { fuse_slab_sum_ = false; throw; }
             fuse_slab_sum_ = false;
         }
@@ -1937,7 +1985,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
     const bool untouched_aside = tune_.untouched_aside;
     // (only when side stream 2 is the stream that built the words CSR: the untouched pass reads its row bounds, and the next
     //  step's sort on that stream clears them — a pass queued on any other stream would have neither order)
-    const bool words_aside = untouched_aside && !dp && !words_.lazy && words_csr_stream_ == aux2_stream_ &&
+    const bool words_aside = untouched_aside && !dp && !words_.lazy && words_csr_stream_ == aux2_stream_ && !words_untouched_hoisted_ &&
                              row_pass_split(csr_of(words_, B_ * cfg_.window_size));
     words_untouched_stream_ = words_aside ? aux2_stream_ : nullptr;
     update_words(lr, sl);

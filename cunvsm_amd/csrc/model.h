@@ -183,6 +183,12 @@ class Model {
     void lazy_scalar_snapshot(TableState& t, const Csr& c, hipStream_t s);   // the touched rows' scalar state, before an update's passes
     void lazy_begin_update(TableState& t, RowPassArgs& a, bool scalar_pingpong);
     void lazy_end_update(TableState& t, const Csr& c, hipStream_t s);
+    RowPassArgs final_words_pass_args(float lr, float sl);
+    bool hoist_untouched_ = false;        // step() -> compute_cost: queue the words rows-without-entries decay behind the CSR build
+    float hoist_lr_ = 0.f, hoist_sl_ = 0.f;
+    bool words_untouched_hoisted_ = false;      // ... done for this step's update
+    bool words_untouched_pending_ = false;      // ... and not yet followed by the main stream (the next word gather does)
+    hipEvent_t ev_untouched_ = nullptr;
     void settle_words_stamp();            // the words table's pending stamps, now (see lazy_end_update)
     bool words_stamp_pending_ = false;    // the last words update's stamps have not been set yet
     int64_t words_stamp_n_ = 0;           //   ... entries of that update's CSR

@@ -71,6 +71,7 @@ Tuning Tuning::from_env() {
     t.dt_min_batch = env_int("NVSM_DT_MIN_B", t.dt_min_batch);
     t.docs_delay_us = env_int("NVSM_DOCS_DELAY_US", t.docs_delay_us);
     t.untouched_aside = env_flag("NVSM_UNTOUCHED_ASIDE", t.untouched_aside);
+    t.hoist_untouched = env_int("NVSM_HOIST_UNTOUCHED", t.hoist_untouched);
     t.slab_sum_in_update = env_flag("NVSM_SLAB_SUM_IN_UPDATE", t.slab_sum_in_update);
     t.planes_in_update = env_flag("NVSM_PLANES_IN_UPDATE", t.planes_in_update);
     t.gemm_rsplit = env_flag("NVSM_GEMM_RSPLIT", t.gemm_rsplit);

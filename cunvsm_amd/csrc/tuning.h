@@ -57,6 +57,7 @@ struct Tuning {
     int docs_delay_us = 0;              // NVSM_DOCS_DELAY_US (a spin kernel in front of the documents update on its side stream)
     int dt_min_batch = 40960;           // NVSM_DT_MIN_B (the split-bf16 dT kernel from this batch size up)
     bool untouched_aside = true;        // NVSM_UNTOUCHED_ASIDE
+    int hoist_untouched = 2;           // NVSM_HOIST_UNTOUCHED (fused step: the decay of the words rows without entries behind the CSR build: 0 off, 1 in front of the build's event, 2 behind it)
     bool slab_sum_in_update = true;     // NVSM_SLAB_SUM_IN_UPDATE (fused step: the projection update adds up the dT product's slabs; 0: launch_splitk_reduce)
     bool planes_in_update = true;       // NVSM_PLANES_IN_UPDATE (the projection update writes T's bf16 planes itself; 0: two launches behind it)
     bool gemm_rsplit = true;            // NVSM_GEMM_RSPLIT (the split-bf16 row-panel kernel at per-rank batch sizes; 0: gemm_rows)

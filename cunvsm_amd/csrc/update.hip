@@ -1023,13 +1023,21 @@ void launch_row_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hipSt
     // Table much larger than the batch (at most one entry per row on average): the rows with entries go through the
     // row pass by list, all the others — if the pass is dense — through the streaming pass.
     if (row_pass_split(c) && kind_is_row_local_when_untouched(a.kind)) {
-        if (a.dense && !a.lazy) { if (V == 4) untouched_dispatch<4>(c, a, nvec, untouched_s); else untouched_dispatch<1>(c, a, nvec, untouched_s); }
+        if (a.dense && !a.lazy && !a.untouched_done) { if (V == 4) untouched_dispatch<4>(c, a, nvec, untouched_s); else untouched_dispatch<1>(c, a, nvec, untouched_s); }
         a.touched_only = 1;
         a.shallow = c.rows >= c.n;      // at most one entry per row on average
         cc.rows = c.n < c.rows ? c.n : c.rows;      // upper bound of the list length: sizes the grid
     }
     if (V == 4) { if (a.table == 0) row_pass_dispatch<4, 0>(cc, a, G, nvec, s); else row_pass_dispatch<4, 1>(cc, a, G, nvec, s); }
     else        { if (a.table == 0) row_pass_dispatch<1, 0>(cc, a, G, nvec, s); else row_pass_dispatch<1, 1>(cc, a, G, nvec, s); }
+}
+
+bool launch_untouched_rows(const Csr& c, const RowPassArgs& a, hipStream_t s) {
+    if (c.rows <= 0 || !(row_pass_split(c) && kind_is_row_local_when_untouched(a.kind)) || !a.dense || a.lazy) return false;
+    int V, nvec, G;
+    group_geometry(a, V, nvec, G);
+    if (V == 4) untouched_dispatch<4>(c, a, nvec, s); else untouched_dispatch<1>(c, a, nvec, s);
+    return true;
 }
 
 // NVSM_MERGED_PASS=0 (A/B runs, tests): the three-launch form
@@ -1153,7 +1161,7 @@ int launch_table_pass(const Csr& c, const RowPassArgs& a_in, hipStream_t s, hipS
     a.touched_only = 0; a.shallow = 0;
     int64_t row_items = c.rows;
     if (row_pass_split(c) && kind_is_row_local_when_untouched(a.kind)) {      // as launch_row_pass
-        if (a.dense && !a.lazy) { if (V == 4) untouched_dispatch<4>(c, a, nvec, untouched_s); else untouched_dispatch<1>(c, a, nvec, untouched_s); }
+        if (a.dense && !a.lazy && !a.untouched_done) { if (V == 4) untouched_dispatch<4>(c, a, nvec, untouched_s); else untouched_dispatch<1>(c, a, nvec, untouched_s); }
         a.touched_only = 1;
         a.shallow = c.rows >= c.n;
         row_items = c.n < c.rows ? c.n : c.rows;

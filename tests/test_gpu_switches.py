@@ -31,6 +31,10 @@ elif shape == "large":    # the headline shape's kernels and stream layout: batc
     spec = dict(num_words=3000, num_entities=5000, word_dim=300, entity_dim=256, window=4, num_random=3, nonlinearity="hard_tanh",
                 batch_norm=True, bias_negative_samples=False, update_method="sparse_adam", **{"lambda": 0.01})
     B = 40960
+elif shape == "lazy":     # lazily decayed sparse-Adam tables (NVSM_LAZY_MIN_MB=0 in the environment): snapshots, stamps, pending decay
+    spec = dict(num_words=20000, num_entities=30000, word_dim=64, entity_dim=96, window=5, num_random=4, nonlinearity="hard_tanh",
+                batch_norm=True, bias_negative_samples=False, update_method="sparse_adam", **{"lambda": 0.01})
+    B = 512
 else:                      # batch larger than the tables: dense passes, chunk tree, batch-norm, sparse Adam (NVSM-like)
     spec = dict(num_words=3000, num_entities=5000, word_dim=60, entity_dim=64, window=6, num_random=5, nonlinearity="hard_tanh",
                 batch_norm=True, bias_negative_samples=False, update_method="sparse_adam", **{"lambda": 0.01})
@@ -72,6 +76,15 @@ EXP_VARIANTS = [
     {"NVSM_LOSS_PIPE": "1"},
     {"NVSM_LOSS_PIPE": "0"},
     {"NVSM_STOP_EVENTS": "0", "NVSM_EVENT_FENCE": "0", "NVSM_HOST_PULL": "0", "NVSM_UNTOUCHED_ASIDE": "0"},
+    # round 5: where the lazy tables' bookkeeping launches sit, the decay of the words rows without entries behind the CSR build or
+    # in the update's tail, who cuts T's bf16 planes and who adds up the dT product's slabs
+    {"NVSM_EARLY_SNAPSHOT": "0"},
+    {"NVSM_STAMP_IN_PROLOGUE": "0"},
+    {"NVSM_HOIST_UNTOUCHED": "0"},
+    {"NVSM_HOIST_UNTOUCHED": "0", "NVSM_UNTOUCHED_ASIDE": "0"},
+    {"NVSM_HOIST_UNTOUCHED": "2"},
+    {"NVSM_PLANES_IN_UPDATE": "0", "NVSM_SLAB_SUM_IN_UPDATE": "0"},
+    {"NVSM_EARLY_SNAPSHOT": "0", "NVSM_STAMP_IN_PROLOGUE": "0", "NVSM_HOIST_UNTOUCHED": "0", "NVSM_PLANES_IN_UPDATE": "0", "NVSM_SLAB_SUM_IN_UPDATE": "0"},
 ]
 DBG_LIB = os.path.join(ROOT, "cunvsm_amd", "libcunvsm_amd_dbg.so")
 
@@ -119,14 +132,15 @@ def test_orchestration_switches_do_not_change_results(shape):
 
 
 @pytest.mark.skipif(not os.path.exists(DBG_LIB), reason="experiments build absent (make -C cunvsm_amd/csrc dbg)")
-@pytest.mark.parametrize("shape", ["split", "dense", "large"])
+@pytest.mark.parametrize("shape", ["split", "dense", "large", "lazy"])
 def test_experiment_switches_do_not_change_results(shape):
     """the experiments build reads the A/B switches; they move work between streams and kernels, never the result — and its
     result is the shipped library's"""
     variants = LARGE_EXP_VARIANTS if shape == "large" else EXP_VARIANTS
-    shipped = _run(shape, {})
+    base = {"NVSM_LAZY_MIN_MB": "0"} if shape == "lazy" else {}
+    shipped = _run(shape, base)
     for v in variants:
-        got = _run(shape, dict(v, CUNVSM_AMD_LIB=DBG_LIB))
+        got = _run(shape, dict(v, CUNVSM_AMD_LIB=DBG_LIB, **base))
         assert got == shipped, (shape, v, got, shipped)
 
 
@@ -154,7 +168,7 @@ def test_describe_names_the_kernels_a_step_takes():
     from tests.helpers import gpu_model
     spec = dict(num_words=3000, num_entities=5000, word_dim=300, entity_dim=256, window=4, num_random=3, nonlinearity="hard_tanh",
                 batch_norm=True, bias_negative_samples=False, update_method="sparse_adam", **{"lambda": 0.01})
-    for B, want_dt in ((40960, True), (6400, False)):
+    for B, want_dt in ((51200, True), (40960, True), (6400, False), (4096, False)):
         m = gpu_model(spec, B, sampler=ca.SAMPLER_DEVICE)
         m.initialize(3)
         d = m.describe()
@@ -167,7 +181,12 @@ def test_describe_names_the_kernels_a_step_takes():
         notes = set(m.profile())
         assert ("dt_split_bf16" in notes) == want_dt, (B, notes)
         assert ("dT gemm_dt" in d) == want_dt and ("on the main stream" in d) == want_dt, d
-        assert ("forward gemm_split" in d) == (B > 8192) and ("forward gemm_rows" in d) == (B <= 8192), d
+        # (per-rank batches: the split-bf16 row-panel kernel for both batch-sized products, the batch-norm backward inside the
+        #  backward one; the projection update adds up the dT product's slabs where the product runs on side stream 2)
+        assert ("forward gemm_split" in d) == (B > 8192) and ("forward gemm_rsplit" in d) == (B <= 8192), d
+        assert ("backward gemm_split" in d) == (B > 8192) and ("backward gemm_rsplit" in d) == (B <= 8192), d
+        assert "with the batch-norm backward / bias gradient inside" in d, d
+        assert ("slab_sum_in_update" in notes) == (not want_dt), (B, notes)
         assert "CSR stream layout %d" % (2 if want_dt else 4) in d, d
         assert "loss loss_rows (one row set per wave)" in d, d
     # a documents table beyond the 256 MB Infinity Cache: the loss kernel keeps two sets of rows in flight per wave

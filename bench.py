@@ -121,6 +121,22 @@ PMC_KERNEL = {"loss_fused": "loss_rows_kernel", "row_pass_entities": "table_pass
               "gather_mean_words": "gather_mean_kernel", "adam_u_words": "adam_u_kernel"}
 
 
+# kernel group -> the source file that defines its kernel: a committed PMC summary only speaks for this run's kernel when that
+# file is byte-for-byte what it was when the summary was taken (tools/rocprof_summary.py stores the hashes)
+KERNEL_SOURCE = {"loss_fused": "loss_bn.hip", "row_pass_entities": "update.hip", "row_pass_words_mv": "update.hip",
+                 "row_pass_words_u": "update.hip", "gather_mean_words": "gather_gemm.hip", "adam_u_words": "update.hip"}
+
+
+def source_sha256(name):
+    import hashlib
+    path = os.path.join(ROOT, "cunvsm_amd", "csrc", name)
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
 def workload_signature(wl, method, uniform_words, B):
     """What a PMC summary must have been taken on to say anything about this run's kernels."""
     return "V%d_D%d_dw%d_de%d_w%d_k%d_B%d_%s_%s" % (wl["num_words"], wl["num_entities"], wl["word_dim"], wl["entity_dim"],
@@ -144,6 +160,12 @@ def pmc_traffic(kernel, signature):
             js = json.load(f)
         if js.get("workload") != signature:
             continue
+        # ... and on this kernel: the summary carries the sha256 of every kernel source it was taken with; a summary without
+        # hashes (rounds 1-4) or with another hash for the kernel's file is stale and says nothing about this build
+        src = KERNEL_SOURCE.get(kernel)
+        have = (js.get("source_sha256") or {}).get(src)
+        if not have or have != source_sha256(src):
+            return None, "stale: %s was taken with another %s" % (os.path.basename(path), src)
         for name, e in js["kernels"].items():
             if name.startswith(pref):
                 return int(e["fetch_bytes_corrected"] + e["write_bytes"]), os.path.basename(path)
@@ -185,10 +207,20 @@ def cpu_baseline(args, wl, method):
         dt = time.perf_counter() - t0
         if s >= warm:
             t_total += dt
+    flags = "unknown"
+    try:
+        with open(os.path.join(ROOT, "oracle", "Makefile")) as f:
+            for line in f:
+                if line.startswith("CXXFLAGS"):
+                    flags = line.split("=", 1)[1].strip()
+    except OSError:
+        pass
     return {"value": B * steps / t_total, "unit": "windows/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
+            "compile_flags": flags,
             "sample": "%d full steps (batch %d) of the fp32 OpenMP oracle after %d warm-up, incl. host negative sampling; OpenMP team = "
-                      "the CPUs the process may use (affinity mask capped by the cgroup quota), %d hardware threads visible"
-                      % (steps, B, warm, os.cpu_count() or 0)}
+                      "the CPUs the process may use (affinity mask capped by the cgroup quota), %d hardware threads visible; built with "
+                      "g++ %s (x86-64-v3 = AVX2 + FMA instead of BASELINE.md's -march=native: the .so is built in the CPU container "
+                      "and must run on the GPU box's host)" % (steps, B, warm, os.cpu_count() or 0, flags)}
 
 
 def self_launch(args):
@@ -210,7 +242,7 @@ def self_launch(args):
 class Leg:
     """One engine handle + its pool of synthetic batches: everything a timed region needs."""
 
-    def __init__(self, env, wl, method, B, uniform_words=False, host_batches=False, seed=1234, exact_tables=False):
+    def __init__(self, env, wl, method, B, uniform_words=False, host_batches=False, seed=1234, exact_tables=False, sync_bn=1):
         import cunvsm_amd as ca
         self.env, self.wl, self.method, self.B = env, wl, method, B
         self.uniform_words = uniform_words
@@ -220,7 +252,7 @@ class Leg:
                                 nonlinearity=wl["nonlinearity"], clip_sigmoid=1,
                                 bias_negative_samples=wl["bias_negative_samples"], regularization_lambda=1e-2, update_method=method,
                                 max_batch_size=B, device=env.local_rank, sampler=ca.SAMPLER_DEVICE,
-                                world_size=env.world, rank=env.rank, sync_batch_norm=1,
+                                world_size=env.world, rank=env.rank, sync_batch_norm=sync_bn,
                                 dp_exact_tables=int(bool(exact_tables) and env.world > 1))
         self.model = ca.Model(cfg)
         self.model.initialize(1)                # --seed 1 (scripts/functions.sh:393); identical replicas on every rank
@@ -356,6 +388,55 @@ class Env:
             self.dist.barrier()
 
 
+def update_roofline(leg, env, wl, method, B, uniform_words, steps):
+    """Roofline entry of the documents update — by GPU time the largest kernel of a step (table_pass_kernel at the metric's
+    shape, entry_walk_kernel where the documents table is much larger than the batch): algorithmic bytes; the kernel's time
+    IN the step from an event pair riding on its own launch (a pass with no other records: it runs on side stream 1 next to the
+    words chain of the main stream, so this includes what sharing the memory system costs it) and ALONE (compute_cost /
+    compute_gradients / update as separate calls: nothing runs beside it); the committed counter bytes when the summary was
+    taken on this workload and this update.hip."""
+    kernel = "row_pass_entities"
+    m, lr = leg.model, leg.wl["lr"]
+    desc = m.describe()
+    lazy = "documents lazy decay" in desc
+    rows = {"entities": leg.touched_rows()["entities"]} if lazy else {}
+    ab = algorithmic_bytes(kernel, wl, method, B, rows)
+    out = {"kernel": kernel, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": ab,
+           "table_rows_visited": rows.get("entities", wl["num_entities"]), "decay": "lazy" if lazy else "eager",
+           "bytes": "gather of proj rows B*(k+1)*d_doc*4 + read and write of E and its first moments for every row the pass visits"}
+
+    def timed(run):
+        m.profile_enable(True)
+        m.profile_select(kernel)
+        m.profile_reset()
+        run()
+        env.sync_all(m)
+        pr = m.profile()
+        m.profile_enable(False)
+        walk = "entry_walk" if pr.get("entry_walk_entities", (0, 0))[1] > 0 else "row_walk"
+        return (pr[kernel][0] / pr[kernel][1] if pr.get(kernel, (0, 0))[1] > 0 else None), walk
+
+    in_step, walk = timed(lambda: leg.run_steps(steps))
+
+    def separate():
+        for s_ in range(steps):
+            b = leg.pool[s_ % len(leg.pool)]
+            m.compute_cost(b)
+            m.compute_gradients()
+            m.update(lr)
+    alone, _ = timed(separate)
+    out["walk"] = walk
+    for name, t in (("in_step", in_step), ("alone", alone)):
+        if t:
+            ach = ab / (t * 1e-3) / 1e9
+            out[name] = {"avg_launch_ms": round(t, 4), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
+    if in_step:
+        out["achieved"], out["frac"], out["avg_launch_ms"] = out["in_step"]["achieved"], out["in_step"]["frac"], out["in_step"]["avg_launch_ms"]
+    traffic, src = pmc_traffic(kernel, workload_signature(wl, method, uniform_words, B))
+    out["traffic"], out["traffic_source"], out["traffic_measured_in_run"] = traffic, src, False
+    return out
+
+
 def secondary_leg(env, args, wl, method):
     """One configuration on an engine of its own: ms per step with no events in the timed regions, then the loss kernel's
     in-step time from a pass of its own with events riding on its launch."""
@@ -380,6 +461,8 @@ def secondary_leg(env, args, wl, method):
                            "unit": "GB/s", "frac": round(ab / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg, 4),
                            "algorithmic_bytes_per_launch": ab, "traffic": None,
                            "note": "in-step time of the kernel (events riding on its launch), from a pass of its own behind the timed regions"}
+    if wl["num_entities"] >= 1000000:      # configs[4]: the documents update (entry walk) dominates that step
+        ent["roofline_update"] = update_roofline(leg, env, wl, method, B, args.uniform_words, min(args.steps, 20))
     leg.model.close()
     return ent
 
@@ -395,6 +478,48 @@ def run_secondary_leg(args, flags):
     if r.returncode != 0 or not lines:
         raise SystemExit("secondary leg %s failed: %s" % (flags, r.stderr[-2000:]))
     return json.loads(lines[-1])
+
+
+def cranfield_cli_leg(epochs=12):
+    """cuNVSMTrainModel on tests/golden/cranfield (BASELINE configs[0]): None when the trainer binary or the fixture is absent."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "cunvsm_amd", "bin", "cuNVSMTrainModel")
+    corpus = os.path.join(ROOT, "tests", "golden", "cranfield", "cranfield.trectext")
+    if not (os.path.exists(exe) and os.path.exists(corpus)):
+        return None
+    out = tempfile.mkdtemp(prefix="nvsm_cranfield_")
+    try:
+        cmd = [exe, "--word_repr_size", "128", "--entity_repr_size", "256", "--window_size", "10", "--num_random_entities", "16",
+               "--batch_size", "4096", "--nonlinearity", "tanh", "--bias_negative_samples", "--update_method", "full_adam",
+               "--learning_rate", "0.001", "--num_epochs", str(epochs), "--seed", "1", "--sampler", "device", "--v", "1",
+               "--output", os.path.join(out, "model"), corpus]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        bps = [float(x) for x in re.findall(r"\(([0-9.]+) batches/second\)", r.stderr)]
+        wps = [float(x) for x in re.findall(r"([0-9.eE+]+) n-gram windows/second", r.stderr)]
+        lists = re.findall(r"Epoch #[0-9]+: duration.*?cost=\[(.*?)\]", r.stderr)      # (the trainer logs the cost history so far)
+        costs = [float(x) for x in lists[-1].split(",") if x.strip()] if lists else []
+        ent = {"workload": "LSE on the Cranfield collection (1400 documents), batch 4096, tanh, bias_negative_samples, full_adam, device sampler, "
+                           "through cuNVSMTrainModel: host batches over PCIe, loss of every step read one step late, async prefetch",
+               "epochs": epochs, "wall_s": round(wall, 2)}
+        if bps:
+            ent.update(value=bps[-1], unit="batches/s", note="cumulative batches per second at the end of the last epoch, as the reference's "
+                       "log line reports it (cpp/main.cu:604-611); the first epoch carries the one-off set-up", batches_per_s_by_epoch=bps)
+        if wps:
+            ent["windows_per_s_last_epoch"] = wps[-1]
+        if costs:
+            ent["cost_first_last"] = [costs[0], costs[-1]]
+        return ent
+    except Exception as e:            # noqa: BLE001
+        return {"error": str(e)[:300]}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def ms_stats(times, steps):
@@ -547,6 +672,23 @@ def main():
         prof = model.profile()
     model.profile_enable(False)
     touched = main_leg.touched_rows() if rank == 0 and not args.no_profile else None
+    roofline_update = None
+    dt_alone = None
+    if world == 1 and not args.no_profile and not args.sequential and not args.gate_us:
+        roofline_update = update_roofline(main_leg, env, wl, method, B, args.uniform_words, min(args.steps, 20))
+        # the dT product alone (separate calls on one stream): what a kernel trace reports for it, with nothing racing it for CUs
+        model.profile_enable(True)
+        model.profile_select("gemm_bwd_T")
+        model.profile_reset()
+        for s_ in range(min(args.steps, 20)):
+            model.compute_cost(main_leg.pool[s_ % len(main_leg.pool)])
+            model.compute_gradients()
+            model.update(wl["lr"])
+        env.sync_all(model)
+        pr = model.profile()
+        model.profile_enable(False)
+        if pr.get("gemm_bwd_T", (0, 0))[1] > 0:
+            dt_alone = pr["gemm_bwd_T"][0] / pr["gemm_bwd_T"][1]
 
     def leg_value(leg, batches=None, read_every=0, repeats=None, deferred=False):
         """windows/s and ms per step of a secondary leg: median of `repeats` regions of --steps steps, all ranks' batches"""
@@ -597,6 +739,13 @@ def main():
             if args.config == "nvsm" and Bg == 51200 and method == "sparse_adam":
                 for name in ("large_tables", "lse_small"):
                     secondary[name] = run_secondary_leg(args, ["--config", name])
+            # (f) BASELINE configs[0]: the LSE recipe on the Cranfield collection through the cuNVSMTrainModel CLI (host layer + HIP
+            #     path end to end: index built from the TREC text, batches over PCIe, every step's loss read one step late, async
+            #     prefetch) — batches per second of the last epoch, as the reference's own log line reports it (cpp/main.cu:604-611)
+            if args.config == "nvsm" and Bg == 51200:
+                cf = cranfield_cli_leg()
+                if cf:
+                    secondary["lse_cranfield_cli"] = cf
             if secondary:
                 extra["secondary"] = secondary
             # (e) the per-rank share of the N-GPU metric (51 200 / N windows per rank) on this one GPU, each
@@ -622,6 +771,17 @@ def main():
                            scaling="weak" if headline_strong else "strong", global_batch=total, batch_per_rank=other_B,
                            steps=args.steps, **st)
                 extra["weak" if headline_strong else "strong"] = fig
+                leg.model.close()
+                del leg
+            if strong_ok and wl["batch_norm"]:
+                # the strong split with PER-SHARD batch-norm statistics (nvsm_config.sync_batch_norm = 0: every rank normalises
+                # with the statistics of its own 51 200 / N windows — not the single-GPU arithmetic, one collective less per step)
+                leg = Leg(env, wl, method, Bg // world, uniform_words=args.uniform_words, host_batches=args.host_batches, seed=4321, sync_bn=0)
+                leg.run_steps(2 + max(3, args.warmup))
+                med, st = leg_value(leg)
+                extra["per_shard_batch_norm"] = dict(value=round(Bg * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), scaling="strong",
+                                                     global_batch=Bg, batch_per_rank=Bg // world, steps=args.steps, collectives_per_step=2,
+                                                     note="sync_batch_norm=0: per-shard batch statistics, two collectives per step instead of three", **st)
                 leg.model.close()
                 del leg
             if args.exact_tables_leg and strong_ok:
@@ -673,6 +833,13 @@ def main():
                 ent["timed_by"] = ("events riding on the kernel's launch; avg_ms_no_other_records = the same in a pass with records on "
                                    "this launch only (the product's whole-CU workgroups and the documents pass race for CUs at the same "
                                    "instant: who wins depends on what else is recorded — DESIGN 5.5 item 7)")
+            if k == "gemm_bwd_T" and dt_alone:
+                # the figure to hold against profiles/: rocprofv3's kernel trace dispatches the product a few microseconds before the
+                # documents pass, so it gets its CUs at once and runs as long as it does alone; the in-step event figures above are
+                # outcomes of that race and are kept for the record only
+                ent["in_step_event_ms"] = ent["avg_ms"]
+                ent["avg_ms"] = round(dt_alone, 4)
+                ent["avg_ms_is"] = "the kernel alone (separate calls on one stream, events riding on its launch): agrees with the rocprofv3 kernel trace under profiles/"
             if k.startswith("gemm_") and not k.endswith("_reduce"):
                 # useful (fp32) flops per second. Large batches run the split-bf16 kernels (gemm_split.hip / gemm_dt.hip): every
                 # fp32 operand cut exactly into three bf16 pieces, 6 (or 9) bf16 MFMAs per product, fp32 accumulation — the
@@ -756,6 +923,7 @@ def main():
                        "workload_signature": sig},
             "timing": tstats,
             "roofline": roofline,
+            "roofline_update": roofline_update,
             "roofline_gather": roofline_gather,
             "kernel_breakdown": breakdown,
             "kernel_breakdown_source": ("timed regions" if args.profile_all else
@@ -773,6 +941,32 @@ def main():
             out["strong_projection_8gpu"] = {"value": round(51200 * 1e3 / ms8, 1), "unit": "windows/s",
                                              "speedup_over_1gpu": round(ms_per_step / ms8, 2),
                                              "basis": "per_rank_shapes[6400] on one GPU, collectives excluded"}
+        if world == 1 and not quick:
+            # What a rank of the N-GPU job adds to the per-rank step: the step's collectives, their payloads, and the
+            # latency of each on a 1-rank RCCL communicator of this GPU — the floor a call costs before any wire time (over xGMI a
+            # ring all-reduce of these sizes is latency-bound: 2 (N - 1) hops). Bounds the 8-GPU step from per_rank_shapes.
+            try:
+                import ctypes
+                us = (ctypes.c_float * 3)()
+                nb = (ctypes.c_int64 * 3)()
+                ca._lib.check(ca.lib().nvsm_comm_latency(local_rank, wl["entity_dim"], wl["word_dim"], 200, us, nb))
+                names = ["allreduce f64 [sum x | sum x^2] (forward, batch-norm)", "allreduce f64 [loss | sum dy | sum dy*xhat] (backward)",
+                         "allreduce f32 dT (projection gradient)"]
+                keep = [0, 1, 2] if wl["batch_norm"] else [1, 2]
+                out["config"]["collectives_dp"] = {
+                    "per_step": len(keep), "per_step_per_shard_batch_norm": 2 if wl["batch_norm"] else 2,
+                    "calls": [{"what": names[i], "payload_bytes": int(nb[i]), "rccl_1rank_latency_us": round(float(us[i]), 2)} for i in keep],
+                    "rccl_1rank_latency_us_per_step": round(float(sum(us[i] for i in keep)), 2),
+                    "note": "each call out of place on a 1-rank communicator of this GPU, 200 calls back to back on one stream (RCCL's launch + "
+                            "copy kernel: the floor a collective starts from; an 8-rank ring adds 2 x 7 xGMI hops); sync_batch_norm=0 (per-shard "
+                            "statistics) drops the forward all-reduce"}
+                if "per_rank_shapes" in extra and "6400" in extra["per_rank_shapes"]:
+                    ms8 = extra["per_rank_shapes"]["6400"]["ms_per_step"] + out["config"]["collectives_dp"]["rccl_1rank_latency_us_per_step"] * 1e-3
+                    out["strong_projection_8gpu"]["with_1rank_collective_latency"] = {
+                        "ms_per_step": round(ms8, 4), "speedup_over_1gpu": round(ms_per_step / ms8, 2),
+                        "basis": "per_rank_shapes[6400] + the three collectives at their 1-rank latency (wire time over xGMI not included)"}
+            except Exception as e:            # noqa: BLE001  (no librccl: the line says so instead of failing the bench)
+                out["config"]["collectives_dp"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, wl, method)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -95,6 +95,7 @@ def lib():
         "nvsm_initialize": (C.c_int, [vp, C.c_uint64]), "nvsm_initialize_from_rng_state": (C.c_int, [vp]),
         "nvsm_host_alloc": (C.c_int, [C.c_size_t, P(vp)]), "nvsm_host_free": (C.c_int, [vp]),
         "nvsm_comm_selftest": (C.c_int, [C.c_int]),
+        "nvsm_comm_latency": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float), P(i64)]),
         "nvsm_rng_get_state": (C.c_int, [vp, P(C.c_uint64)]), "nvsm_rng_set_state": (C.c_int, [vp, C.c_uint64]),
         "nvsm_param_size": (C.c_int, [vp, cp, P(i64)]),
         "nvsm_get_param": (C.c_int, [vp, cp, vp, i64]), "nvsm_set_param": (C.c_int, [vp, cp, vp, i64]),

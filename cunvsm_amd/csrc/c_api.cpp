@@ -10,6 +10,7 @@
 namespace cunvsm {
 void rccl_unique_id(char id[128]);
 void rccl_selftest(int device);
+void rccl_latency(int device, int de, int dw, int repeats, float us[3], int64_t bytes[3]);
 void range_push(const char* name);
 void range_pop();
 }
@@ -177,6 +178,10 @@ int nvsm_dp_average_tables(nvsm_model* m) { NVSM_REQUIRE(m); return guarded_on(m
 void nvsm_range_push(const char* name) { if (name) cunvsm::range_push(name); }
 void nvsm_range_pop(void) { cunvsm::range_pop(); }
 int nvsm_comm_selftest(int device) { return guarded_hook([&] { cunvsm::rccl_selftest(device); }); }
+int nvsm_comm_latency(int device, int entity_dim, int word_dim, int repeats, float us[3], int64_t bytes[3]) {
+    NVSM_REQUIRE(us); NVSM_REQUIRE(bytes);
+    return guarded_hook([&] { cunvsm::rccl_latency(device, entity_dim, word_dim, repeats, us, bytes); });
+}
 int nvsm_set_allreduce_callback(nvsm_model* m, nvsm_allreduce_fn fn, void* user) {
     NVSM_REQUIRE(m);
     return guarded_on(m, [&] { m->impl.set_allreduce_callback(fn, user); });

@@ -108,6 +108,48 @@ void rccl_selftest(int device) {
     if (rf != hf || rd != hd) throw Error(NVSM_ERR_DEVICE, "1-rank all-reduce did not return its input (wrong dtype / op enum?)");
 }
 
+// nvsm_comm_latency: the step's three collectives on a 1-rank communicator, timed one kind at a time (HIP events around
+// `repeats` back-to-back calls on a stream of the handle's kind): what a call costs before any wire time
+void rccl_latency(int device, int de, int dw, int repeats, float us[3], int64_t bytes[3]) {
+    if (de <= 0 || dw <= 0 || repeats <= 0) throw Error(NVSM_ERR_INVALID_ARGUMENT, "dimensions and repeats must be positive");
+    RcclApi* api = RcclApi::load();
+    NVSM_HIP_CHECK(hipSetDevice(device));
+    RcclApi::UniqueId u;
+    if (api->GetUniqueId(&u) != 0) throw Error(NVSM_ERR_DEVICE, "ncclGetUniqueId failed");
+    void* comm = nullptr;
+    if (api->CommInitRank(&comm, 1, u, 0) != 0) throw Error(NVSM_ERR_DEVICE, "ncclCommInitRank(1 rank) failed");
+    hipStream_t s;
+    NVSM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    // (out of place: an in-place all-reduce over one rank is a no-op that RCCL returns from without launching anything — 0.02 us;
+    //  out of place it launches its copy kernel, which is the launch + kernel floor a real collective starts from)
+    DevBuf<double> d, d2; DevBuf<float> f, f2;
+    d.alloc(static_cast<size_t>(1 + 2 * de), true); f.alloc(static_cast<size_t>(de) * dw, true);
+    d2.alloc(static_cast<size_t>(1 + 2 * de), true); f2.alloc(static_cast<size_t>(de) * dw, true);
+    hipEvent_t e0, e1;
+    NVSM_HIP_CHECK(hipEventCreate(&e0)); NVSM_HIP_CHECK(hipEventCreate(&e1));
+    const size_t counts[3] = {static_cast<size_t>(2 * de), static_cast<size_t>(1 + 2 * de), static_cast<size_t>(de) * dw};
+    int rc = 0;
+    for (int k = 0; k < 3; ++k) {
+        auto call = [&] {
+            return k < 2 ? api->AllReduce(d.p, d2.p, counts[k], RcclApi::kFloat64, RcclApi::kSum, comm, s)
+                         : api->AllReduce(f.p, f2.p, counts[k], RcclApi::kFloat32, RcclApi::kSum, comm, s);
+        };
+        for (int i = 0; i < 3 && rc == 0; ++i) rc = call();          // (first-use set-up out of the way)
+        NVSM_HIP_CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < repeats && rc == 0; ++i) rc = call();
+        NVSM_HIP_CHECK(hipEventRecord(e1, s));
+        NVSM_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        NVSM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        us[k] = ms * 1e3f / static_cast<float>(repeats);
+        bytes[k] = static_cast<int64_t>(counts[k] * (k < 2 ? sizeof(double) : sizeof(float)));
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    api->CommDestroy(comm);
+    (void)hipStreamDestroy(s);
+    if (rc != 0) throw Error(NVSM_ERR_DEVICE, "ncclAllReduce failed in the latency probe");
+}
+
 void rccl_unique_id(char id[128]) {
     RcclApi* api = RcclApi::load();
     RcclApi::UniqueId u;
@@ -1631,7 +1673,9 @@ void Model::update_entities(float lr, float sl, hipStream_t strm, hipEvent_t row
     a.nt_m = nt_mask() & 1; a.nt_p = (nt_mask() >> 1) & 1;
     if (row_pass_after) NVSM_HIP_CHECK(hipStreamWaitEvent(strm, row_pass_after, 0));
     int path;
-    { PROF_ON("row_pass_entities", strm); path = launch_table_pass(c, a, strm); }
+    // (timed by an event pair that rides on the pass's own launch: the kernel's execution time in the step — bench.py
+    //  roofline_update —, not the side stream's wait for it)
+    timed_launch(prof, "row_pass_entities", strm, /*single=*/true, [&] { path = launch_table_pass(c, a, strm); });
     if (path == TABLE_PASS_ENTRY_WALK) prof.note("entry_walk_entities");
     if (swap_sc) t.sc_cur ^= 1;
     lazy_end_update(t, c, strm);

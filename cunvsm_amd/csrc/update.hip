@@ -1066,9 +1066,14 @@ static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
     if (a.rows_elsewhere) row_blocks = 0;
     if (chunk_blocks + row_blocks < 1) return;
     const dim3 grid(static_cast<unsigned>(chunk_blocks + row_blocks)), block(256);
+    // (NVSM_LAUNCH: a pass the caller times carries the event pair as its own start / stop — not the chunk-only launch in front of
+    //  an entry walk, which leaves them to the walk)
 #define NVSM_TABLE_CASE(K) case K: \
-        if (a.shallow) hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
-        else hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+        if (a.rows_elsewhere) { \
+            if (a.shallow) hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+            else hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+        } else if (a.shallow) NVSM_LAUNCH((table_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+        else NVSM_LAUNCH((table_pass_kernel<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
         break;
     switch (a.kind) {
         NVSM_TABLE_CASE(ROW_SGD)
@@ -1133,8 +1138,8 @@ static void entry_walk_dispatch(const Csr& c, const RowPassArgs& a, int nvec, hi
     if (blocks > 256 * 64) blocks = 256 * 64;
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 #define NVSM_WALK_CASE(K) case K: \
-        if (nvec <= 64) hipLaunchKernelGGL((entry_walk_kernel<V, TABLE, K, 1>), grid, block, 0, s, c, a, nvec, ppw); \
-        else hipLaunchKernelGGL((entry_walk_kernel<V, TABLE, K, 2>), grid, block, 0, s, c, a, nvec, ppw); \
+        if (nvec <= 64) NVSM_LAUNCH((entry_walk_kernel<V, TABLE, K, 1>), grid, block, 0, s, c, a, nvec, ppw); \
+        else NVSM_LAUNCH((entry_walk_kernel<V, TABLE, K, 2>), grid, block, 0, s, c, a, nvec, ppw); \
         break;
     switch (a.kind) {
         NVSM_WALK_CASE(ROW_SGD)

@@ -7,7 +7,7 @@
 //     --document_list resolves docnos through the repository's docno look-up files), or the TREC-text collection file itself, indexed
 //     in memory on start-up (host/trectext_index.hpp).
 //   * only TextEntity::Objective (LSE / NVSM) is accelerated: non-zero --entity_similarity_weight /
-//     --term_similarity_weight and the l2 normalisers are refused with a clear message.
+//     --term_similarity_weight are refused with a clear message (the optional l2 normalisers are supported: untuned).
 //   * extensions: --stopwords, --device, --sampler {host,device}, --allow_ragged_batches, and data parallelism over RCCL
 //     (--gpus N spawns one process per GPU; or --world_size / --rank [or WORLD_SIZE / RANK / LOCAL_RANK] under any launcher).
 #include <sys/stat.h>

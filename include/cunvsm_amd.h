@@ -253,6 +253,12 @@ int nvsm_set_allreduce_callback(nvsm_model* m, nvsm_allreduce_fn fn, void* user)
 /* Single-process check of the RCCL plumbing (dlopen, symbols, enum values, stream use): builds a 1-rank communicator
  * on `device` and all-reduces an f32 and an f64 buffer through the same code path nvsm_step uses with world_size > 1. */
 int nvsm_comm_selftest(int device);
+/* The three collectives of a data-parallel step (all-reduce of [Σx | Σx²]: 2·entity_dim doubles; of [loss | Σdy | Σdy·x̂]:
+ * 1 + 2·entity_dim doubles; of the projection gradient: entity_dim·word_dim floats) on a 1-rank communicator, each on a stream of
+ * its own, `repeats` times back to back: average microseconds per call in us[0..2] and the payload bytes in bytes[0..2] — the
+ * latency floor of each collective on this GPU (what a rank of the N-GPU job pays per step before any wire time), for
+ * bench.py's `--gpus 1` line. */
+int nvsm_comm_latency(int device, int entity_dim, int word_dim, int repeats, float us[3], int64_t bytes[3]);
 
 /* Per-kernel timing of the hot path, measured with HIP events on the handle's stream (bench.py's
  * roofline leg). enable=1 records around every launch of subsequent steps (adds sync points at

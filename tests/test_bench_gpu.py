@@ -63,12 +63,32 @@ def test_bench_single_gpu_line():
     # a busy stream once reported; the figure of a pass with no other records rides along
     dt = d["kernel_breakdown"]["gemm_bwd_T"]
     assert not dt.get("overlapped") and 0.03 < dt["avg_ms"] < 0.26 and 0.03 < dt["avg_ms_no_other_records"] < 0.26
+    # ... and `avg_ms` is the kernel ALONE (what the rocprofv3 kernel trace under profiles/ shows): never longer than the racy in-step figure
+    assert "alone" in dt["avg_ms_is"] and dt["avg_ms"] <= dt["in_step_event_ms"] * 1.15
+    # the documents update — the largest kernel of the step by GPU time — has a roofline entry of its own: algorithmic bytes,
+    # time in the step (next to the words chain) and alone, committed counter bytes (or the reason there are none)
+    ru = d["roofline_update"]
+    assert ru["kernel"] == "row_pass_entities" and ru["bound"] == "hbm" and ru["decay"] == "eager" and ru["walk"] == "row_walk"
+    assert ru["algorithmic_bytes_per_launch"] == 51200 * 17 * 256 * 4 + 4 * 100000 * 256 * 4
+    assert 0.2 < ru["in_step"]["frac"] <= ru["alone"]["frac"] < 1.0 and ru["frac"] == ru["in_step"]["frac"]
+    assert ru["traffic_measured_in_run"] is False and (ru["traffic"] is None or ru["traffic_source"])
+    lu = lt["roofline_update"]
+    assert lu["walk"] == "entry_walk" and lu["decay"] == "lazy" and lu["table_rows_visited"] < 2000000 and 0.2 < lu["in_step"]["frac"] < 1.0
+    # what a rank of the N-GPU job adds per step: three collectives, their payloads and 1-rank RCCL latencies
+    cd = d["config"]["collectives_dp"]
+    assert cd["per_step"] == 3 and [c["payload_bytes"] for c in cd["calls"]] == [2 * 256 * 8, (1 + 2 * 256) * 8, 256 * 300 * 4]
+    assert all(c["rccl_1rank_latency_us"] > 0 for c in cd["calls"])
+    assert d["strong_projection_8gpu"]["with_1rank_collective_latency"]["speedup_over_1gpu"] <= d["strong_projection_8gpu"]["speedup_over_1gpu"]
+    # BASELINE configs[0] through the trainer CLI
+    cf = d["secondary"]["lse_cranfield_cli"]
+    assert cf["unit"] == "batches/s" and cf["value"] > 100 and cf["cost_first_last"][1] < cf["cost_first_last"][0]
     assert "TFLOPs" not in d["kernel_breakdown"]["gemm_bwd_T_reduce"]
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.3 < roof["frac"] < 1.0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "windows/s"
+    assert "-O3" in cb["compile_flags"] and "x86-64-v3" in cb["sample"]
     assert "workload" in d["config"] and "model" not in d["config"]
 
 

@@ -37,7 +37,7 @@ def problem():
     return params, full_batch(rs, weighted=True)
 
 
-@pytest.mark.parametrize("method", ["sparse_adam", "sgd"])
+@pytest.mark.parametrize("method", ["sparse_adam", "sgd", "dense_adam", "full_adam"])
 def test_full_size_step_matches_fp64_oracle(problem, method):
     params, (words, ww, labels, iw, ids) = problem
     spec = dict(SPEC, update_method=method)
@@ -185,3 +185,43 @@ def test_back_to_back_fused_steps_equal_separate_calls(problem):
     for n in PARAMS:
         np.testing.assert_array_equal(a.get_param(n), b.get_param(n))
     assert a.get_cost() == b.get_cost()
+
+
+# ---------------------------------------------------------------------------------------------
+# The per-rank share of the 8-GPU metric: 6 400 windows at the metric's dimensions, through the FUSED nvsm_step (the form the
+# trainer and bench.py's per_rank_shapes run: split-bf16 row-panel products, lazily decayed tables with sparse Adam, the
+# projection update adding up the dT product's slabs) against the fp64 oracle, for all five optimisers: two steps, so that the
+# second one reads what the first one wrote (pending decay, optimiser state, the bf16 planes of the updated projection).
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("method", ["sgd", "adagrad", "sparse_adam", "dense_adam", "full_adam"])
+def test_per_rank_batch_fused_steps_match_fp64_oracle(method):
+    Bp = 6400
+    spec = dict(SPEC, update_method=method)
+    rs = np.random.RandomState(640)
+    params = random_params(spec, rs)
+    params[PARAMS[2]] = (params[PARAMS[2]] * 4).astype(np.float32)
+    o, g = oracle_model(spec, orc.F64), gpu_model(spec, Bp)
+    load_params(o, params, False)
+    load_params(g, params, True)
+    lr = 1e-3
+    for step in range(2):
+        words = zipf_ids(rs, spec["num_words"], Bp * spec["window"])
+        labels = rs.randint(0, spec["num_entities"], Bp).astype(np.int64)
+        ww = rs.uniform(0.5, 1.5, Bp * spec["window"]).astype(np.float32)
+        iw = rs.uniform(0.5, 1.5, Bp).astype(np.float32)
+        ids = rs.randint(0, spec["num_entities"], (Bp, spec["num_random"] + 1)).astype(np.int64)
+        ids[:, 0] = labels
+        ids = ids.ravel()
+        o.forward(words, ww, ids, iw)
+        o.backward()
+        o.update(lr)
+        cg = g.step(ca.Batch(words, labels, ww, iw), lr, entity_ids=ids, want_cost=True)
+        co = o.get_cost()
+        assert abs(co - cg) <= 2e-5 * abs(co), (step, co, cg)
+    tol = 1e-2 if method.endswith("adam") else 5e-4      # (Adam: as test_full_size_step_matches_fp64_oracle, two steps)
+    for name in PARAMS:
+        new_o, new_g, old = o.get(name), g.get_param(name).astype(np.float64), params[name].astype(np.float64)
+        change = np.linalg.norm(new_o - old)
+        assert np.linalg.norm(new_g - new_o) <= tol * change + 1e-7 * np.linalg.norm(old), (name, np.linalg.norm(new_g - new_o), change)
+    d = g.describe(Bp)
+    assert "forward gemm_rsplit" in d and "backward gemm_rsplit" in d, d

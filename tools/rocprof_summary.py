@@ -96,8 +96,13 @@ def pmc(fetch_path, write_path, json_path=None, workload=None):
         import json
         js = {k: {"launches": e[0], "fetch_bytes_corrected": 2 * e[1] * 1024, "write_bytes": e[2] * 1024, "avg_us": e[3] / 1e3}
               for k, e in out.items()}
+        import glob, hashlib, os
+        csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cunvsm_amd", "csrc")
+        hashes = {os.path.basename(p): hashlib.sha256(open(p, "rb").read()).hexdigest() for p in sorted(glob.glob(os.path.join(csrc, "*.hip")))}
         with open(json_path, "w") as f:
             json.dump({"workload": workload,
+                       # bench.py's pmc_traffic() only cites a summary whose kernel source is byte-for-byte this build's
+                       "source_sha256": hashes,
                        "note": "per-launch HBM-side bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); "
                                "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads), "
                                "WRITE_SIZE as reported", "kernels": js}, f, indent=1, sort_keys=True)

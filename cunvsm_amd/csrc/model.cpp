@@ -557,7 +557,10 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
     dt_ok_ = gemm_dt_covers(dw, de, static_cast<int>(B));
     // A batch BELOW max_batch_size can need MORE slabs than the full one (slab lengths round up to whole K tiles: 6 400 rows cut
     // 64 ways are 50 slabs of 128, 6 144 rows are 64 slabs of 96), but never more than asked for: size for that bound.
-    const int slabs = std::max({gemm_slabs_want_, num_cus_ / 2, 1});
+    // (the split-K dT kernel's slabs — up to a slab per two CUs — only where a batch of this handle can take that kernel: a per-rank
+    //  or small-batch handle needs gemm_slabs_want_ slabs, 2-7 MB instead of 39)
+    const bool dt_possible = dt_ok_ && gemm_split_products() != 0 && B >= tune_.dt_min_batch;
+    const int slabs = std::max({gemm_slabs_want_, dt_possible ? std::max(tune_.dt_slabs, num_cus_ / 2) : 0, 1});
     gT_partial_.alloc(static_cast<size_t>(slabs) * de * dw);
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -1827,9 +1830,8 @@ std::string Model::describe(int64_t batch) const {
     const bool fuse = !l2p && B >= 512 && (B <= gemm_rows_max_m() || tune_.split_fuse);
     out += " | backward " + product(1, dw, de, false, need_msq && !l2p, fuse) + (fuse ? " with the batch-norm backward / bias gradient inside" : "");
     // (B_ decides use_dt() / dt_on_main() at run time: evaluated here for `B`)
-    const bool dt = dt_ok_ && gemm_split_products() != 0 && B >= tune_.dt_min_batch;
-    const bool lazy = words_.lazy || ents_.lazy;
-    const bool dt_main = (tune_.dt_on_main >= 0 ? tune_.dt_on_main != 0 : (B >= 40960 && !lazy)) && cfg_.world_size <= 1 && dt;
+    const bool dt = use_dt_at(B);
+    const bool dt_main = dt_on_main_at(B);
     out += std::string(" | dT ") + (dt ? "gemm_dt (3 bf16 planes, split-K)" : "gemm_f32_mfma / gemm_panel split-K (exact fp32 MFMA)") +
            (dt_main ? " on the main stream" : " on side stream 2");
     if (loss_reads_lazily(de, static_cast<int>(R_), cfg_.l2_normalize_entity_reprs != 0))      // (= the row-gathering kernel covers the shape)
@@ -1837,7 +1839,7 @@ std::string Model::describe(int64_t batch) const {
     else out += " | loss loss_kernel (generic)";
     out += std::string(" | tables: words ") + (words_.lazy ? "lazy" : "eager") + " decay, documents " + (ents_.lazy ? "lazy" : "eager") + " decay";
     out += " | CSR stream layout " + std::to_string(tune_.sort_layout >= 0 ? tune_.sort_layout : (dt_main ? 2 : 4));
-    char buf[512];
+    char buf[2048];
     const char* sw = tuning_describe(tune_, buf, sizeof(buf));
     out += std::string(" | switches: ") + (sw[0] ? sw : "defaults");
     return out;
@@ -1855,12 +1857,14 @@ int Model::csr_stream_layout() const {
 // for 18 us alone, exactly as long as the 128 x 128-tiled fp32 kernel takes there, whose small workgroups slip in between the
 // passes' and leave the step shorter: batch 6 400 / 12 800 / 25 600: 0.291 / 0.403 / 0.584 ms tiled against 0.312 / 0.426 /
 // 0.610 (0.340 / 0.438 / 0.593 with this kernel on the main stream). Interleaved A/B, tools/ab_shapes.sh.
-bool Model::use_dt() const { return dt_ok_ && gemm_split_products() != 0 && B_ >= tune_.dt_min_batch; }
+bool Model::use_dt() const { return use_dt_at(B_); }
 
 // the fused step's dT product on the main stream (see step()): large batches of eager tables
-bool Model::dt_on_main() const {
+bool Model::dt_on_main() const { return dt_on_main_at(B_); }
+bool Model::use_dt_at(int64_t B) const { return dt_ok_ && gemm_split_products() != 0 && B >= tune_.dt_min_batch; }
+bool Model::dt_on_main_at(int64_t B) const {      // (one rule for step() and describe())
     const int dt_main_env = tune_.dt_on_main;
-    return (dt_main_env >= 0 ? dt_main_env != 0 : (B_ >= 40960 && !words_.lazy && !ents_.lazy && use_dt())) && cfg_.world_size <= 1;
+    return (dt_main_env >= 0 ? dt_main_env != 0 : (B >= 40960 && !words_.lazy && !ents_.lazy)) && use_dt_at(B) && cfg_.world_size <= 1;
 }
 
 // T changed: its bf16 planes for the next two projection products, behind the writer on the writer's stream (off the critical
@@ -2000,7 +2004,10 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         // Interleaved A/B: NVSM shape 0.931 -> 0.921 ms, full_adam 0.850 -> 0.787; batch 25 600 0.588 -> 0.597 and
         // |D| = 2 M 1.71 -> 1.72 the other way (the main stream is their longer chain): hence the rule. NVSM_DT_ON_MAIN=0 / 1.
         if (dt_on_main()) {
-            backward_T(stream_);
+            // (the slab sum leaves the main stream too: the projection update on side stream 2 adds the slabs up)
+            fuse_slab_sum_ = tune_.slab_sum_in_update && cfg_.world_size <= 1;
+            try { backward_T(stream_); } catch (...) { fuse_slab_sum_ = false; throw; }
+            fuse_slab_sum_ = false;
             NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_));
             NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_gathered_, 0));
         } else {

@@ -271,6 +271,8 @@ class Model {
     GemmSplitWs split_fwd_{}, split_bwd_{};
     void cut_transform_planes(hipStream_t strm);
     bool dt_on_main() const;
+    bool dt_on_main_at(int64_t B) const;
+    bool use_dt_at(int64_t B) const;
     int csr_stream_layout() const;
     int last_csr_layout_ = -1;          // the layout of the previous step's builds (host-batch copies lean on it)
     void alloc_sums(SumsBufs& b, int colgroups, int contrib_cap, int width_cap);

@@ -1,5 +1,5 @@
 // Every switch of the engine in ONE place, read from the environment ONCE per handle (nvsm_create) — never on a launch path.
-//   * the documented switches (INTEGRATION.md §5; each one exercised by a test) are read by every build;
+//   * the documented switches (INTEGRATION.md §6; each one exercised by a test) are read by every build;
 //   * the experiment switches — launch shapes, stream placement, kernel choice: what A/B runs turn — are read only by builds
 //     with -DNVSM_EXPERIMENTS (`make dbg` → libcunvsm_amd_dbg.so); the shipped library runs their defaults, so a stray
 //     variable in a user's environment cannot change what it does.

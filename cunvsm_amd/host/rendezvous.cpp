@@ -17,18 +17,38 @@ namespace nvsm_host {
 namespace {
 
 struct Header {
-    char magic[8];            // "NVSMRCCL"
+    char magic[8];            // "NVSMRCC2"
     uint64_t nonce_hash;
     int64_t created_ns;
     uint32_t pid;
     uint32_t id_bytes;
+    // where `pid` means something: the writer's host and pid namespace. A reader elsewhere (another container or node of an external
+    // launcher that shares the file over a volume) cannot ask whether that pid is alive and does not try.
+    uint64_t host_hash;       // fnv1a(hostname | boot id)
+    uint64_t pidns_inode;     // st_ino of /proc/self/ns/pid (0: unknown)
 };
-const char kMagic[8] = {'N', 'V', 'S', 'M', 'R', 'C', 'C', 'L'};
+const char kMagic[8] = {'N', 'V', 'S', 'M', 'R', 'C', 'C', '2'};
 
 uint64_t fnv1a(const std::string& s) {
     uint64_t h = 1469598103934665603ull;
     for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
     return h;
+}
+
+uint64_t this_host_hash() {
+    char host[256] = {0};
+    (void)::gethostname(host, sizeof(host) - 1);
+    std::string key = host;
+    if (FILE* f = std::fopen("/proc/sys/kernel/random/boot_id", "r")) {
+        char b[64] = {0};
+        if (std::fgets(b, sizeof(b), f)) key += std::string("|") + b;
+        std::fclose(f);
+    }
+    return fnv1a(key);
+}
+uint64_t this_pidns_inode() {
+    struct stat st;
+    return ::stat("/proc/self/ns/pid", &st) == 0 ? static_cast<uint64_t>(st.st_ino) : 0;
 }
 
 bool write_all(int fd, const void* p, size_t n) {
@@ -85,6 +105,7 @@ void rendezvous_publish(const std::string& path, const std::string& nonce, const
     Header h{};
     std::memcpy(h.magic, kMagic, 8);
     h.nonce_hash = fnv1a(nonce); h.created_ns = wall_clock_ns(); h.pid = static_cast<uint32_t>(getpid()); h.id_bytes = kCommIdBytes;
+    h.host_hash = this_host_hash(); h.pidns_inode = this_pidns_inode();
     const bool ok = write_all(fd, &h, sizeof(h)) && write_all(fd, id, kCommIdBytes) && ::fsync(fd) == 0;
     ::close(fd);
     if (!ok || ::rename(tmp.c_str(), path.c_str()) != 0) {
@@ -114,8 +135,13 @@ bool rendezvous_read(const std::string& path, const std::string& nonce, int64_t 
     if (h.created_ns < not_before_ns) return no("is older than this run");
     // The writer (rank 0 of this launch) is alive for as long as anybody may read the file: a file whose writer is gone was left
     // behind by a run that crashed — a relaunch from the same shell within the clock-skew window carries the same fall-back nonce
-    // (parent pid + port), and its ranks would otherwise join a communicator id nobody is waiting on. (Same host: one node.)
-    if (h.pid == 0 || (::kill(static_cast<pid_t>(h.pid), 0) != 0 && errno == ESRCH)) return no("was written by a process that no longer exists (stale)");
+    // (parent pid + port), and its ranks would otherwise join a communicator id nobody is waiting on. The question can only be
+    // asked where the writer's pid means something: on its host, in its pid namespace (the header says which). A reader in
+    // another container / on another node — an external launcher with --comm_id_file on a shared volume — relies on nonce and
+    // creation time alone.
+    const bool same_place = h.host_hash == this_host_hash() && h.pidns_inode != 0 && h.pidns_inode == this_pidns_inode();
+    if (h.pid == 0) return no("carries no writer pid");
+    if (same_place && ::kill(static_cast<pid_t>(h.pid), 0) != 0 && errno == ESRCH) return no("was written by a process that no longer exists (stale)");
     std::memcpy(id, buf, kCommIdBytes);
     return true;
 }

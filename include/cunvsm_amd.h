@@ -212,7 +212,7 @@ int nvsm_set_stream(nvsm_model* m, void* hip_stream);
 int nvsm_synchronize(nvsm_model* m);
 /* One line of text: which kernel each of a step's three projection products takes at `batch` windows on this handle, where the
  * dT product and the CSR builds run, whether the tables decay lazily, and every NVSM_* switch that is off its default (the
- * switches are read from the environment ONCE, by nvsm_create: INTEGRATION.md §5). No reference counterpart. */
+ * switches are read from the environment ONCE, by nvsm_create: INTEGRATION.md §6). No reference counterpart. */
 int nvsm_describe(nvsm_model* m, int64_t batch, char* buf, int64_t buf_bytes);
 
 /* Data parallelism over RCCL / xGMI: one all-reduce of [grad_transform | grad_bias] per

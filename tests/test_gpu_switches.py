@@ -57,7 +57,7 @@ for p in PARAMS:
 print("RESULT " + json.dumps({"params": h.hexdigest(), "costs": [c for c in costs if c is not None]}))
 """
 
-# the DOCUMENTED switches (tuning.h, INTEGRATION.md §5): read by the shipped library, once per handle
+# the DOCUMENTED switches (tuning.h, INTEGRATION.md §6): read by the shipped library, once per handle
 VARIANTS = [
     {},
     {"NVSM_STOP_EVENTS": "0"},
@@ -118,7 +118,8 @@ LARGE_EXP_VARIANTS = [
     # differently — the last bits of the loss, not the kernel's arithmetic)
     {"NVSM_LOSS_PIPE": "1", "NVSM_LOSS_EPW": "20"},
     {"NVSM_LOSS_PIPE": "0"},
-]      # (not NVSM_DT_ON_MAIN: the dT product is cut into 48 slabs on the main stream and 16 on side stream 2 — another summation order)
+]      # (not NVSM_DT_ON_MAIN: on the main stream the split-bf16 product's slabs are added up by launch_splitk_reduce or by the projection
+       #  update in another grouping than the tiled product's on side stream 2 — another summation order)
 
 
 @pytest.mark.parametrize("shape", ["split", "dense", "large"])
@@ -155,7 +156,14 @@ def test_the_shipped_library_ignores_experiment_switches():
         assert r.returncode == 0, r.stderr[-2000:]
         return [l for l in r.stdout.splitlines() if l.startswith("DESC ")][-1]
     assert desc({}).endswith("switches: defaults")
-    assert desc({"NVSM_SPLIT_FUSE": "0", "NVSM_DOCS_ON_MAIN": "1", "NVSM_GEMM_PANEL": "0"}).endswith("switches: defaults")
+    # behaviour, not just the switch list: NVSM_LOSS_PIPE=1 changes the loss kernel's dispatch in the experiments build (which names the
+    # switch) and nothing at all in the shipped library
+    exp = {"NVSM_SPLIT_FUSE": "0", "NVSM_DOCS_ON_MAIN": "1", "NVSM_GEMM_PANEL": "0", "NVSM_LOSS_PIPE": "1"}
+    assert desc(exp) == desc({})
+    if os.path.exists(DBG_LIB):
+        dd = desc(dict(exp, CUNVSM_AMD_LIB=DBG_LIB))
+        assert "two row sets per wave" in dd and "one row set per wave" in desc({}), dd
+        assert "loss_pipe=1" in dd and "docs_on_main=1" in dd and "split_fuse=0" in dd and "(experiments build)" in dd, dd
     d = desc({"NVSM_STOP_EVENTS": "0", "NVSM_GEMM_SPLIT": "9"})
     assert "stop_events=0" in d and "gemm_split=9" in d
 
@@ -182,11 +190,11 @@ def test_describe_names_the_kernels_a_step_takes():
         assert ("dt_split_bf16" in notes) == want_dt, (B, notes)
         assert ("dT gemm_dt" in d) == want_dt and ("on the main stream" in d) == want_dt, d
         # (per-rank batches: the split-bf16 row-panel kernel for both batch-sized products, the batch-norm backward inside the
-        #  backward one; the projection update adds up the dT product's slabs where the product runs on side stream 2)
+        #  backward one; the projection update adds up the dT product's slabs in the fused step: no launch_splitk_reduce)
         assert ("forward gemm_split" in d) == (B > 8192) and ("forward gemm_rsplit" in d) == (B <= 8192), d
         assert ("backward gemm_split" in d) == (B > 8192) and ("backward gemm_rsplit" in d) == (B <= 8192), d
         assert "with the batch-norm backward / bias gradient inside" in d, d
-        assert ("slab_sum_in_update" in notes) == (not want_dt), (B, notes)
+        assert "slab_sum_in_update" in notes and "gemm_bwd_T_reduce" not in notes, (B, notes)
         assert "CSR stream layout %d" % (2 if want_dt else 4) in d, d
         assert "loss loss_rows (one row set per wave)" in d, d
     # a documents table beyond the 256 MB Infinity Cache: the loss kernel keeps two sets of rows in flight per wave

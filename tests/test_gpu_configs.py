@@ -138,7 +138,7 @@ def test_large_tables_rows_evolve_as_compacted_oracle(method, B, steps, word_ids
     elif method == "full_adam":
         assert not walked and not lazy, prof.keys()
 
-    tol = 1e-2 if method.endswith("adam") else 2e-3
+    tol = 6e-3 if method.endswith("adam") else 2e-3      # (three Adam steps: measured 2.9e-3 of the change; the bound was 1e-2 until round 5)
     decay = (1.0 - lr * spec["lambda"] / B) ** steps
     for name, old, used, dim in ((PARAMS[0], W, used_w, dw), (PARAMS[1], E, used_e, de)):
         new_g = g.get_param(name).reshape(-1, dim)

@@ -57,9 +57,9 @@ def test_full_size_step_matches_fp64_oracle(problem, method):
     lr = 1e-3
     o.update(lr)
     g.update(lr)
-    # Adam divides every component by its own sqrt(v): components whose gradient is small (and therefore carries a
-    # larger relative fp32 error) weigh as much as the large ones in the update, hence the looser bound
-    tol = 5e-3 if method.endswith("adam") else 5e-4
+    # (measured, tools/exp/adam_tol.py: the three Adam modes 2.9e-6 … 2.4e-5 of the parameter change, Adagrad ≤ 4.7e-4; for SGD at
+    #  lr = 1e-3 the change itself is of the size of T's fp32 spacing — the second term of the bound. Round 5: the Adam bound was 5e-3.)
+    tol = 2e-4 if method.endswith("adam") else 5e-4
     for name in PARAMS:
         new_o, new_g, old = o.get(name), g.get_param(name).astype(np.float64), params[name].astype(np.float64)
         change = np.linalg.norm(new_o - old)
@@ -218,7 +218,9 @@ def test_per_rank_batch_fused_steps_match_fp64_oracle(method):
         cg = g.step(ca.Batch(words, labels, ww, iw), lr, entity_ids=ids, want_cost=True)
         co = o.get_cost()
         assert abs(co - cg) <= 2e-5 * abs(co), (step, co, cg)
-    tol = 1e-2 if method.endswith("adam") else 5e-4      # (Adam: as test_full_size_step_matches_fp64_oracle, two steps)
+    # (two steps: the second Adam step divides by the sqrt(v) the first one left — components whose gradients are tiny carry their
+    #  relative fp32 error into a full-size update; one step at full size stays below 2.4e-5, test_full_size_step_matches_fp64_oracle)
+    tol = 5e-3 if method.endswith("adam") else 5e-4
     for name in PARAMS:
         new_o, new_g, old = o.get(name), g.get_param(name).astype(np.float64), params[name].astype(np.float64)
         change = np.linalg.norm(new_o - old)

@@ -520,6 +520,15 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
 // index order), so results are bit-identical to the three-launch form. The remaining workgroups are the row pass over
 // the rows of at most kChunk entries, which depend on nothing: they overlap the chunk work instead of queueing behind
 // two kernel boundaries. Counters return to zero (reset by the last arriver) for the next pass.
+// Partials in flight in the final sum of a row of up to kFan level-1 chunks (the same additions in the same order whatever it is).
+// Four at first: a row of 64 chunks then ends in sixteen dependent round trips behind its last chunk; twelve (six trips) is what
+// fits under 128 registers for every kind. Separate processes, interleaved: batch 51 200 0.885 -> 0.879 ms, LSE batch 4 096
+// 0.164 -> 0.160, batch 6 400 0.263 -> 0.265; eight: 0.886 / 0.161 / 0.263; sixteen costs the documents pass a wave per SIMD.
+// (Seven or eight source rows in flight in the chunk walk instead of five, for the same reason: 51 200 +1 %, LSE -1 %: not kept.)
+#ifndef NVSM_ROW_SUM_UNROLL
+#define NVSM_ROW_SUM_UNROLL 12
+#endif
+constexpr int kRowSumUnroll = NVSM_ROW_SUM_UNROLL;
 constexpr int kMaxGroupsPerBlock = 256;      // one-column rows: a thread group is a single thread
 // (Forcing four waves per SIMD — the words passes need 133 registers, five too many — was measured with
 // amdgpu_waves_per_eu: the spills cost more than the occupancy gains, 1.123 against 1.105 ms per step.)
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
             for (int i = 0; i < V; ++i) g[i] = 0.f;
             float q = 0.f;
             if (two_level) sum_partials_agent<V, VEC, 4>(c.partial2, c.partial2_q, c.chunk2_base[row], (nch + kFan - 1) / kFan, dim, col, g, q);
-            else sum_partials_agent<V, VEC, 4>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
+            else sum_partials_agent<V, VEC, kRowSumUnroll>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, true, g, q, p, m, v);
         }
         }

@@ -316,6 +316,7 @@ class Leg:
         env.sync_all(self.model)
         t0 = time.perf_counter()
         self.run_steps(n, batches, read_every, deferred)
+        self.enqueue_s.append(time.perf_counter() - t0)      # the host's share: all n steps queued (the GPU may still be running)
         self.model.synchronize()
         torch.cuda.synchronize()
         if env.dist is not None:
@@ -328,6 +329,7 @@ class Leg:
         return dt
 
     def timed_repeats(self, n, repeats, batches=None, read_every=0, deferred=False):
+        self.enqueue_s = []
         return [self.timed(n, batches, read_every, deferred) for _ in range(max(1, repeats))]
 
     def touched_rows(self):
@@ -345,6 +347,17 @@ class Env:
         self.device = torch.device("cuda", local_rank)
         self.dist = None
         self.keep = []
+        # the submitting thread onto the CPUs of the GPU's NUMA node (nvsm_bind_host_thread: the small-batch legs are ~45 launches
+        # and event calls per 0.15 ms, which the far socket cannot queue as fast as the GPU runs them); the CPU baseline gets the
+        # process's original mask back
+        self.cpu_mask = os.sched_getaffinity(0)
+        self.numa_node = None
+        try:
+            import cunvsm_amd as ca
+            self.numa_node = ca.bind_host_thread(local_rank)
+        except Exception:      # (no library / no GPU: the legs below fail loudly on their own)
+            pass
+        self.cpus_bound = len(os.sched_getaffinity(0))
         if world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -443,7 +456,7 @@ def secondary_leg(env, args, wl, method):
     B = wl["batch"]
     leg = Leg(env, wl, method, B, uniform_words=args.uniform_words)
     leg.run_steps(max(5, args.warmup))
-    med, st = ms_stats(leg.timed_repeats(args.steps, min(args.repeats, 3)), args.steps)
+    med, st = ms_stats(leg.timed_repeats(args.steps, min(args.repeats, 3)), args.steps, leg)
     ent = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), batch=B, update_method=method,
                workload="|V|=%d |D|=%d d_word=%d d_doc=%d" % (wl["num_words"], wl["num_entities"], wl["word_dim"], wl["entity_dim"]), **st)
     kernel = "loss_fused"
@@ -522,11 +535,16 @@ def cranfield_cli_leg(epochs=12):
         shutil.rmtree(out, ignore_errors=True)
 
 
-def ms_stats(times, steps):
+def ms_stats(times, steps, leg=None, enqueue=None):
     ms = sorted(t * 1e3 / steps for t in times)
     med = statistics.median(ms)
-    return med, {"repeats": len(ms), "ms_per_step_all": [round(x, 4) for x in ms],
-                 "spread": round((ms[-1] - ms[0]) / med, 4) if med > 0 else None}
+    st = {"repeats": len(ms), "ms_per_step_all": [round(x, 4) for x in ms],
+          "spread": round((ms[-1] - ms[0]) / med, 4) if med > 0 else None}
+    # how long the HOST took to queue a step (median region): well below ms_per_step = the GPU is the limit, equal = the host is
+    enq = enqueue if enqueue is not None else getattr(leg, "enqueue_s", None)
+    if enq and len(enq) == len(times):
+        st["host_enqueue_ms_per_step"] = round(statistics.median(enq) * 1e3 / steps, 4)
+    return med, st
 
 
 def main():
@@ -644,6 +662,7 @@ def main():
     model.profile_select(None if args.profile_all else ROOFLINE_KERNEL)
     model.profile_reset()
     times = main_leg.timed_repeats(args.steps, args.repeats, None, args.read_cost_every)
+    main_enqueue = list(main_leg.enqueue_s)
     final_cost = model.get_cost()
     prof_timed = model.profile()
     prof = prof_timed
@@ -693,7 +712,7 @@ def main():
     def leg_value(leg, batches=None, read_every=0, repeats=None, deferred=False):
         """windows/s and ms per step of a secondary leg: median of `repeats` regions of --steps steps, all ranks' batches"""
         ts = leg.timed_repeats(args.steps, repeats or min(args.repeats, 3), batches, read_every, deferred)
-        med, st = ms_stats(ts, args.steps)
+        med, st = ms_stats(ts, args.steps, leg)
         return med, st
 
     # ---- secondary legs: no events ----------------------------------------------------------------------------------
@@ -802,7 +821,7 @@ def main():
                 del leg
 
     if rank == 0:
-        ms_per_step, tstats = ms_stats(times, args.steps)
+        ms_per_step, tstats = ms_stats(times, args.steps, enqueue=main_enqueue)
         global_batch = Bg if (headline_strong or world == 1) else Bg * world
         value = global_batch * 1e3 / ms_per_step
         scaling = "single" if world == 1 else ("strong" if headline_strong else "weak")
@@ -925,7 +944,10 @@ def main():
                        # (f64, backward), dT (f32, 307 KB) — DESIGN.md §6
                        "collectives_per_step": 0 if world == 1 else (3 if wl["batch_norm"] else 2),
                        "inputs": "host" if args.host_batches else "hbm", "step": "sequential calls" if args.sequential else "fused nvsm_step",
-                       "workload_signature": sig},
+                       "workload_signature": sig,
+                       "host_thread": {"gpu_numa_node": env.numa_node, "cpus_bound": env.cpus_bound, "cpus_given": len(env.cpu_mask),
+                                       "note": "nvsm_bind_host_thread: the submitting thread on the CPUs of the GPU's NUMA node; "
+                                               "timing.host_enqueue_ms_per_step = the host's time to queue one step"}},
             "timing": tstats,
             "roofline": roofline,
             "roofline_update": roofline_update,
@@ -973,6 +995,7 @@ def main():
             except Exception as e:            # noqa: BLE001  (no librccl: the line says so instead of failing the bench)
                 out["config"]["collectives_dp"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
+            os.sched_setaffinity(0, env.cpu_mask)      # every CPU the process was given, not only the GPU's node
             out["cpu_baseline"] = cpu_baseline(args, wl, method)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         else:

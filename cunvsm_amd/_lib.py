@@ -94,6 +94,7 @@ def lib():
         "nvsm_create": (C.c_int, [P(NvsmConfig), P(vp)]), "nvsm_destroy": (None, [vp]),
         "nvsm_initialize": (C.c_int, [vp, C.c_uint64]), "nvsm_initialize_from_rng_state": (C.c_int, [vp]),
         "nvsm_host_alloc": (C.c_int, [C.c_size_t, P(vp)]), "nvsm_host_free": (C.c_int, [vp]),
+        "nvsm_bind_host_thread": (C.c_int, [C.c_int, P(C.c_int)]),
         "nvsm_comm_selftest": (C.c_int, [C.c_int]),
         "nvsm_comm_latency": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float), P(i64)]),
         "nvsm_rng_get_state": (C.c_int, [vp, P(C.c_uint64)]), "nvsm_rng_set_state": (C.c_int, [vp, C.c_uint64]),
@@ -138,3 +139,10 @@ def check(status):
 
 def device_count():
     return lib().nvsm_device_count()
+
+
+def bind_host_thread(device=0):
+    """nvsm_bind_host_thread: the calling thread onto the CPUs of the device's NUMA node. Returns that node (-1: unknown)."""
+    node = C.c_int(-1)
+    check(lib().nvsm_bind_host_thread(int(device), C.byref(node)))
+    return node.value

@@ -1,7 +1,11 @@
 // extern "C" surface of libcunvsm_amd.so — see include/cunvsm_amd.h. No C++ exception and no abort
 // crosses this boundary: every entry point returns an nvsm_status and records nvsm_last_error().
 #include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <sched.h>
 #include <vector>
 #include <string>
 
@@ -71,6 +75,59 @@ int nvsm_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// "0-63,128-191" -> CPU set (sysfs cpulist format)
+static bool parse_cpulist(const std::string& text, cpu_set_t* set) {
+    CPU_ZERO(set);
+    bool any = false;
+    size_t at = 0;
+    while (at < text.size()) {
+        size_t end = text.find(',', at);
+        if (end == std::string::npos) end = text.size();
+        const std::string item = text.substr(at, end - at);
+        at = end + 1;
+        if (item.empty() || item[0] < '0' || item[0] > '9') continue;
+        char* rest = nullptr;
+        const long lo = std::strtol(item.c_str(), &rest, 10);
+        long hi = lo;
+        if (rest && *rest == '-') hi = std::strtol(rest + 1, nullptr, 10);
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) { if (c >= 0) { CPU_SET(static_cast<int>(c), set); any = true; } }
+    }
+    return any;
+}
+static std::string read_first_line(const std::string& path) {
+    std::string out;
+    if (FILE* f = std::fopen(path.c_str(), "r")) {
+        char buf[4096];
+        if (std::fgets(buf, sizeof(buf), f)) out = buf;
+        std::fclose(f);
+    }
+    while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
+    return out;
+}
+
+int nvsm_bind_host_thread(int device, int* numa_node) {
+    if (numa_node) *numa_node = -1;
+    return guarded([&] {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw Error(NVSM_ERR_NO_DEVICE, "no HIP device visible");
+        if (device < 0 || device >= ndev) throw Error(NVSM_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+        char bus[64] = {0};
+        NVSM_HIP_CHECK(hipDeviceGetPCIBusId(bus, static_cast<int>(sizeof(bus)), device));
+        std::string id(bus);
+        for (char& ch : id) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
+        const std::string dir = "/sys/bus/pci/devices/" + id + "/";
+        const std::string node = read_first_line(dir + "numa_node");
+        if (numa_node && !node.empty()) *numa_node = std::atoi(node.c_str());
+        if (!cunvsm::env_bind_host()) return;
+        cpu_set_t local, now, both;
+        if (!parse_cpulist(read_first_line(dir + "local_cpulist"), &local)) return;      // (no topology information: leave the thread alone)
+        if (sched_getaffinity(0, sizeof(now), &now) != 0) return;
+        CPU_AND(&both, &local, &now);
+        if (CPU_COUNT(&both) == 0) return;                                                // (the caller's mask excludes the node: theirs wins)
+        (void)sched_setaffinity(0, sizeof(both), &both);
+    });
 }
 
 // Defaults of the reference CLI: cpp/main.cu:15-76 + the NVSM recipe of scripts/functions.sh:266,380-399.

@@ -81,6 +81,8 @@ Tuning Tuning::from_env() {
     return t;
 }
 
+bool env_bind_host() { return env_flag("NVSM_BIND_HOST", true); }
+
 const Tuning& tuning() {
     if (tl_tuning) return *tl_tuning;
     static const Tuning process_defaults = Tuning::from_env();

@@ -428,6 +428,12 @@ int run(int argc, char** argv) {
     const int rank = static_cast<int>(FLAGS_rank >= 0 ? FLAGS_rank : env_int("RANK", 0));
     NVSM_CHECK(world_size >= 1 && rank >= 0 && rank < world_size) << "bad --world_size / --rank";
     if (FLAGS_device < 0) FLAGS_device = world_size > 1 ? env_int("LOCAL_RANK", rank) : 0;
+    {
+        // this thread — it queues every launch of every step — and the prefetch thread it starts later, onto the CPUs of the GPU's
+        // NUMA node (include/cunvsm_amd.h nvsm_bind_host_thread; NVSM_BIND_HOST=0: no)
+        int node = -1;
+        if (nvsm_bind_host_thread(static_cast<int>(FLAGS_device), &node) == NVSM_OK) NVSM_VLOG(1) << "GPU " << FLAGS_device << " hangs off NUMA node " << node << ".";
+    }
     // RCCL bootstrap file (rendezvous.hpp): rank 0 removes whatever an earlier run left under the name FIRST THING — before
     // the minutes it spends indexing the collection, and long before any other rank of this run looks for the file
     const int64_t process_start_ns = wall_clock_ns();

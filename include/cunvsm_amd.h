@@ -109,6 +109,15 @@ const char* nvsm_version(void);
 /* number of visible HIP devices (0 ⇒ nvsm_create fails with NVSM_ERR_NO_DEVICE) */
 int nvsm_device_count(void);
 
+/* Bind the CALLING host thread (and the threads it creates afterwards) to the CPUs of the NUMA node the device hangs off
+ * (/sys/bus/pci/devices/<bus id>/local_cpulist, intersected with the thread's present affinity mask; left as it is when the
+ * intersection is empty or the node is unknown). The steps of a small batch are a chain of ~45 launches and event calls per
+ * 0.15 ms: queued from the far socket they take the host LONGER than they take the GPU (LSE recipe, batch 4096, two-socket
+ * host: 0.159 ms per step unbound or on the far node, 0.150 on the device's node). The reference has no counterpart (one
+ * GPU, one thread, cpp/main.cu:623-767); the trainer and bench.py call it once per process, right after choosing the device.
+ * *numa_node (may be null): the device's node, -1 if unknown. NVSM_BIND_HOST=0 in the environment makes it a no-op. */
+int nvsm_bind_host_thread(int device, int* numa_node);
+
 /* Model::Model (cpp/model.cu:95-103) / ~Model */
 int nvsm_create(const nvsm_config* cfg, nvsm_model** out);
 void nvsm_destroy(nvsm_model* m);

@@ -113,6 +113,12 @@ __device__ __forceinline__ double ld_agent_f64(const double* p) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
 #error "grid_sum_ordered orders its hand-over with s_waitcnt vmcnt(0) + relaxed agent-scope atomics: valid on gfx90a / gfx942 / gfx950 only"
 #endif
+// (vectors in flight per thread in the two sums of the last arrivers: a group of 32 members is then two dependent round trips
+//  instead of four — the tail of a kernel that a whole step waits behind; the same additions in the same order)
+#ifndef NVSM_GRID_SUM_IN_FLIGHT
+#define NVSM_GRID_SUM_IN_FLIGHT 16
+#endif
+constexpr int kGridSumInFlight = NVSM_GRID_SUM_IN_FLIGHT;
 template <int THREADS, class Val, class Out>
 __device__ __forceinline__ void grid_sum_ordered(float* part, double* part2, int* arrive, int fan, int n, int me, int total,
                                                  Val val, Out out, int* flag) {
@@ -140,12 +146,12 @@ __device__ __forceinline__ void grid_sum_ordered(float* part, double* part2, int
     const float* gp = part + static_cast<size_t>(grp) * fan * n;
     for (int i = tid; i < n; i += T) {
         double s = 0.0;
-        for (int j0 = 0; j0 < members; j0 += 8) {        // eight members in flight, added in member order
-            float v[8];
+        for (int j0 = 0; j0 < members; j0 += kGridSumInFlight) {        // members in flight, added in member order
+            float v[kGridSumInFlight];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ld_agent1(gp + static_cast<size_t>(min(j0 + u, members - 1)) * n + i);
+            for (int u = 0; u < kGridSumInFlight; ++u) v[u] = ld_agent1(gp + static_cast<size_t>(min(j0 + u, members - 1)) * n + i);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += (j0 + u < members) ? static_cast<double>(v[u]) : 0.0;
+            for (int u = 0; u < kGridSumInFlight; ++u) s += (j0 + u < members) ? static_cast<double>(v[u]) : 0.0;
         }
         if (ngroups == 1) out(i, s); else st_agent_f64(part2 + static_cast<size_t>(grp) * n + i, s);
     }
@@ -164,12 +170,12 @@ __device__ __forceinline__ void grid_sum_ordered(float* part, double* part2, int
     if (!*flag) return;
     for (int i = tid; i < n; i += T) {
         double s = 0.0;
-        for (int g0 = 0; g0 < ngroups; g0 += 8) {
-            double v[8];
+        for (int g0 = 0; g0 < ngroups; g0 += kGridSumInFlight) {
+            double v[kGridSumInFlight];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ld_agent_f64(part2 + static_cast<size_t>(min(g0 + u, ngroups - 1)) * n + i);
+            for (int u = 0; u < kGridSumInFlight; ++u) v[u] = ld_agent_f64(part2 + static_cast<size_t>(min(g0 + u, ngroups - 1)) * n + i);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += (g0 + u < ngroups) ? v[u] : 0.0;
+            for (int u = 0; u < kGridSumInFlight; ++u) s += (g0 + u < ngroups) ? v[u] : 0.0;
         }
         out(i, s);
     }

@@ -116,8 +116,8 @@ def algorithmic_bytes(kernel, wl, method, B, rows=None):
 
 
 # kernel group (engine profiler name) -> rocprofv3 kernel name prefix, for the PMC traffic figures kept under profiles/
-PMC_KERNEL = {"loss_fused": "loss_rows_kernel", "row_pass_entities": "table_pass_kernel<4, 1, 3",
-              "row_pass_words_mv": "table_pass_kernel<4, 0, 2", "row_pass_words_u": "table_pass_kernel<4, 0, 0",
+PMC_KERNEL = {"loss_fused": "loss_rows_kernel", "row_pass_entities": "table_pass_wide_kernel<4, 1, 3",
+              "row_pass_words_mv": "table_pass_wide_kernel<4, 0, 2", "row_pass_words_u": "table_pass_wide_kernel<4, 0, 0",
               "gather_mean_words": "gather_mean_kernel", "adam_u_words": "adam_u_kernel"}
 
 

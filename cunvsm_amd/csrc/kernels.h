@@ -306,6 +306,7 @@ struct RowPassArgs {
     int shallow;               // set by launch_row_pass: two entries in flight per lane instead of eight (rows >= entries)
     int lazy;                  // lazy dense decay (below): rows without entries are NOT visited, their decay stays pending
     int rows_elsewhere;        // set by launch_table_pass: the rows of at most a chunk's entries are done by entry_walk_kernel
+    int wide;                  // this ROW_SGD pass belongs to an Adam update (update.hip: the WIDE family of the one-launch pass)
     int untouched_done;        // the streaming pass over the rows WITHOUT entries of a split dense pass has been queued already (launch_untouched_rows)
     LazyView pending;          // lazy: the row's P (and m, by s_m) first get the factors of the updates (stamp[row], now] the
                                //   row sat out, one by one (pending.stamp null: the rows are current)

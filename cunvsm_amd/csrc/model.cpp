@@ -1763,7 +1763,7 @@ void Model::update_words(float lr, float sl) {
     if (!t.lazy) t.sc_cur ^= 1;
     { PROF("adam_u_words"); launch_adam_u(t.m.p, t.sc[t.sc_cur].p, dw, u.widx, w, u.B, a.bc, a.eps, U_.p, stream_); }
     RowPassArgs r = a;
-    r.kind = ROW_SGD; r.X = U_.p; r.sq_src = nullptr; r.dense = sl > 0.f;
+    r.kind = ROW_SGD; r.X = U_.p; r.sq_src = nullptr; r.dense = sl > 0.f; r.wide = 1;
     r.nt_m = 0; r.nt_p = (nt_mask() >> 3) & 1;
     { PROF("row_pass_words_u"); launch_table_pass(c, r, stream_, words_untouched_stream_); }
     lazy_end_update(t, c, stream_);

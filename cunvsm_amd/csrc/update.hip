@@ -520,20 +520,30 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
 // index order), so results are bit-identical to the three-launch form. The remaining workgroups are the row pass over
 // the rows of at most kChunk entries, which depend on nothing: they overlap the chunk work instead of queueing behind
 // two kernel boundaries. Counters return to zero (reset by the last arriver) for the next pass.
-// Partials in flight in the final sum of a row of up to kFan level-1 chunks (the same additions in the same order whatever it is).
-// Four at first: a row of 64 chunks then ends in sixteen dependent round trips behind its last chunk; twelve (six trips) is what
-// fits under 128 registers for every kind. Separate processes, interleaved: batch 51 200 0.885 -> 0.879 ms, LSE batch 4 096
-// 0.164 -> 0.160, batch 6 400 0.263 -> 0.265; eight: 0.886 / 0.161 / 0.263; sixteen costs the documents pass a wave per SIMD.
-// (Seven or eight source rows in flight in the chunk walk instead of five, for the same reason: 51 200 +1 %, LSE -1 %: not kept.)
-#ifndef NVSM_ROW_SUM_UNROLL
-#define NVSM_ROW_SUM_UNROLL 12
+// Partials in flight in the sums of the chunk tree — the level-2 sum of up to kFan level-1 partials and the final sum of a row
+// of up to kFan chunks (the same additions in the same order whatever the depth) — and the kernel's occupancy. Two families,
+// measured over every bench shape in separate processes (profiles/r05_exp_table_pass_family.txt):
+//   * DEEP (16 / 12 in flight, registers as they come: 110-114, four waves per SIMD) — SGD and Adagrad. Their small-batch steps
+//     (LSE recipe, batch 4 096) end in the hottest row's chain of dependent round trips: four in flight in the final sum were
+//     sixteen trips behind the row's last chunk (LSE 0.164 -> 0.160 ms with twelve; 0.1591 -> 0.1616 back at eight).
+//   * WIDE (8 / 8 in flight, amdgpu_waves_per_eu(5): 85-93 registers, no scratch) — the passes of the Adam modes, whose steps are
+//     the rows of at most a chunk's entries, one thread group each, bounded by how many are in flight: batch 6 400 0.2651 ->
+//     0.2569 ms, 12 800 0.4015 -> 0.399, 25 600 0.5989 -> 0.5766, 51 200 0.8683 -> 0.8668, full_adam 0.7604 -> 0.7579. (The
+//     request on the SGD / Adagrad kinds too: LSE +5 %; on the scalar-only pass: 72 B of scratch, LSE +12 %; eight in flight
+//     without the request: full_adam +1.3 %.)
+// (Seven or eight source rows in flight in the chunk walk instead of five: 51 200 +1 %, LSE -1 %: not kept.)
+constexpr int kL2SumDeep = 16, kRowSumDeep = 12, kL2SumWide = 8, kRowSumWide = 8;
+#ifndef NVSM_TABLE_PASS_WAVES
+#define NVSM_TABLE_PASS_WAVES 5
 #endif
-constexpr int kRowSumUnroll = NVSM_ROW_SUM_UNROLL;
+#if NVSM_TABLE_PASS_WAVES > 0
+#define NVSM_TABLE_PASS_ATTR __attribute__((amdgpu_waves_per_eu(NVSM_TABLE_PASS_WAVES, NVSM_TABLE_PASS_WAVES)))
+#else
+#define NVSM_TABLE_PASS_ATTR
+#endif
 constexpr int kMaxGroupsPerBlock = 256;      // one-column rows: a thread group is a single thread
-// (Forcing four waves per SIMD — the words passes need 133 registers, five too many — was measured with
-// amdgpu_waves_per_eu: the spills cost more than the occupancy gains, 1.123 against 1.105 ms per step.)
-template <int V, int TABLE, int KIND, int UNROLL>
-__global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
+template <int V, int TABLE, int KIND, int UNROLL, int L2SUM, int ROWSUM>
+__device__ __forceinline__ void table_pass_body(const Csr& c, const RowPassArgs& a, int G, int nvec, int chunk_blocks) {
     constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
     __shared__ float hist[kLazyHistory];      // lazy decay: the factor history, out of the kernel arguments (per-lane index)
     if (a.pending.stamp) {
@@ -610,7 +620,7 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
 #pragma unroll
                 for (int i = 0; i < V; ++i) g[i] = 0.f;
                 float q = 0.f;
-                sum_partials_agent<V, VEC, 16>(c.partial, c.partial_q, first, count, dim, col, g, q);
+                sum_partials_agent<V, VEC, L2SUM>(c.partial, c.partial_q, first, count, dim, col, g, q);
                 if (VEC) st_agent<V>(c.partial2 + static_cast<size_t>(slot) * dim + col, g);
                 if (cv == 0) st_agent1(c.partial2_q + slot, q);
             }
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
             for (int i = 0; i < V; ++i) g[i] = 0.f;
             float q = 0.f;
             if (two_level) sum_partials_agent<V, VEC, 4>(c.partial2, c.partial2_q, c.chunk2_base[row], (nch + kFan - 1) / kFan, dim, col, g, q);
-            else sum_partials_agent<V, VEC, kRowSumUnroll>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
+            else sum_partials_agent<V, VEC, ROWSUM>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, true, g, q, p, m, v);
         }
         }
@@ -675,6 +685,15 @@ __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, i
             apply_row_formula<V, KIND>(a, row, cv == 0, off, cnt, touch_p, g, q, p, m, v);
         }
     }
+}
+template <int V, int TABLE, int KIND, int UNROLL>
+__global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
+    table_pass_body<V, TABLE, KIND, UNROLL, kL2SumDeep, kRowSumDeep>(c, a, G, nvec, chunk_blocks);
+}
+// the passes of the Adam modes (RowPassArgs::wide): see above
+template <int V, int TABLE, int KIND, int UNROLL>
+__global__ __launch_bounds__(256) NVSM_TABLE_PASS_ATTR void table_pass_wide_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
+    table_pass_body<V, TABLE, KIND, UNROLL, kL2SumWide, kRowSumWide>(c, a, G, nvec, chunk_blocks);
 }
 
 // ---- rows of a table much larger than the batch: walk the sorted ENTRIES, not a list of rows --------------------------------
@@ -1077,23 +1096,28 @@ static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
     const dim3 grid(static_cast<unsigned>(chunk_blocks + row_blocks)), block(256);
     // (NVSM_LAUNCH: a pass the caller times carries the event pair as its own start / stop — not the chunk-only launch in front of
     //  an entry walk, which leaves them to the walk)
-#define NVSM_TABLE_CASE(K) case K: \
+#define NVSM_TABLE_LAUNCH(KERNEL, K) \
         if (a.rows_elsewhere) { \
-            if (a.shallow) hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
-            else hipLaunchKernelGGL((table_pass_kernel<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
-        } else if (a.shallow) NVSM_LAUNCH((table_pass_kernel<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
-        else NVSM_LAUNCH((table_pass_kernel<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
-        break;
+            if (a.shallow) hipLaunchKernelGGL((KERNEL<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+            else hipLaunchKernelGGL((KERNEL<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+        } else if (a.shallow) NVSM_LAUNCH((KERNEL<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+        else NVSM_LAUNCH((KERNEL<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks);
+#define NVSM_TABLE_CASE(K) case K: NVSM_TABLE_LAUNCH(table_pass_kernel, K) break;
+#define NVSM_TABLE_CASE_WIDE(K) case K: NVSM_TABLE_LAUNCH(table_pass_wide_kernel, K) break;
+    // (ROW_SGD is both: the last pass of sparse Adam's words update and the whole of SGD's)
+    if (a.wide && a.kind == ROW_SGD) { NVSM_TABLE_LAUNCH(table_pass_wide_kernel, ROW_SGD) return; }
     switch (a.kind) {
         NVSM_TABLE_CASE(ROW_SGD)
         NVSM_TABLE_CASE(ROW_ADAGRAD_ENT)
-        NVSM_TABLE_CASE(ROW_ADAM_MV)
-        NVSM_TABLE_CASE(ROW_ADAM_SPARSE_ENT)
-        NVSM_TABLE_CASE(ROW_ADAM_DENSE)
-        NVSM_TABLE_CASE(ROW_ADAM_FULL)
+        NVSM_TABLE_CASE_WIDE(ROW_ADAM_MV)
+        NVSM_TABLE_CASE_WIDE(ROW_ADAM_SPARSE_ENT)
+        NVSM_TABLE_CASE_WIDE(ROW_ADAM_DENSE)
+        NVSM_TABLE_CASE_WIDE(ROW_ADAM_FULL)
         NVSM_TABLE_CASE(ROW_SCALAR_ACC)
         default: break;
     }
+#undef NVSM_TABLE_CASE_WIDE
+#undef NVSM_TABLE_LAUNCH
 #undef NVSM_TABLE_CASE
 }
 

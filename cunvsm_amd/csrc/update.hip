@@ -157,6 +157,16 @@ void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared, int* o
 #define NVSM_SEG_UNROLL_DOCS 5
 #endif
 template <int TABLE> struct SegUnrollDeep { static constexpr int value = TABLE == 0 ? NVSM_SEG_UNROLL_WORDS : NVSM_SEG_UNROLL_DOCS; };
+// ... in the WIDE family of the one-launch table pass (the Adam modes: five waves per SIMD, table_pass_wide_kernel): with a
+// quarter more rows in flight per CU the best depth is lower — w4 d3 against w5 d5: batch 51 200 0.879 -> 0.860 ms, 6 400
+// 0.251 -> 0.249, 25 600 0.563 -> 0.5636, full_adam 0.762 -> 0.757 (w4 d4 / w3 d3 / w2 d4 within 0.5 % of it; six spills)
+#ifndef NVSM_SEG_UNROLL_WIDE_WORDS
+#define NVSM_SEG_UNROLL_WIDE_WORDS 4
+#endif
+#ifndef NVSM_SEG_UNROLL_WIDE_DOCS
+#define NVSM_SEG_UNROLL_WIDE_DOCS 3
+#endif
+template <int TABLE> struct SegUnrollWide { static constexpr int value = TABLE == 0 ? NVSM_SEG_UNROLL_WIDE_WORDS : NVSM_SEG_UNROLL_WIDE_DOCS; };
 // rows of a table much larger than the batch hold one or two entries: two slots in flight per lane leave registers for
 // 2-3x as many rows in flight per CU, which is what bounds that regime (a dependent chain of four loads per row)
 constexpr int kSegUnrollScalar = 16;      // ROW_SCALAR_ACC gathers scalars only: sixteen entries in flight cost a handful of registers
@@ -542,7 +552,7 @@ constexpr int kL2SumDeep = 16, kRowSumDeep = 12, kL2SumWide = 8, kRowSumWide = 8
 #define NVSM_TABLE_PASS_ATTR
 #endif
 constexpr int kMaxGroupsPerBlock = 256;      // one-column rows: a thread group is a single thread
-template <int V, int TABLE, int KIND, int UNROLL, int L2SUM, int ROWSUM>
+template <int V, int TABLE, int KIND, int UNROLL, int L2SUM, int ROWSUM, int CHUNKU>
 __device__ __forceinline__ void table_pass_body(const Csr& c, const RowPassArgs& a, int G, int nvec, int chunk_blocks) {
     constexpr bool VEC = (KIND != ROW_SCALAR_ACC);
     __shared__ float hist[kLazyHistory];      // lazy decay: the factor history, out of the kernel arguments (per-lane index)
@@ -576,7 +586,7 @@ __device__ __forceinline__ void table_pass_body(const Csr& c, const RowPassArgs&
 #pragma unroll
                 for (int i = 0; i < V; ++i) g[i] = 0.f;
                 float q = 0.f;
-                accumulate_segment<V, TABLE, VEC, VEC ? SegUnrollDeep<TABLE>::value : kSegUnrollScalar>(a, c.sorted_entry, begin, end, col, g, q);
+                accumulate_segment<V, TABLE, VEC, VEC ? CHUNKU : kSegUnrollScalar>(a, c.sorted_entry, begin, end, col, g, q);
                 if (VEC) st_agent<V>(c.partial + static_cast<size_t>(ci) * dim + col, g);
                 if (cv == 0) st_agent1(c.partial_q + ci, q);
             }
@@ -688,12 +698,12 @@ __device__ __forceinline__ void table_pass_body(const Csr& c, const RowPassArgs&
 }
 template <int V, int TABLE, int KIND, int UNROLL>
 __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
-    table_pass_body<V, TABLE, KIND, UNROLL, kL2SumDeep, kRowSumDeep>(c, a, G, nvec, chunk_blocks);
+    table_pass_body<V, TABLE, KIND, UNROLL, kL2SumDeep, kRowSumDeep, SegUnrollDeep<TABLE>::value>(c, a, G, nvec, chunk_blocks);
 }
 // the passes of the Adam modes (RowPassArgs::wide): see above
 template <int V, int TABLE, int KIND, int UNROLL>
 __global__ __launch_bounds__(256) NVSM_TABLE_PASS_ATTR void table_pass_wide_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
-    table_pass_body<V, TABLE, KIND, UNROLL, kL2SumWide, kRowSumWide>(c, a, G, nvec, chunk_blocks);
+    table_pass_body<V, TABLE, KIND, UNROLL, kL2SumWide, kRowSumWide, SegUnrollWide<TABLE>::value>(c, a, G, nvec, chunk_blocks);
 }
 
 // ---- rows of a table much larger than the batch: walk the sorted ENTRIES, not a list of rows --------------------------------
@@ -1096,16 +1106,16 @@ static void table_pass_dispatch(const Csr& c, const RowPassArgs& a, int G, int n
     const dim3 grid(static_cast<unsigned>(chunk_blocks + row_blocks)), block(256);
     // (NVSM_LAUNCH: a pass the caller times carries the event pair as its own start / stop — not the chunk-only launch in front of
     //  an entry walk, which leaves them to the walk)
-#define NVSM_TABLE_LAUNCH(KERNEL, K) \
+#define NVSM_TABLE_LAUNCH(KERNEL, K, DEPTH) \
         if (a.rows_elsewhere) { \
             if (a.shallow) hipLaunchKernelGGL((KERNEL<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
-            else hipLaunchKernelGGL((KERNEL<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
+            else hipLaunchKernelGGL((KERNEL<V, TABLE, K, DEPTH<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
         } else if (a.shallow) NVSM_LAUNCH((KERNEL<V, TABLE, K, kSegUnrollShallow>), grid, block, 0, s, c, a, G, nvec, chunk_blocks); \
-        else NVSM_LAUNCH((KERNEL<V, TABLE, K, SegUnrollDeep<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks);
-#define NVSM_TABLE_CASE(K) case K: NVSM_TABLE_LAUNCH(table_pass_kernel, K) break;
-#define NVSM_TABLE_CASE_WIDE(K) case K: NVSM_TABLE_LAUNCH(table_pass_wide_kernel, K) break;
+        else NVSM_LAUNCH((KERNEL<V, TABLE, K, DEPTH<TABLE>::value>), grid, block, 0, s, c, a, G, nvec, chunk_blocks);
+#define NVSM_TABLE_CASE(K) case K: NVSM_TABLE_LAUNCH(table_pass_kernel, K, SegUnrollDeep) break;
+#define NVSM_TABLE_CASE_WIDE(K) case K: NVSM_TABLE_LAUNCH(table_pass_wide_kernel, K, SegUnrollWide) break;
     // (ROW_SGD is both: the last pass of sparse Adam's words update and the whole of SGD's)
-    if (a.wide && a.kind == ROW_SGD) { NVSM_TABLE_LAUNCH(table_pass_wide_kernel, ROW_SGD) return; }
+    if (a.wide && a.kind == ROW_SGD) { NVSM_TABLE_LAUNCH(table_pass_wide_kernel, ROW_SGD, SegUnrollWide) return; }
     switch (a.kind) {
         NVSM_TABLE_CASE(ROW_SGD)
         NVSM_TABLE_CASE(ROW_ADAGRAD_ENT)

@@ -1314,8 +1314,9 @@ void launch_adam_u(const float* m, const float* v, int dim, const int* idx, int 
     const bool vec = dim % 4 == 0;
     const uint32_t nvec = vec ? dim / 4 : dim, total = static_cast<uint32_t>(B * nvec);
     const dim3 grid(stream_grid(total, 256));
-    if (vec) adam_u_dispatch<4>(window_unroll(window), grid, s, m, v, dim, idx, window, total, nvec, bc, eps, U);
-    else adam_u_dispatch<1>(window_unroll(window), grid, s, m, v, dim, idx, window, total, nvec, bc, eps, U);
+    const int wu = window_unroll(window);      // (five / seven in flight instead of the window's ten, as the word gather now does: nothing / +1 %)
+    if (vec) adam_u_dispatch<4>(wu, grid, s, m, v, dim, idx, window, total, nvec, bc, eps, U);
+    else adam_u_dispatch<1>(wu, grid, s, m, v, dim, idx, window, total, nvec, bc, eps, U);
 }
 
 // =============================================================================================

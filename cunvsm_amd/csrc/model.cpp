@@ -559,7 +559,7 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
     // 64 ways are 50 slabs of 128, 6 144 rows are 64 slabs of 96), but never more than asked for: size for that bound.
     // (the split-K dT kernel's slabs — up to a slab per two CUs — only where a batch of this handle can take that kernel: a per-rank
     //  or small-batch handle needs gemm_slabs_want_ slabs, 2-7 MB instead of 39)
-    const bool dt_possible = dt_ok_ && gemm_split_products() != 0 && B >= tune_.dt_min_batch;
+    const bool dt_possible = dt_ok_ && gemm_split_products() != 0 && B >= std::min<int64_t>(tune_.dt_min_batch, kDtMainMinBatch);
     const int slabs = std::max({gemm_slabs_want_, dt_possible ? std::max(tune_.dt_slabs, num_cus_ / 2) : 0, 1});
     gT_partial_.alloc(static_cast<size_t>(slabs) * de * dw);
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1861,10 +1861,16 @@ bool Model::use_dt() const { return use_dt_at(B_); }
 
 // the fused step's dT product on the main stream (see step()): large batches of eager tables
 bool Model::dt_on_main() const { return dt_on_main_at(B_); }
-bool Model::use_dt_at(int64_t B) const { return dt_ok_ && gemm_split_products() != 0 && B >= tune_.dt_min_batch; }
+// (round 5, after the table passes went to five waves per SIMD: with eagerly decayed tables and one rank the main-stream placement
+//  — below — pays from 16 384 windows: 16 384: 0.436 -> 0.428 ms, 20 480: 0.492 -> 0.481, 25 600: 0.564 -> 0.547, 32 768: 0.659 ->
+//  0.640, 40 000: 0.753 -> 0.731; 12 800, whose tables decay lazily: 0.381 -> 0.422. Everything else keeps dt_min_batch.)
+bool Model::use_dt_at(int64_t B) const {
+    const bool early = B >= kDtMainMinBatch && !words_.lazy && !ents_.lazy && cfg_.world_size <= 1 && tune_.dt_on_main != 0;
+    return dt_ok_ && gemm_split_products() != 0 && (B >= tune_.dt_min_batch || early);
+}
 bool Model::dt_on_main_at(int64_t B) const {      // (one rule for step() and describe())
     const int dt_main_env = tune_.dt_on_main;
-    return (dt_main_env >= 0 ? dt_main_env != 0 : (B >= 40960 && !words_.lazy && !ents_.lazy)) && use_dt_at(B) && cfg_.world_size <= 1;
+    return (dt_main_env >= 0 ? dt_main_env != 0 : (B >= kDtMainMinBatch && !words_.lazy && !ents_.lazy)) && use_dt_at(B) && cfg_.world_size <= 1;
 }
 
 // T changed: its bf16 planes for the next two projection products, behind the writer on the writer's stream (off the critical

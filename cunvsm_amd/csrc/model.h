@@ -285,6 +285,7 @@ class Model {
     bool dt_ok_ = false;               // the split-K dT kernel (gemm_dt.hip) covers this model's shapes
     int num_cus_ = 256;
     bool table_decays_lazily(bool documents, int64_t rows, int dim, int64_t max_entries) const;
+    static constexpr int64_t kDtMainMinBatch = 16384;      // eager tables, one rank: the dT product on the split-bf16 kernel, on the main stream, from here
     bool use_dt() const;               // this step's dT product runs on it (else: the exact-fp32 tiled / panel kernels)
 
     bool have_forward_ = false, have_grads_ = false;

@@ -227,3 +227,70 @@ def test_per_rank_batch_fused_steps_match_fp64_oracle(method):
         assert np.linalg.norm(new_g - new_o) <= tol * change + 1e-7 * np.linalg.norm(old), (name, np.linalg.norm(new_g - new_o), change)
     d = g.describe(Bp)
     assert "forward gemm_rsplit" in d and "backward gemm_rsplit" in d, d
+
+
+# ---------------------------------------------------------------------------------------------
+# Batches of 16 384 windows and more with eagerly decayed tables on one rank (round 5): the dT product on the split-bf16 split-K
+# kernel, on the main stream in front of the words update, its slabs added up by the projection update — the shape of the
+# 2-GPU share (25 600). Loss and dense gradients against the fp64 oracle, then six fused steps queued back to back against
+# separate, fully ordered calls, bit for bit.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("method,Bp", [("sparse_adam", 16384), ("full_adam", 25600)])
+def test_mid_batch_dt_on_the_main_stream(method, Bp, monkeypatch):
+    spec = dict(SPEC, update_method=method)
+    rs = np.random.RandomState(Bp)
+    params = random_params(spec, rs)
+    params[PARAMS[2]] = (params[PARAMS[2]] * 4).astype(np.float32)
+    o, a, b = oracle_model(spec, orc.F64), gpu_model(spec, Bp), gpu_model(spec, Bp)
+    monkeypatch.setenv("NVSM_GEMM_SPLIT", "0")      # a twin on the exact-fp32 MFMA kernels (the switch is read when a handle is made)
+    e = gpu_model(spec, Bp)
+    monkeypatch.delenv("NVSM_GEMM_SPLIT")
+    assert "exact fp32" in e.describe(Bp).split("| dT")[1].split("|")[0], e.describe(Bp)
+    d = a.describe(Bp)
+    assert "dT gemm_dt" in d and "on the main stream" in d and "documents eager" in d, d
+    d12 = a.describe(12800)
+    assert "dT gemm_f32_mfma" in d12 and "on side stream 2" in d12, d12      # (below 16 384 windows: the tiled kernel beside the updates)
+    load_params(o, params, False)
+    for m in (a, b, e):
+        load_params(m, params, True)
+    batches = []
+    for _ in range(3):
+        words = zipf_ids(rs, spec["num_words"], Bp * spec["window"])
+        labels = rs.randint(0, spec["num_entities"], Bp).astype(np.int64)
+        ww = rs.uniform(0.5, 1.5, Bp * spec["window"]).astype(np.float32)
+        iw = rs.uniform(0.5, 1.5, Bp).astype(np.float32)
+        ids = rs.randint(0, spec["num_entities"], (Bp, spec["num_random"] + 1)).astype(np.int64)
+        ids[:, 0] = labels
+        batches.append((words, labels, ww, iw, ids.ravel()))
+    words, labels, ww, iw, ids = batches[0]
+    o.forward(words, ww, ids, iw)
+    o.backward()
+    a.compute_cost(ca.Batch(words, labels, ww, iw), ids)
+    a.compute_gradients()
+    co, cg = o.get_cost(), a.get_cost()
+    assert abs(co - cg) <= 2e-5 * abs(co), (co, cg)
+    # (hard_tanh: ONE of the 4 M projected units landing on the other side of its bound — the projections of two fp32 paths differ
+    #  in the seventh digit — switches that unit's derivative between 0 and 1 and moves dT by 1 / sqrt(B · d_e) ≈ 5e-4 of its norm;
+    #  and grad_phrase / grad_bias likewise. tools/exp/dbg_mid.py: five (batch, seed) pairs give 3e-7 … 7e-7 for every dense gradient
+    #  on whichever of the split-bf16 path and the exact-fp32 twin has no such unit against fp64, 5e-4 … 9e-4 on the other, and 3e-7
+    #  for both once T is small enough that nothing saturates. Hence 2e-3 here, against fp64 and against the twin;
+    #  tests/test_gpu_parity.py::test_gemm_dt_split_bf16 holds the product alone to 1e-6.)
+    e.compute_cost(ca.Batch(words, labels, ww, iw), ids)
+    e.compute_gradients()
+    for name, tol in (("grad_transform", 2e-3), ("grad_bias", 2e-3), ("grad_phrase", 2e-3)):
+        x, y, z = a.get_tensor(name), o.get(name), e.get_tensor(name)
+        assert rel_err(x, y) < tol, (name, rel_err(x, y))
+        assert rel_err(x, z) < tol, (name, rel_err(x, z))
+    a.update(1e-3)
+    b.step(ca.Batch(words, labels, ww, iw), 1e-3, entity_ids=ids)
+    for s_ in range(1, 6):
+        words, labels, ww, iw, ids = batches[s_ % 3]
+        b.step(ca.Batch(words, labels, ww, iw), 1e-3, entity_ids=ids)
+    for s_ in range(1, 6):
+        words, labels, ww, iw, ids = batches[s_ % 3]
+        a.compute_cost(ca.Batch(words, labels, ww, iw), ids)
+        a.compute_gradients()
+        a.update(1e-3)
+    for n in PARAMS:
+        np.testing.assert_array_equal(a.get_param(n), b.get_param(n))
+    assert a.get_cost() == b.get_cost()

@@ -1863,7 +1863,7 @@ bool Model::use_dt() const { return use_dt_at(B_); }
 bool Model::dt_on_main() const { return dt_on_main_at(B_); }
 // (round 5, after the table passes went to five waves per SIMD: with eagerly decayed tables and one rank the main-stream placement
 //  — below — pays from 16 384 windows: 16 384: 0.436 -> 0.428 ms, 20 480: 0.492 -> 0.481, 25 600: 0.564 -> 0.547, 32 768: 0.659 ->
-//  0.640, 40 000: 0.753 -> 0.731; 12 800, whose tables decay lazily: 0.381 -> 0.422. Everything else keeps dt_min_batch.)
+//  0.640, 40 000: 0.753 -> 0.731; 12 800: 0.381 -> 0.422 the other way. Lazily decayed tables and data-parallel ranks keep dt_min_batch.)
 bool Model::use_dt_at(int64_t B) const {
     const bool early = B >= kDtMainMinBatch && !words_.lazy && !ents_.lazy && cfg_.world_size <= 1 && tune_.dt_on_main != 0;
     return dt_ok_ && gemm_split_products() != 0 && (B >= tune_.dt_min_batch || early);

@@ -38,6 +38,16 @@ def test_null_arguments_are_status_codes_not_crashes():
 
 
 @pytest.mark.skipif(gpu_available(), reason="checks the no-GPU failure mode")
+def test_bind_host_thread_without_a_device_is_a_status_code():
+    import os
+    before = os.sched_getaffinity(0)
+    with pytest.raises(ca.NvsmError) as e:
+        ca.bind_host_thread(0)
+    assert e.value.status == 5          # NVSM_ERR_NO_DEVICE
+    assert os.sched_getaffinity(0) == before
+
+
+@pytest.mark.skipif(gpu_available(), reason="checks the no-GPU failure mode")
 def test_no_cpu_fallback():
     cfg = ca.default_config(num_words=10, num_entities=10, max_batch_size=8)
     with pytest.raises(ca.NvsmError) as e:

@@ -200,3 +200,40 @@ def test_describe_names_the_kernels_a_step_takes():
     # a documents table beyond the 256 MB Infinity Cache: the loss kernel keeps two sets of rows in flight per wave
     big = gpu_model(dict(spec, num_entities=300000), 2048, sampler=ca.SAMPLER_DEVICE)
     assert "two row sets per wave" in big.describe(), big.describe()
+
+
+@pytest.mark.gpu
+def test_bind_host_thread_narrows_the_mask_to_the_devices_node(monkeypatch):
+    """nvsm_bind_host_thread: afterwards the calling thread may run on a subset of the CPUs it had, all of them in the device's
+    local_cpulist; NVSM_BIND_HOST=0 leaves the mask alone; a bad ordinal is a status code."""
+    before = os.sched_getaffinity(0)
+    try:
+        monkeypatch.setenv("NVSM_BIND_HOST", "0")
+        node0 = ca.bind_host_thread(0)
+        assert os.sched_getaffinity(0) == before
+        monkeypatch.delenv("NVSM_BIND_HOST")
+        node = ca.bind_host_thread(0)
+        assert node == node0
+        after = os.sched_getaffinity(0)
+        assert after and after <= before
+        if node >= 0:
+            import torch
+            bus = torch.cuda.get_device_properties(0).pci_bus_id if hasattr(torch.cuda.get_device_properties(0), "pci_bus_id") else None
+            lists = [p for p in os.listdir("/sys/bus/pci/devices") if os.path.exists("/sys/bus/pci/devices/%s/local_cpulist" % p)]
+            local = set()
+            for dev in lists:
+                try:
+                    if int(open("/sys/bus/pci/devices/%s/numa_node" % dev).read()) != node:
+                        continue
+                    for item in open("/sys/bus/pci/devices/%s/local_cpulist" % dev).read().strip().split(","):
+                        lo, _, hi = item.partition("-")
+                        local |= set(range(int(lo), int(hi or lo) + 1))
+                    break
+                except (OSError, ValueError):
+                    continue
+            if local:
+                assert after <= local, (sorted(after)[:4], sorted(local)[:4])
+        with pytest.raises(ca.NvsmError):
+            ca.bind_host_thread(10 ** 6)
+    finally:
+        os.sched_setaffinity(0, before)

@@ -206,6 +206,7 @@ def test_describe_names_the_kernels_a_step_takes():
 def test_bind_host_thread_narrows_the_mask_to_the_devices_node(monkeypatch):
     """nvsm_bind_host_thread: afterwards the calling thread may run on a subset of the CPUs it had, all of them in the device's
     local_cpulist; NVSM_BIND_HOST=0 leaves the mask alone; a bad ordinal is a status code."""
+    import cunvsm_amd as ca
     before = os.sched_getaffinity(0)
     try:
         monkeypatch.setenv("NVSM_BIND_HOST", "0")

@@ -341,22 +341,13 @@ class Leg:
 class Env:
     """Process-wide state of a run: ranks, device, torch.distributed, the RCCL plumbing of each engine handle."""
 
-    def __init__(self, args, world, rank, local_rank):
+    def __init__(self, args, world, rank, local_rank, host_bind):
         import torch
         self.args, self.world, self.rank, self.local_rank = args, world, rank, local_rank
         self.device = torch.device("cuda", local_rank)
         self.dist = None
         self.keep = []
-        # the submitting thread onto the CPUs of the GPU's NUMA node (nvsm_bind_host_thread: the small-batch legs are ~45 launches
-        # and event calls per 0.15 ms, which the far socket cannot queue as fast as the GPU runs them); the CPU baseline gets the
-        # process's original mask back
-        self.cpu_mask = os.sched_getaffinity(0)
-        self.numa_node = None
-        try:
-            import cunvsm_amd as ca
-            self.numa_node = ca.bind_host_thread(local_rank)
-        except Exception:      # (no library / no GPU: the legs below fail loudly on their own)
-            pass
+        self.cpu_mask, self.numa_node = host_bind["cpu_mask"], host_bind["numa_node"]      # (main(): bound before the HIP runtime came up)
         self.cpus_bound = len(os.sched_getaffinity(0))
         if world > 1:
             import torch.distributed as dist
@@ -616,6 +607,15 @@ def main():
 
     import cunvsm_amd as ca  # noqa: F401  (fails loudly without the HIP library: no CPU fallback)
 
+    # The submitting thread onto the CPUs of the GPU's NUMA node BEFORE anything touches the HIP runtime (nvsm_bind_host_thread finds
+    # the device through sysfs then): the runtime's own threads and host allocations land on that node too. The small-batch legs are
+    # ~45 launches and event calls per 0.15 ms, which the far socket cannot keep up with; the CPU baseline gets the original mask back.
+    host_bind = {"cpu_mask": os.sched_getaffinity(0), "numa_node": None}
+    try:
+        host_bind["numa_node"] = ca.bind_host_thread(0 if args.test_shared_gpu else local_rank)
+    except Exception:      # (no GPU: the check below says so)
+        pass
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if args.test_shared_gpu:
@@ -624,7 +624,7 @@ def main():
         raise SystemExit("--gpus %d but only %d GPU(s) are visible (--test-shared-gpu exercises the N-rank control flow on one)"
                          % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    env = Env(args, world, rank, local_rank)
+    env = Env(args, world, rank, local_rank, host_bind)
     dist = env.dist
 
     wl = workload(args)

@@ -115,6 +115,10 @@ int nvsm_device_count(void);
  * 0.15 ms: queued from the far socket they take the host LONGER than they take the GPU (LSE recipe, batch 4096, two-socket
  * host: 0.159 ms per step unbound or on the far node, 0.150 on the device's node). The reference has no counterpart (one
  * GPU, one thread, cpp/main.cu:623-767); the trainer and bench.py call it once per process, right after choosing the device.
+ * Call it BEFORE the first HIP call of the process where possible: the device is then found through sysfs (the AMD render nodes the
+ * process may open, in order; nvsm_create re-checks the guess against hipDeviceGetPCIBusId and re-binds if it was wrong), and the
+ * runtime's own threads and host allocations land on the device's node as well (LSE: 0.1495 ms in every process against
+ * 0.150-0.162 when bound after the runtime came up). Where sysfs does not identify the device the runtime is asked (and comes up).
  * *numa_node (may be null): the device's node, -1 if unknown. NVSM_BIND_HOST=0 in the environment makes it a no-op. */
 int nvsm_bind_host_thread(int device, int* numa_node);
 

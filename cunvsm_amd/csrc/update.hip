@@ -18,8 +18,13 @@ namespace cunvsm {
 // =============================================================================================
 // CSR construction from the sorted (row key, entry) pairs
 // =============================================================================================
+// (round 5: the chunk ranges of the long rows are reserved here too. A row is long iff the entry a chunk's length in front of its
+//  LAST entry carries the same key — one more load for the lane that closes the row, which then finds the row's first entry by
+//  bisection (rows that long are a few hundred hot words; no documents row at |D| = 2 M) — instead of a launch of its own that read
+//  both bounds of EVERY table row: 141 us on the documents CSR chain at |D| = 2 M, 5-10 us and a launch per table elsewhere.)
 __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* __restrict__ row_begin,
-                                  int* __restrict__ row_end, int* __restrict__ touched, int* __restrict__ num_touched) {
+                                  int* __restrict__ row_end, int* __restrict__ touched, int* __restrict__ num_touched,
+                                  int* __restrict__ chunk_base, int* __restrict__ chunk2_base, int* __restrict__ num_chunks) {
     const int lane = threadIdx.x & 63;
     const uint64_t lt = (1ull << lane) - 1ull;
     // (whole waves iterate together: the touched-row list is appended to with ONE atomic per wave and turn — one per row
@@ -31,7 +36,32 @@ __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* _
         const int k = in ? key[i] : 0;
         const bool head = in && (i == 0 || key[i - 1] != k);
         if (head) row_begin[k] = static_cast<int>(i);
-        if (in && (i == n - 1 || key[i + 1] != k)) row_end[k] = static_cast<int>(i + 1);
+        const bool tail = in && (i == n - 1 || key[i + 1] != k);
+        if (tail) row_end[k] = static_cast<int>(i + 1);
+        // rows of more than kChunk entries that end in this wave's range, one after the other: the whole wave looks for the row's
+        // first entry — 64 probes per round trip, three rounds for 2^18 entries (a lane bisecting on its own was twenty dependent
+        // loads, each of them microseconds next to the loss kernel: the words CSR came 50 us late at batch 51 200)
+        uint64_t long_tails = __ballot(chunk_base && tail && i >= kChunk && key[i - kChunk] == k);
+        while (long_tails) {
+            const int l = __ffsll(static_cast<long long>(long_tails)) - 1;
+            long_tails &= long_tails - 1;
+            const int kk = __builtin_amdgcn_readlane(k, l);
+            const int last = __builtin_amdgcn_readlane(static_cast<int>(i), l);      // (n < 2^31: sort_pairs)
+            int lo = 0, hi = last - kChunk;                              // the first position of key kk lies in [lo, hi]
+            while (lo < hi) {
+                const int64_t span = hi - lo;
+                const int p = lo + static_cast<int>(span * lane / 64);    // lane 0 probes lo
+                const int less = __popcll(__ballot(key[p] < kk));       // the keys are sorted: lanes 0 .. less - 1
+                const int nlo = less == 0 ? lo : lo + static_cast<int>(span * (less - 1) / 64) + 1;
+                const int nhi = less == 64 ? hi : lo + static_cast<int>(span * less / 64);
+                lo = nlo; hi = nhi;
+            }
+            if (lane == l) {
+                const int nch = (last + 1 - lo + kChunk - 1) / kChunk;
+                chunk_base[kk] = atomicAdd(num_chunks, nch);
+                if (nch > kFan) chunk2_base[kk] = atomicAdd(num_chunks + 1, (nch + kFan - 1) / kFan);
+            }
+        }
         if (touched) {                                                   // list order is irrelevant: rows are independent
             const uint64_t heads = __ballot(head);
             if (heads) {
@@ -49,7 +79,8 @@ __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* _
 // parallel (level 1); rows with more than kFan level-1 chunks additionally get level-2 chunks, each the ordered
 // sum of kFan level-1 partials, so that no thread group ever walks more than max(kChunk, kFan) items serially
 // (until a row exceeds kChunk·kFan² entries) and every sum has a fixed order: results are run-to-run deterministic.
-// csr_chunks_kernel only reserves the chunk ranges of the long rows; the descriptors are written by
+// csr_chunks_kernel (large batches) / csr_bounds_kernel itself (small ones: launch_csr_build) reserve the chunk ranges of the long
+// rows; the descriptors are written by
 // csr_chunk_fill_kernel, one thread per entry (a row-serial fill took 94 us for the Zipf head word).
 __global__ void csr_chunks_kernel(const int* __restrict__ row_begin, const int* __restrict__ row_end, int64_t rows,
                                   int* __restrict__ chunk_base, int* __restrict__ chunk2_base, int* __restrict__ num_chunks) {
@@ -116,6 +147,7 @@ __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, co
 // sits on is closed to the backward projection product behind the loss kernel, whose workgroups need a CU's whole register file
 // (173 us there for 65 alone): |V| = 500 k, |D| = 2 M 1.717 -> 1.668 ms (96: 1.675, 48: 1.647, 32: 1.61-1.65, 16: 1.79, 8: 2.19,
 // uncapped: 1.71), batch 6 400 0.298 -> 0.292, LSE 0.168 -> 0.164. NVSM_CSR_GRID_CAP overrides for every table (experiments).
+constexpr int64_t kCsrMergeMaxEntries = 64 * 4096;      // (the batch size from which a table gets a chunk order / an entry walk, too)
 static int csr_grid(int64_t items, bool sparse_table) {
     const int cap_env = tuning().csr_grid_cap;
     const int cap = cap_env >= 0 ? cap_env : (sparse_table ? 64 : 0);
@@ -127,11 +159,17 @@ void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared, int* o
     // row_begin | row_end | num_chunks | num_touched are one allocation (model.cpp), padded so that one fill kernel does it
     const bool sparse = row_pass_split(c);
     if (!counters_cleared) (void)hipMemsetAsync(c.row_begin, 0, sizeof(int) * csr_counter_ints(c.rows), s);
+    // Small batches (a CSR build there is a chain of launch latencies, and a launch the host has to queue: the LSE step is
+    // within 5 % of host-bound): the bounds kernel reserves the long rows' chunks itself — LSE 0.1495 -> 0.1477 ms, batch 6 400
+    // 0.2413 -> 0.2389. Large batches keep the launch of their own: the build is off their critical path, and WITHOUT it the
+    // updates it feeds start earlier and take bandwidth from the main stream (batch 51 200 +0.7 %, |D| = 2 M +0.6 %).
+    const bool reserve_in_bounds = c.n > 0 && c.n < kCsrMergeMaxEntries;
     if (c.n > 0)
         hipLaunchKernelGGL(csr_bounds_kernel, dim3(csr_grid(c.n, sparse)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end,
-                           row_pass_split(c) ? c.touched : nullptr, c.num_touched);
-    hipLaunchKernelGGL(csr_chunks_kernel, dim3(csr_grid(c.rows, sparse)), dim3(256), 0, s, c.row_begin, c.row_end, c.rows,
-                       c.chunk_base, c.chunk2_base, c.num_chunks);
+                           row_pass_split(c) ? c.touched : nullptr, c.num_touched, reserve_in_bounds ? c.chunk_base : nullptr, c.chunk2_base, c.num_chunks);
+    if (!reserve_in_bounds)
+        hipLaunchKernelGGL(csr_chunks_kernel, dim3(csr_grid(c.rows, sparse)), dim3(256), 0, s, c.row_begin, c.row_end, c.rows,
+                           c.chunk_base, c.chunk2_base, c.num_chunks);
     if (c.n > 0)
         hipLaunchKernelGGL(csr_chunk_fill_kernel, dim3(csr_grid(c.n, sparse)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin,
                            c.row_end, c.chunk_base, c.chunk2_base, c.chunk_desc, c.chunk2_desc, c.max_chunks, c.max_chunks2, c.num_chunks,

@@ -137,7 +137,7 @@ static std::string sysfs_device_dir_without_hip(int device) {
     std::sort(nodes.begin(), nodes.end());
     int index = device;
     for (const char* name : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"}) {
-        const char* v = std::getenv(name);
+        const char* v = cunvsm::env_raw(name);
         if (!v || !v[0]) continue;
         std::vector<int> list;
         bool plain = true;

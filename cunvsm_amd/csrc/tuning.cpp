@@ -81,6 +81,7 @@ Tuning Tuning::from_env() {
     return t;
 }
 
+const char* env_raw(const char* name) { return std::getenv(name); }
 bool env_bind_host() { return env_flag("NVSM_BIND_HOST", true); }
 
 const Tuning& tuning() {

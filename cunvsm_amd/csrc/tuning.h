@@ -77,6 +77,7 @@ struct TuningScope {
     TuningScope(const TuningScope&) = delete;
     TuningScope& operator=(const TuningScope&) = delete;
 };
+const char* env_raw(const char* name);      // the value of a variable that is not ours (HIP_VISIBLE_DEVICES, ROCR_VISIBLE_DEVICES: nvsm_bind_host_thread), or null
 bool env_bind_host();      // NVSM_BIND_HOST=0: nvsm_bind_host_thread leaves the calling thread's affinity alone (read per call)
 const char* tuning_describe(const Tuning& t, char* buf, int n);      // "name=value ..." of every switch that differs from its default
 

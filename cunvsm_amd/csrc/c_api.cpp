@@ -183,13 +183,17 @@ static std::string hip_device_dir(int device) {
     return "/sys/bus/pci/devices/" + id + "/";
 }
 // nvsm_create: the runtime is up now — was the guess right?
-static void rebind_if_guessed_wrong(int device) {
+static void rebind_if_guessed_wrong(int device) noexcept {
     if (!tl_bound_by_guess) return;
     tl_bound_by_guess = false;
-    char a[PATH_MAX], b[PATH_MAX];
-    const std::string exact = hip_device_dir(device);
-    if (realpath(exact.c_str(), a) && realpath(tl_guessed_dir.c_str(), b) && std::string(a) == std::string(b)) return;
-    (void)bind_to_device_dir(exact, tl_mask_before, nullptr);
+    try {      // (best effort: a handle that has just been made is not given up over the thread's affinity)
+        char a[PATH_MAX], b[PATH_MAX];
+        const std::string exact = hip_device_dir(device);
+        if (realpath(exact.c_str(), a) && realpath(tl_guessed_dir.c_str(), b) && std::string(a) == std::string(b)) return;
+        (void)bind_to_device_dir(exact, tl_mask_before, nullptr);
+    } catch (...) {
+        (void)hipGetLastError();
+    }
 }
 
 int nvsm_bind_host_thread(int device, int* numa_node) {

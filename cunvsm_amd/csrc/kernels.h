@@ -257,7 +257,8 @@ struct Csr {
     int max_chunks, max_chunks2;
 };
 constexpr int kChunk = 64;    // entries per level-1 chunk of a long row
-constexpr int kFan = 64;      // level-1 partials per level-2 chunk
+constexpr int kFan = 32;      // level-1 partials per level-2 chunk (64 until round 5: a row of 33-64 chunks then ended in one sum of up to 64 partials;
+                              //   32 / 128: batch 51 200 and 6 400 the same / +0.4 %, +1.2 %, LSE batch 4 096 0.1473 -> 0.1456 ms / the same)
 
 // bounds + long-row chunk list, from sorted_key; counters_cleared: row_begin | row_end | num_chunks | num_touched (one
 // allocation of csr_counter_ints(rows) ints) are already zero (sort_pairs cleared them), otherwise a memset does it

@@ -255,8 +255,11 @@ struct Csr {
     int64_t n;            // entries
     int64_t rows;
     int max_chunks, max_chunks2;
+    int chunk;            // entries per level-1 chunk of a long row this step: kChunk, or kChunkSmall (Model::chunk_entries)
 };
 constexpr int kChunk = 64;    // entries per level-1 chunk of a long row
+constexpr int kChunkSmall = 32;       // (48 / 20 / 16: LSE 0.1533 / 0.1506 / 0.1534 ms against 0.1503; 64: 0.1568)      // ... for the small batches of SGD / Adagrad handles (Model::chunk_entries)
+constexpr int64_t kChunkSmallMaxEntries = 131072;
 constexpr int kFan = 32;      // level-1 partials per level-2 chunk (64 until round 5: a row of 33-64 chunks then ended in one sum of up to 64 partials;
                               //   32 / 128: batch 51 200 and 6 400 the same / +0.4 %, +1.2 %, LSE batch 4 096 0.1473 -> 0.1456 ms / the same)
 

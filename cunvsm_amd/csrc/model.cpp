@@ -366,8 +366,14 @@ void Model::alloc_table(TableState& t, int64_t rows, int dim, int64_t max_entrie
         if (mode == NVSM_ADAM_DENSE_UPDATE_DENSE_VARIANCE) t.vfull.alloc(rows * dim, true);
         else { t.sc[0].alloc(rows, true); t.sc[1].alloc(rows, true); }
     }
-    t.max_chunks = static_cast<int>(2 * max_entries / kChunk + 2);
-    t.max_chunks2 = static_cast<int>(2 * max_entries / (static_cast<int64_t>(kChunk) * kFan) + 2);
+    // (a long row of c entries has at most c / chunk + 1 chunks and there are fewer than n / chunk long rows: at most 2 n / chunk
+    //  chunks; SGD / Adagrad handles cut the long rows of their small batches into shorter chunks — chunk_entries())
+    {
+        int64_t c1 = 2 * max_entries / kChunk;
+        if (method != NVSM_ADAM && dim <= 128) c1 = std::max<int64_t>(c1, 2 * std::min<int64_t>(max_entries, kChunkSmallMaxEntries) / kChunkSmall);
+        t.max_chunks = static_cast<int>(c1 + 2);
+        t.max_chunks2 = static_cast<int>(c1 / kFan + 2);
+    }
     for (int k = 0; k < t.idx_sets; ++k) {
         TableState::CsrIndex& x = t.idx[k];
         x.sorted_key.alloc(max_entries); x.sorted_entry.alloc(max_entries);
@@ -1505,6 +1511,15 @@ float Model::adam_bc(uint64_t t) const {
     return static_cast<float>(std::sqrt(1.0 - std::pow(b2, static_cast<double>(t))) / (1.0 - std::pow(b1, static_cast<double>(t))));
 }
 
+// Entries per level-1 chunk of a long row. The small-batch steps of SGD and Adagrad on NARROW rows (the LSE recipe: batch 4 096,
+// 128-wide word rows, eight thread groups to a workgroup) end in the hottest row's chain of dependent round trips — a 64-entry chunk
+// walked five entries at a time is thirteen of them —: chunks of 32 there, LSE 0.1562 -> 0.1504 ms. Not where a workgroup holds three
+// rows' groups (300-wide rows: twice the chunks are nearly twice the chunk workgroups next to the other pass — Adagrad at batch
+// 6 400 0.2384 -> 0.2457, the Adam modes +1...4 %) and not for large batches (the passes are bytes there).
+int Model::chunk_entries(const TableState& t, int64_t n) const {
+    return (cfg_.update_method != NVSM_ADAM && n <= kChunkSmallMaxEntries && t.dim <= 128) ? kChunkSmall : kChunk;
+}
+
 Csr Model::csr_of(TableState& t, int64_t n) {
     Csr c{};
     TableState::CsrIndex& x = t.idx[t.idx_cur];
@@ -1517,6 +1532,7 @@ Csr Model::csr_of(TableState& t, int64_t n) {
     c.partial2 = t.partial2.p; c.partial2_q = t.partial2_q.p;
     c.arrive_row = t.arrive_row.p; c.arrive2 = t.arrive2.p;
     c.n = n; c.rows = t.rows; c.max_chunks = t.max_chunks; c.max_chunks2 = t.max_chunks2;
+    c.chunk = chunk_entries(t, n);
     return c;
 }
 

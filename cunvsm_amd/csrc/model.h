@@ -286,6 +286,7 @@ class Model {
     int num_cus_ = 256;
     bool table_decays_lazily(bool documents, int64_t rows, int dim, int64_t max_entries) const;
     static constexpr int64_t kDtMainMinBatch = 16384;      // eager tables, one rank: the dT product on the split-bf16 kernel, on the main stream, from here
+    int chunk_entries(const TableState& t, int64_t n) const;      // entries per level-1 chunk of a long row for a batch of n entries of table t
     bool use_dt() const;               // this step's dT product runs on it (else: the exact-fp32 tiled / panel kernels)
 
     bool have_forward_ = false, have_grads_ = false;

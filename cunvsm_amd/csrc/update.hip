@@ -24,7 +24,7 @@ namespace cunvsm {
 //  both bounds of EVERY table row: 141 us on the documents CSR chain at |D| = 2 M, 5-10 us and a launch per table elsewhere.)
 __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* __restrict__ row_begin,
                                   int* __restrict__ row_end, int* __restrict__ touched, int* __restrict__ num_touched,
-                                  int* __restrict__ chunk_base, int* __restrict__ chunk2_base, int* __restrict__ num_chunks) {
+                                  int* __restrict__ chunk_base, int* __restrict__ chunk2_base, int* __restrict__ num_chunks, int chunk) {
     const int lane = threadIdx.x & 63;
     const uint64_t lt = (1ull << lane) - 1ull;
     // (whole waves iterate together: the touched-row list is appended to with ONE atomic per wave and turn — one per row
@@ -41,13 +41,13 @@ __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* _
         // rows of more than kChunk entries that end in this wave's range, one after the other: the whole wave looks for the row's
         // first entry — 64 probes per round trip, three rounds for 2^18 entries (a lane bisecting on its own was twenty dependent
         // loads, each of them microseconds next to the loss kernel: the words CSR came 50 us late at batch 51 200)
-        uint64_t long_tails = __ballot(chunk_base && tail && i >= kChunk && key[i - kChunk] == k);
+        uint64_t long_tails = __ballot(chunk_base && tail && i >= chunk && key[i - chunk] == k);
         while (long_tails) {
             const int l = __ffsll(static_cast<long long>(long_tails)) - 1;
             long_tails &= long_tails - 1;
             const int kk = __builtin_amdgcn_readlane(k, l);
             const int last = __builtin_amdgcn_readlane(static_cast<int>(i), l);      // (n < 2^31: sort_pairs)
-            int lo = 0, hi = last - kChunk;                              // the first position of key kk lies in [lo, hi]
+            int lo = 0, hi = last - chunk;                               // the first position of key kk lies in [lo, hi]
             while (lo < hi) {
                 const int64_t span = hi - lo;
                 const int p = lo + static_cast<int>(span * lane / 64);    // lane 0 probes lo
@@ -57,7 +57,7 @@ __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* _
                 lo = nlo; hi = nhi;
             }
             if (lane == l) {
-                const int nch = (last + 1 - lo + kChunk - 1) / kChunk;
+                const int nch = (last + 1 - lo + chunk - 1) / chunk;
                 chunk_base[kk] = atomicAdd(num_chunks, nch);
                 if (nch > kFan) chunk2_base[kk] = atomicAdd(num_chunks + 1, (nch + kFan - 1) / kFan);
             }
@@ -83,12 +83,12 @@ __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* _
 // rows; the descriptors are written by
 // csr_chunk_fill_kernel, one thread per entry (a row-serial fill took 94 us for the Zipf head word).
 __global__ void csr_chunks_kernel(const int* __restrict__ row_begin, const int* __restrict__ row_end, int64_t rows,
-                                  int* __restrict__ chunk_base, int* __restrict__ chunk2_base, int* __restrict__ num_chunks) {
+                                  int* __restrict__ chunk_base, int* __restrict__ chunk2_base, int* __restrict__ num_chunks, int chunk) {
     for (int64_t r = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; r < rows;
          r += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int cnt = row_end[r] - row_begin[r];
-        if (cnt > kChunk) {
-            const int nch = (cnt + kChunk - 1) / kChunk;
+        if (cnt > chunk) {
+            const int nch = (cnt + chunk - 1) / chunk;
             chunk_base[r] = atomicAdd(num_chunks, nch);
             if (nch > kFan) chunk2_base[r] = atomicAdd(num_chunks + 1, (nch + kFan - 1) / kFan);
         }
@@ -99,7 +99,7 @@ __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, co
                                       const int* __restrict__ row_end, const int* __restrict__ chunk_base,
                                       const int* __restrict__ chunk2_base, int* __restrict__ chunk_desc,
                                       int* __restrict__ chunk2_desc, int max_chunks, int max_chunks2, const int* __restrict__ num_chunks,
-                                      const int* __restrict__ sorted_entry, int* __restrict__ order_key) {
+                                      const int* __restrict__ sorted_entry, int* __restrict__ order_key, int chunk) {
     // no row of more than kChunk entries this step (the documents table, most steps): nothing to describe — the kernel would
     // otherwise read three words per entry to find that out (27 us next to the loss kernel for 870 k entries)
     if (num_chunks[0] == 0) return;
@@ -115,14 +115,14 @@ __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, co
         const int b = row_begin[r], e = row_end[r];
         const int cnt = e - b;
         const int rel = static_cast<int>(i) - b;
-        if (cnt <= kChunk || rel % kChunk != 0) continue;
-        const int c = rel / kChunk;                       // this entry opens level-1 chunk c of row r
-        const int nch = (cnt + kChunk - 1) / kChunk;
+        if (cnt <= chunk || rel % chunk != 0) continue;
+        const int c = rel / chunk;                        // this entry opens level-1 chunk c of row r
+        const int nch = (cnt + chunk - 1) / chunk;
         const int base = chunk_base[r];
         if (base + c < max_chunks) {
             chunk_desc[(base + c) * 3 + 0] = r;
             chunk_desc[(base + c) * 3 + 1] = static_cast<int>(i);
-            chunk_desc[(base + c) * 3 + 2] = min(e, static_cast<int>(i) + kChunk);
+            chunk_desc[(base + c) * 3 + 2] = min(e, static_cast<int>(i) + chunk);
             if (order_key) {
                 const uint64_t first = static_cast<uint32_t>(sorted_entry[i]);
                 order_key[base + c] = static_cast<int>(min<uint64_t>(511, first * 512 / static_cast<uint64_t>(n)));
@@ -166,14 +166,14 @@ void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared, int* o
     const bool reserve_in_bounds = c.n > 0 && c.n < kCsrMergeMaxEntries;
     if (c.n > 0)
         hipLaunchKernelGGL(csr_bounds_kernel, dim3(csr_grid(c.n, sparse)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end,
-                           row_pass_split(c) ? c.touched : nullptr, c.num_touched, reserve_in_bounds ? c.chunk_base : nullptr, c.chunk2_base, c.num_chunks);
+                           row_pass_split(c) ? c.touched : nullptr, c.num_touched, reserve_in_bounds ? c.chunk_base : nullptr, c.chunk2_base, c.num_chunks, c.chunk);
     if (!reserve_in_bounds)
         hipLaunchKernelGGL(csr_chunks_kernel, dim3(csr_grid(c.rows, sparse)), dim3(256), 0, s, c.row_begin, c.row_end, c.rows,
-                           c.chunk_base, c.chunk2_base, c.num_chunks);
+                           c.chunk_base, c.chunk2_base, c.num_chunks, c.chunk);
     if (c.n > 0)
         hipLaunchKernelGGL(csr_chunk_fill_kernel, dim3(csr_grid(c.n, sparse)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin,
                            c.row_end, c.chunk_base, c.chunk2_base, c.chunk_desc, c.chunk2_desc, c.max_chunks, c.max_chunks2, c.num_chunks,
-                           c.sorted_entry, c.chunk_order ? order_key : nullptr);
+                           c.sorted_entry, c.chunk_order ? order_key : nullptr, c.chunk);
 }
 
 // =============================================================================================
@@ -548,8 +548,8 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
 #pragma unroll
             for (int i = 0; i < V; ++i) g[i] = 0.f;
             float q = 0.f;
-            if (cnt > kChunk) {            // long row: ordered sum of its chunk partials
-                const int nch = (cnt + kChunk - 1) / kChunk;
+            if (cnt > c.chunk) {           // long row: ordered sum of its chunk partials
+                const int nch = (cnt + c.chunk - 1) / c.chunk;
                 if (nch > kFan) sum_partials<V, VEC, 4>(c.partial2, c.partial2_q, c.chunk2_base[row], (nch + kFan - 1) / kFan, dim, col, g, q);
                 else sum_partials<V, VEC, 4>(c.partial, c.partial_q, c.chunk_base[row], nch, dim, col, g, q);
             } else if (cnt > 0) {
@@ -616,7 +616,7 @@ __device__ __forceinline__ void table_pass_body(const Csr& c, const RowPassArgs&
         if (active) {
             row = c.chunk_desc[ci * 3 + 0];
             const int begin = c.chunk_desc[ci * 3 + 1], end = c.chunk_desc[ci * 3 + 2];
-            nch = (c.row_end[row] - c.row_begin[row] + kChunk - 1) / kChunk;
+            nch = (c.row_end[row] - c.row_begin[row] + c.chunk - 1) / c.chunk;
             c_in_row = ci - c.chunk_base[row];
             for (int cv = lig; cv < nvec; cv += G) {
                 const int col = cv * V;
@@ -716,7 +716,7 @@ __device__ __forceinline__ void table_pass_body(const Csr& c, const RowPassArgs&
         const int64_t row = a.touched_only ? static_cast<int64_t>(c.touched[r]) : r;
         const int begin = c.row_begin[row], end = c.row_end[row];
         const int cnt = end - begin;
-        if (cnt > kChunk || (cnt == 0 && !a.dense)) continue;
+        if (cnt > c.chunk || (cnt == 0 && !a.dense)) continue;
         const bool p_always = (a.decay != 1.f) || KIND == ROW_ADAM_FULL || KIND == ROW_ADAM_DENSE;
         const bool touch_p = p_always || cnt != 0;
         for (int cv = lig; cv < nvec; cv += G) {
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void entry_walk_kernel(Csr c, RowPassArgs a, i
                 cnt2 = __popcll(__ballot(key2 == row));
             }
             const int cnt = cnt1 + cnt2;
-            if (cnt > kChunk) continue;                                                  // chunk tree (table_pass_kernel)
+            if (cnt > c.chunk) continue;                                                 // chunk tree (table_pass_kernel)
             const float sc_old = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_mine), h));
             float p[NT][V], m[NT][V], v[NT][V], g[NT][V];
 #pragma unroll

@@ -581,6 +581,10 @@ __global__ __launch_bounds__(256) void row_pass_kernel(Csr c, RowPassArgs a, int
 //     without the request: full_adam +1.3 %.)
 // (Seven or eight source rows in flight in the chunk walk instead of five: 51 200 +1 %, LSE -1 %: not kept.)
 constexpr int kL2SumDeep = 16, kRowSumDeep = 12, kL2SumWide = 8, kRowSumWide = 8;
+// source rows in flight per lane in the DEEP family's walk of a level-1 chunk (its rows keep SegUnrollDeep): seven — 113-120 registers,
+// still four waves per SIMD — against five: Adagrad batch 6 400 0.2388 -> 0.2172 ms, 51 200 0.7635 -> 0.7456, SGD batch 6 400 0.2029
+// -> 0.1992, LSE 0.1503 -> 0.1496; six: about the same; eight: 129 registers, three waves, LSE +8 %
+template <int TABLE> constexpr int kDeepChunkWalk = 7;
 #ifndef NVSM_TABLE_PASS_WAVES
 #define NVSM_TABLE_PASS_WAVES 5
 #endif
@@ -736,7 +740,7 @@ __device__ __forceinline__ void table_pass_body(const Csr& c, const RowPassArgs&
 }
 template <int V, int TABLE, int KIND, int UNROLL>
 __global__ __launch_bounds__(256) void table_pass_kernel(Csr c, RowPassArgs a, int G, int nvec, int chunk_blocks) {
-    table_pass_body<V, TABLE, KIND, UNROLL, kL2SumDeep, kRowSumDeep, SegUnrollDeep<TABLE>::value>(c, a, G, nvec, chunk_blocks);
+    table_pass_body<V, TABLE, KIND, UNROLL, kL2SumDeep, kRowSumDeep, kDeepChunkWalk<TABLE>>(c, a, G, nvec, chunk_blocks);
 }
 // the passes of the Adam modes (RowPassArgs::wide): see above
 template <int V, int TABLE, int KIND, int UNROLL>

@@ -207,8 +207,12 @@ template <int TABLE> struct SegUnrollDeep { static constexpr int value = TABLE =
 template <int TABLE> struct SegUnrollWide { static constexpr int value = TABLE == 0 ? NVSM_SEG_UNROLL_WIDE_WORDS : NVSM_SEG_UNROLL_WIDE_DOCS; };
 // rows of a table much larger than the batch hold one or two entries: two slots in flight per lane leave registers for
 // 2-3x as many rows in flight per CU, which is what bounds that regime (a dependent chain of four loads per row)
-constexpr int kSegUnrollScalar = 16;      // ROW_SCALAR_ACC gathers scalars only: sixteen entries in flight cost a handful of registers
-constexpr int kSegUnrollShallow = 4;      // (2 at first; A/B over 2-4: LSE batch 4096 0.197 -> 0.193 ms, |D| = 2 M unchanged)
+// ROW_SCALAR_ACC (the accumulator pass of Adagrad's words update) gathers scalars only. Sixteen entries in flight at first ("a handful
+// of registers") — but the kernel is compiled for it at 114 registers, four waves per SIMD, where four in flight give 74 and six
+// waves, and the pass is a few thousand short rows bounded by how many are in flight: LSE batch 4 096 0.1480 -> 0.1412 ms (8: 0.1426,
+// 6: 0.142, 3: 0.137 / 2: 0.1385 against 0.135 on another box), Adagrad at batch 51 200 0.751 -> 0.726
+constexpr int kSegUnrollScalar = 4;
+constexpr int kSegUnrollShallow = 3;      // (2 at first; round 2: 4 — LSE batch 4096 0.197 -> 0.193 ms —; round 5, after the families: 3 — LSE 0.1493 -> 0.148, 0.1429 -> 0.1406 on another box, |D| = 2 M -0.6 %, batch 6 400 / 9 600 unchanged; 5 / 6: LSE +1 / +4 %)
 
 template <int V, int TABLE, bool VEC, int kSegUnroll = SegUnrollDeep<TABLE>::value>
 __device__ __forceinline__ void accumulate_segment(const RowPassArgs& a, const int* __restrict__ sorted_entry,
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(256) void entry_walk_kernel(Csr c, RowPassArgs a, i
 // row and its registers are sized for the 8-deep gather (3 waves per SIMD): 3 TB/s at |D| = 2M. This pass streams
 // them instead — one (row, 16 B column group) item per thread, four independent items in flight per thread, few
 // registers — and leaves the rows that do have entries to the row pass (launched on Csr::touched only).
-constexpr int kUntouchedUnroll = 4;
+constexpr int kUntouchedUnroll = 4;      // (2: the same; 8: LSE +4 %)
 template <int V, int KIND>
 __global__ __launch_bounds__(256) void untouched_rows_kernel(Csr c, RowPassArgs a, uint32_t nvec, uint64_t total) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;

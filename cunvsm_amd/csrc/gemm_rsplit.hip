@@ -57,6 +57,26 @@ struct RsArgs {
     float* dump;
 };
 
+// GATH: the panel of A is not read but MADE — the word gather-mean of the forward pass (gather_gemm.hip gather_mean_kernel,
+// cpp/params.cu:75-95) rides on the staging: a thread that would have fetched float4 c4 of phrase row r fetches that float4 of
+// the window's word rows instead (the 32 windows' ids and weights first, into LDS; then five rows in flight per float4), adds them
+// up in the gather kernel's order — acc = fma(w_j, x_j, acc) for j ascending, then acc / window — and writes the result to
+// `phrase` on the way (the dT product reads it later). Same bits as the gather kernel's, one launch, one gap and a 2 x B x K x 4
+// byte round trip through memory less on the step's critical stream. GATH 2: the words table decays lazily (kernels.h LazyView).
+constexpr int kRsGatherU = 5;                  // rows in flight per float4 of the panel
+constexpr int kRsGatherMaxWindow = 32;
+struct RsNoGather { };
+struct RsGather {
+    const float* table; const int* idx; const float* wts; int window; float* phrase;
+};
+struct RsGatherLazy {
+    const float* table; const int* idx; const float* wts; int window; float* phrase;
+    LazyView lazy;
+};
+template <int GATH> struct RsGatherArgs { typedef RsNoGather type; };
+template <> struct RsGatherArgs<1> { typedef RsGather type; };
+template <> struct RsGatherArgs<2> { typedef RsGatherLazy type; };
+
 // a - b as ONE v_sub_f32 (see gemm_split.hip split_sub: packed fp32 VALU is slow next to MFMAs)
 __device__ __forceinline__ float rs_sub(float a, float b) {
     float r;
@@ -89,8 +109,8 @@ __device__ __forceinline__ int rs_slot(int ks, int lane) { return lane ^ (((ks &
 struct RsFrag { u32x4 h, m, l; };
 
 // RCH: float4s of the panel a thread holds at once while staging (the panel is 32 x 4 KSP float4s over 64 WAVES threads)
-template <bool PRE, int WAVES, int RCH, int NPROD>
-__global__ __launch_bounds__(64 * WAVES) void gemm_rsplit_kernel(RsArgs g) {
+template <bool PRE, int WAVES, int RCH, int NPROD, int GATH = 0>
+__global__ __launch_bounds__(64 * WAVES) void gemm_rsplit_kernel(RsArgs g, typename RsGatherArgs<GATH>::type ga) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
     constexpr int T = 64 * WAVES;
     constexpr int NP = 32 * WAVES;                              // columns covered by the waves' tiles (>= N)
@@ -106,6 +126,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_rsplit_kernel(RsArgs g) {
     float* red = reinterpret_cast<float*>(rs_lds + img_bytes);  // [WAVES][32] or [2][NP]
     float* consts = red + 2 * NP;                               // PRE: [4][K] μ, invσ, dβ, dγ
     int* flag = reinterpret_cast<int*>(consts + (PRE ? 4 * g.K : 0));
+    // GATH: [32 x window] ids | weights | (lazy) stamps | (lazy) the factor history
+    int* gid = flag + 4;
 
     // ---- this wave's fragments of B for the first two k steps: requested before anything else ----
     const bool has_tile = wid < g.NT;
@@ -134,7 +156,98 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_rsplit_kernel(RsArgs g) {
         for (int k = tid; k < g.K; k += T) g.grad_bias[k] = static_cast<float>(g.bn_sums[k]);
 
     // ---- stage the panel: 32 rows x 4 KSP float4s (zeros past K and past M), RCH per thread at a time ----
-    {
+    if constexpr (GATH != 0) {
+        const int window = ga.window;
+        const int nid = SM * window;
+        float* gwt = reinterpret_cast<float*>(gid + nid);
+        int* gst = reinterpret_cast<int*>(gwt + nid);
+        float* hist = reinterpret_cast<float*>(gst + nid);
+        // the 32 windows' ids and weights (rows past M: row 0 with weight 0 — loaded, never stored)
+        for (int i = tid; i < nid; i += T) {
+            const int r = i / window;
+            const bool ok = m0 + r < g.M;
+            const size_t at = static_cast<size_t>(m0) * window + i;
+            gid[i] = ok ? ga.idx[at] : 0;
+            gwt[i] = ok ? (ga.wts ? ga.wts[at] : 1.f) : 0.f;
+        }
+        if constexpr (GATH == 2)
+            for (int i = tid; i < kLazyHistory; i += T) hist[i] = ga.lazy.decay[i];
+        __syncthreads();
+        const int C4 = 4 * KSP, K4 = g.K >> 2;
+        const int total = SM * C4;
+        const float fw = static_cast<float>(window);
+        for (int base = 0; base < total; base += T * RCH) {
+            int row[RCH], c4[RCH]; bool in[RCH];
+            float acc[RCH][4];
+#pragma unroll
+            for (int u = 0; u < RCH; ++u) {
+                const int idx = base + tid + T * u;
+                row[u] = idx / C4; c4[u] = idx - row[u] * C4;
+                in[u] = idx < total && c4[u] < K4 && m0 + row[u] < g.M;
+                if (!(idx < total)) row[u] = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[u][e] = 0.f;
+            }
+            for (int j0 = 0; j0 < window; j0 += kRsGatherU) {
+                u32x4 x[RCH][kRsGatherU];
+#pragma unroll
+                for (int u = 0; u < RCH; ++u) {
+#pragma unroll
+                    for (int v = 0; v < kRsGatherU; ++v) {
+                        const int j = min(j0 + v, window - 1);          // (past the window: a harmless re-read, not added)
+                        const int id = gid[row[u] * window + j];
+                        const size_t off = in[u] ? static_cast<size_t>(id) * g.lda + 4 * c4[u] : 0;
+                        x[u][v] = *reinterpret_cast<const u32x4*>(ga.table + off);
+                    }
+                }
+                if constexpr (GATH == 2) {
+                    if (base == 0 && j0 == 0) {      // the stamps of the windows' rows: requested behind the first round of rows, needed in front of the first sum
+                        for (int i = tid; i < nid; i += T) gst[i] = ga.lazy.stamp[gid[i]];
+                        __syncthreads();
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < RCH; ++u) {
+#pragma unroll
+                    for (int v = 0; v < kRsGatherU; ++v) {
+                        if (j0 + v < window) {
+                            const int at = row[u] * window + j0 + v;
+                            float xf[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xf[e] = __uint_as_float(x[u][v][e]);
+                            if constexpr (GATH == 2) {
+                                for (int k = gst[at]; k < ga.lazy.now; ++k) {
+                                    const float d = hist[k % kLazyHistory];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) xf[e] *= d;
+                                }
+                            }
+                            const float wt = gwt[at];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[u][e] = __builtin_fmaf(wt, xf[e], acc[u][e]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RCH; ++u) {
+                const int idx = base + tid + T * u;
+                if (idx >= total) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = in[u] ? acc[u][e] / fw : 0.f;
+                if (in[u]) *reinterpret_cast<float4*>(ga.phrase + static_cast<size_t>(m0 + row[u]) * g.lda + 4 * c4[u]) = make_float4(v[0], v[1], v[2], v[3]);
+                unsigned h0, m0_, l0, h1, m1, l1;
+                rs_pair(v[0], v[1], h0, m0_, l0);
+                rs_pair(v[2], v[3], h1, m1, l1);
+                const int ks = c4[u] >> 2, fl = row[u] + 32 * ((c4[u] >> 1) & 1);
+                unsigned char* p = rs_lds + ks * 1024 + rs_slot(ks, fl) * 16 + (c4[u] & 1) * 8;
+                *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(p + plane_bytes) = make_uint2(m0_, m1);
+                *reinterpret_cast<uint2*>(p + 2 * plane_bytes) = make_uint2(l0, l1);
+            }
+        }
+    } else {
         const int C4 = 4 * KSP, K4 = g.K >> 2;
         const int total = SM * C4;
         for (int base = 0; base < total; base += T * RCH) {
@@ -301,7 +414,9 @@ __global__ __launch_bounds__(256) void gemm_rsplit_planes_kernel(const float* __
 struct RsPlan { int waves, rch, ksp, nt; size_t lds; };
 
 // the shapes the kernel covers: N <= 320, N and K multiples of 4, the panel's planes in LDS
-bool rs_plan(int b_layout, int M, int N, int K, bool colstats, bool rowsq, bool bn, RsPlan* p) {
+// gather_window > 0: the forward product with the word gather-mean inside (GATH): at most five float4s of the panel per thread
+// (five word rows in flight for each), at most eight waves
+bool rs_plan(int b_layout, int M, int N, int K, bool colstats, bool rowsq, bool bn, RsPlan* p, int gather_window = 0) {
     if (M <= 0 || N < 32 || K < 16 || N > 320 || (N % 4) || (K % 4)) return false;
     if ((colstats && rowsq) || (b_layout == 0 && (bn || rowsq)) || (bn && (b_layout != 1 || colstats))) return false;
     const int nt = (N + 31) / 32;
@@ -312,29 +427,31 @@ bool rs_plan(int b_layout, int M, int N, int K, bool colstats, bool rowsq, bool 
     const int rch = rounds <= 4 ? 4 : (rounds == 5 ? 5 : (rounds <= 8 ? 8 : 0));
     if (!rch) return false;
     if (bn && rch > 4) return false;            // (the instantiations: PRE comes with four float4s + four of `pre` per thread)
+    if (gather_window && (bn || b_layout != 0 || rch > 5 || waves > 8 || gather_window > kRsGatherMaxWindow)) return false;
     const int np = 32 * waves;
     const size_t img = std::max<size_t>(static_cast<size_t>(3) * ksp * 1024, static_cast<size_t>(SM) * (np + 4) * 4);
-    const size_t lds = img + (static_cast<size_t>(2) * np + (bn ? 4 * static_cast<size_t>(K) : 0) + 4) * sizeof(float);
+    const size_t lds = img + (static_cast<size_t>(2) * np + (bn ? 4 * static_cast<size_t>(K) : 0) + 4 +
+                              (gather_window ? 3 * static_cast<size_t>(SM) * gather_window + kLazyHistory : 0)) * sizeof(float);
     if (lds > kRsLdsMax) return false;
     p->waves = waves; p->rch = rch; p->ksp = ksp; p->nt = nt; p->lds = lds;
     return true;
 }
 
-template <bool PRE, int WAVES, int RCH, int NPROD>
-bool rs_launch(const RsArgs& g, int grid, size_t lds, hipStream_t s) {
+template <bool PRE, int WAVES, int RCH, int NPROD, int GATH = 0>
+bool rs_launch(const RsArgs& g, int grid, size_t lds, hipStream_t s, const typename RsGatherArgs<GATH>::type& ga = typename RsGatherArgs<GATH>::type{}) {
     // more than 64 KB of dynamic LDS is an opt-in per kernel and per DEVICE
     static std::atomic<bool> attr_set[kRsMaxDevices];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kRsMaxDevices) return false;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rsplit_kernel<PRE, WAVES, RCH, NPROD>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rsplit_kernel<PRE, WAVES, RCH, NPROD, GATH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kRsLdsMax)) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
         attr_set[dev].store(true, std::memory_order_release);
     }
-    NVSM_LAUNCH((gemm_rsplit_kernel<PRE, WAVES, RCH, NPROD>), dim3(grid), dim3(64 * WAVES), lds, s, g);
+    NVSM_LAUNCH((gemm_rsplit_kernel<PRE, WAVES, RCH, NPROD, GATH>), dim3(grid), dim3(64 * WAVES), lds, s, g, ga);
     return true;
 }
 
@@ -360,12 +477,16 @@ bool gemm_rsplit_covers(int b_layout, int M, int N, int K, bool colstats, bool r
     RsPlan p;
     return gemm_split_products() != 0 && tuning().gemm_rsplit && rs_plan(b_layout, M, N, K, colstats, rowsq, bn, &p);
 }
+bool gemm_rsplit_gather_covers(int M, int N, int K, bool colstats, int window) {
+    RsPlan p;
+    return window >= 1 && gemm_split_products() != 0 && tuning().gemm_rsplit && rs_plan(0, M, N, K, colstats, false, false, &p, window);
+}
 
 // true: launched. A [M][K] row-major, 16 B aligned operands, leading dimensions multiples of 4. ws: the planes of B in this
 // kernel's layout (GemmSplitWs::rplanes; cut here, on `s`, unless ws->rready says they are current).
 bool launch_gemm_rsplit(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                         float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
-                        float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn) {
+                        float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn, const GatherFused* gf) {
     const int nprod = gemm_split_products();
     if (!nprod || !tuning().gemm_rsplit || !ws || !ws->rplanes || ws->rbytes < gemm_rsplit_planes_bytes(N, K)) return false;
     if ((lda % 4) || (ldb % 4) || (ldc % 4) || lda < K) return false;
@@ -373,7 +494,8 @@ bool launch_gemm_rsplit(int b_layout, const float* A, const float* B, float* C, 
     const bool fused_bn = bn && bn->pre;
     if (fused_bn && (bn->dy != A || reinterpret_cast<uintptr_t>(bn->pre) % 16)) return false;
     RsPlan p;
-    if (!rs_plan(b_layout, M, N, K, colstats != nullptr, rowsq != nullptr, fused_bn, &p)) return false;
+    if (gf && (gf->window < 1 || lda != K || !gf->table || !gf->idx || reinterpret_cast<uintptr_t>(gf->table) % 16)) return false;
+    if (!rs_plan(b_layout, M, N, K, colstats != nullptr, rowsq != nullptr, fused_bn, &p, gf ? gf->window : 0)) return false;
     const int grid = (M + SM - 1) / SM;
     RsArgs g{};
     g.A = A; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.KSP = p.ksp; g.NT = p.nt;
@@ -393,6 +515,19 @@ bool launch_gemm_rsplit(int b_layout, const float* A, const float* B, float* C, 
     if (!g.dump) return false;
     if (!ws->rready) { launch_gemm_rsplit_planes(b_layout, B, N, K, ldb, ws->rplanes, s); ws->rready = true; }
     g.planes = static_cast<const unsigned char*>(ws->rplanes);
+    if (gf) {      // the word gather-mean inside (forward product): A is written — the phrase matrix — not read
+        const bool lz = gf->lazy && gf->lazy->stamp;
+        RsGather ge{gf->table, gf->idx, gf->wts, gf->window, const_cast<float*>(A)};
+        RsGatherLazy gl{gf->table, gf->idx, gf->wts, gf->window, const_cast<float*>(A), lz ? *gf->lazy : LazyView{}};
+#define NVSM_RSG_CASE(W, R)                                                                                             \
+        if (p.waves == W && p.rch == R) {                                                                               \
+            if (lz) return nprod == 9 ? rs_launch<false, W, R, 9, 2>(g, grid, p.lds, s, gl) : rs_launch<false, W, R, 6, 2>(g, grid, p.lds, s, gl); \
+            return nprod == 9 ? rs_launch<false, W, R, 9, 1>(g, grid, p.lds, s, ge) : rs_launch<false, W, R, 6, 1>(g, grid, p.lds, s, ge); \
+        }
+        NVSM_RSG_CASE(4, 4) NVSM_RSG_CASE(4, 5) NVSM_RSG_CASE(8, 4) NVSM_RSG_CASE(8, 5)
+#undef NVSM_RSG_CASE
+        return false;
+    }
 #define NVSM_RS_CASE(W, R)                                                                                              \
     if (p.waves == W && p.rch == R) {                                                                                   \
         if (fused_bn) { if constexpr (R == 4) return nprod == 9 ? rs_launch<true, W, R, 9>(g, grid, p.lds, s) : rs_launch<true, W, R, 6>(g, grid, p.lds, s); else return false; } \

@@ -66,6 +66,10 @@ struct PlaneTarget { unsigned char* planes; size_t plane_stride; int kind; int d
 // batch-norm backward (or, pre == null, the bias gradient alone) riding on the backward projection product: see launch_gemm_rows
 struct BnDxFused { float* dy; const float* pre; const float* mean; const float* inv_std; const double* sums;
                    float* dbeta; float* dgamma; float* grad_bias; double n_global; };
+// the word gather-mean (launch_gather_mean's arguments) riding on the forward projection product's staging of A (gemm_rsplit.hip,
+// gemm_split.hip): phrase[b] = (Σ_j wts[b, j] · table[idx[b, j]]) / window is formed as the product stages its rows and written
+// out on the way, bit for bit what the gather kernel writes
+struct GatherFused { const float* table; const int* idx; const float* wts; int window; const LazyView* lazy; };
 // planes of the small operand for the split-bf16 GEMM (gemm_split.hip; see launch_gemm_split)
 // ... and for the split-bf16 row-panel kernel of the per-rank batch sizes (gemm_rsplit.hip), which wants them in another order
 struct GemmSplitWs { void* planes; size_t bytes; bool ready; void* rplanes; size_t rbytes; bool rready; };
@@ -112,10 +116,13 @@ bool gemm_rows_covers(int b_layout, int M, int N, int K, bool colstats, bool row
 // gemm_rsplit_planes_bytes(N, K) bytes, cut here unless `rready`), a barrier-free K loop. Arguments as launch_gemm_rows.
 size_t gemm_rsplit_planes_bytes(int N, int K);
 void launch_gemm_rsplit_planes(int b_layout, const float* B, int N, int K, int ldb, void* planes, hipStream_t s);
+// gf (forward product, b_layout 0, lda == K): the word gather-mean of launch_gather_mean rides on the staging of A — A is then
+// WRITTEN (the phrase matrix [M][K], the gather kernel's bits) instead of read: see GatherFused.
 bool launch_gemm_rsplit(int b_layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                         float alpha, const float* bias_n, hipStream_t s, double* colstats, const GridSumWs* sums, float* rowsq,
-                        float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn);
+                        float rowsq_scale, GemmSplitWs* ws, const BnDxFused* bn, const GatherFused* gf = nullptr);
 bool gemm_rsplit_covers(int b_layout, int M, int N, int K, bool colstats, bool rowsq, bool bn);
+bool gemm_rsplit_gather_covers(int M, int N, int K, bool colstats, int window);      // ... with the gather inside
 // Split-bf16 kernel for large batches (gemm_split.hip): fp32 operands cut exactly into three bf16 planes, nine (or six) bf16
 // MFMAs per product with fp32 accumulation. rowsq [M]: COMPLETE rowsq_scale · Σ_cols C² per row. false: not covered / switched off.
 // B travels as its three bf16 planes (GemmSplitWs::planes, gemm_split_planes_bytes(N, K) bytes, owned by the caller): cut by a

@@ -1166,9 +1166,16 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     if (join_e_at == 2) join_E();
     if (words_tail_pending_) { join_T(); words_tail_pending_ = false; }      // the previous step's streaming decay of the words table (step())
 
-    {
-        const bool l2p = cfg_.l2_normalize_phrase_reprs != 0;
-        const LazyView lv = lazy_view(words_);
+    // F3 inside F5 (round 6): where the forward product's kernel forms the phrase rows itself as it stages them — the gather
+    // kernel's arithmetic in its order, `phrase` written on the way for the dT product — the gather is not a launch of its own:
+    // one launch, one gap and a write + read of the phrase matrix less at the head of the critical stream. Not with the phrase
+    // normaliser (it sits between the two) and not in the experiments that queue the CSR builds behind the gather.
+    const LazyView words_view = lazy_view(words_);
+    const bool l2p_fwd = cfg_.l2_normalize_phrase_reprs != 0;
+    const bool gather_in_product = gather_fused_at(B) && !l2p_fwd && csr_after != 1;
+    if (!gather_in_product) {
+        const bool l2p = l2p_fwd;
+        const LazyView& lv = words_view;
         timed_launch(prof, "gather_mean_words", stream_, /*single=*/!l2p, [&] {
             launch_gather_mean(words_.P.p, dw, widx_.p, wwts_, w, B, l2p ? phrase_raw_.p : phrase_p_, stream_, &lv);
             // optional phrase normaliser (objective.cu:136-142): the raw means stay cached for its backward pass
@@ -1176,13 +1183,26 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
         });
     }
     if (csr_after == 1 && !csr_first) { NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_)); launch_csr_builds(ev_gathered_); }
-    debug_check(phrase_p_, B * dw, 0);                  // CHECK_MATRIX(*result->phrase_reprs_), objective.cu:134,141
+    if (!gather_in_product) debug_check(phrase_p_, B * dw, 0);                  // CHECK_MATRIX(*result->phrase_reprs_), objective.cu:134,141
 
     // F5: projection GEMM  pre[B][de] = phrase[B][dw] · Tt[dw][de] (+ b when no BN)   (params.cu:417-421)
     // F6 (first half): with batch-norm the column sums Σx, Σx² of the projection ride in the GEMM epilogue
     join_T();        // the previous step's projection update (after its dT GEMM, the last reader of dy)
     if (join_e_at == 1) join_E();
-    {
+    if (gather_in_product) {
+        const GatherFused gf{words_.P.p, widx_.p, wwts_, w, &words_view};
+        bool launched = false;
+        {
+            PROF("gemm_fwd");
+            if (B <= gemm_rows_max_m())
+                launched = launch_gemm_rsplit(0, phrase_p_, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
+                                              cfg_.batch_normalization ? nullptr : b_.p, stream_, cfg_.batch_normalization ? stats_fwd_ : nullptr,
+                                              &sums_fwd_.ws, nullptr, 0.f, &split_fwd_, nullptr, &gf);
+        }
+        if (!launched) throw Error(NVSM_ERR_UNSUPPORTED, "forward product with the gather inside refused a shape its caller had checked");
+        prof.note("gather_in_product");
+        debug_check(phrase_p_, B * dw, 0);
+    } else {
         PROF("gemm_fwd");
         launch_gemm(0, 0, phrase_p_, T_.p, pre_.p, static_cast<int>(B), de, dw, dw, de, de, 1.f,
                     cfg_.batch_normalization ? nullptr : b_.p, 1, 0, stream_,
@@ -1439,7 +1459,9 @@ void Model::backward_T(hipStream_t strm) {
             timed_launch(prof, "gemm_bwd_T_reduce", strm, true, [&] { launch_splitk_reduce(gT_partial_.p, n, stride, gT_.p, static_cast<int64_t>(stride), strm); });
         };
         pending_slabs_ = 0;
-        if (use_dt()) {
+        if (tune_.skip_dt) {
+            prof.note("dt_skipped_timing_only");      // (experiments build: gT keeps the previous step's values)
+        } else if (use_dt()) {
             // the split-K product on the bf16 matrix pipe (gemm_dt.hip): two workgroups per slab.
             // Slabs: the kernel ALONE is fastest with a workgroup on every CU (128 slabs: 55 us at batch 51 200), but in a step it
             // runs next to the documents pass, which wants the CUs it leaves free and the bandwidth its partials do not take: on
@@ -1844,7 +1866,8 @@ std::string Model::describe(int64_t batch) const {
         if (B >= 1024 && K % 4 == 0 && N % 4 == 0) return "gemm_tstat (exact fp32 MFMA, projection stationary in LDS) or tiled";
         return "gemm_f32_mfma (exact fp32 MFMA, 128 x 128 tiles)";
     };
-    std::string out = "batch " + std::to_string(B) + ": forward " + product(0, de, dw, bn, false, false);
+    std::string out = "batch " + std::to_string(B) + ": forward " + product(0, de, dw, bn, false, false) +
+                      (gather_fused_at(B) && !l2p ? " with the word gather inside" : "");
     const bool fuse = !l2p && B >= 512 && (B <= gemm_rows_max_m() || tune_.split_fuse);
     out += " | backward " + product(1, dw, de, false, need_msq && !l2p, fuse) + (fuse ? " with the batch-norm backward / bias gradient inside" : "");
     // (B_ decides use_dt() / dt_on_main() at run time: evaluated here for `B`)
@@ -1861,6 +1884,16 @@ std::string Model::describe(int64_t batch) const {
     const char* sw = tuning_describe(tune_, buf, sizeof(buf));
     out += std::string(" | switches: ") + (sw[0] ? sw : "defaults");
     return out;
+}
+
+// the forward product of a batch of B windows forms the phrase rows itself (compute_cost): the kernel launch_gemm would take
+// covers the shape with the gather inside
+bool Model::gather_fused_at(int64_t B) const {
+    const int dw = cfg_.word_repr_size, de = cfg_.entity_repr_size, w = cfg_.window_size;
+    if (!gemm_split_products() || B < 512 || !split_fwd_.rplanes) return false;
+    if (B <= gemm_rows_max_m())
+        return (tune_.gather_fuse & 1) && gemm_rsplit_gather_covers(static_cast<int>(B), de, dw, cfg_.batch_normalization != 0, w);
+    return false;
 }
 
 // which side streams build the two tables' CSRs this step (compute_cost: NVSM_SORT_LAYOUT)

@@ -274,6 +274,7 @@ class Model {
     bool dt_on_main_at(int64_t B) const;
     bool use_dt_at(int64_t B) const;
     int csr_stream_layout() const;
+    bool gather_fused_at(int64_t B) const;      // the forward product at this batch size forms the phrase rows itself
     int last_csr_layout_ = -1;          // the layout of the previous step's builds (host-batch copies lean on it)
     void alloc_sums(SumsBufs& b, int colgroups, int contrib_cap, int width_cap);
     bool csr_joined_words_ = true, csr_joined_ents_ = true;      // the main stream is behind the current CSR builds

@@ -171,6 +171,67 @@ def test_gather_mean_reference_kat():
                                      (1.0 + 2.0 * 10 + 0.2 * 4) / 3., (2.0 + 2.0 * 11 + 0.2 * 5) / 3.], rtol=1e-6)
 
 
+GATHER_FUSED_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import cunvsm_amd as ca
+from tests.helpers import PARAMS, gpu_model, load_params, random_batch, random_params
+out = []
+for dw, de, window, B, weighted, lazy in ((300, 256, 10, 6400, True, False), (128, 128, 10, 4096, False, False), (60, 64, 6, 1000, True, False),
+                                          (300, 256, 3, 8192, True, False), (64, 96, 5, 515, True, False), (64, 96, 5, 515, True, True)):
+    spec = dict(num_words=5000, num_entities=700, word_dim=dw, entity_dim=de, window=window, num_random=3, nonlinearity="hard_tanh",
+                batch_norm=True, update_method="sparse_adam" if lazy else "sgd", **{"lambda": 0.01})
+    rs = np.random.RandomState(B + dw)
+    g = gpu_model(spec, B)
+    params = random_params(spec, rs)
+    load_params(g, params, True)
+    desc = g.describe(B)
+    if lazy:      # two updates first: the words table then carries pending decay factors the gather has to apply (LazyView)
+        for _ in range(2):
+            words, ww, labels, iw, ids = random_batch(spec, rs, B, zipf=True, weighted=True)
+            g.step(ca.Batch(words, labels, ww, iw), 0.05, entity_ids=ids)
+    words, ww, labels, iw, ids = random_batch(spec, rs, B, zipf=True, weighted=weighted)
+    g.profile_enable(True)
+    g.compute_cost(ca.Batch(words, labels, ww if weighted else None, iw), ids)
+    g.synchronize()
+    notes = sorted(g.profile())
+    phrase = g.get_tensor("phrase")
+    pre = g.get_tensor("pre").reshape(B, de)
+    table = g.get_param(PARAMS[0])           # (flushes pending decay: the rows as the dense passes would have left them)
+    T = g.get_param(PARAMS[2]).reshape(dw, de).astype(np.float64)
+    ref_phrase = np.empty(B * dw, np.float32)
+    ca._lib.check(ca.lib().nvsm_debug_gather_mean(spec["num_words"], dw, table.ctypes.data, words.ctypes.data,
+                                                  ww.ctypes.data if weighted else None, window, B, ref_phrase.ctypes.data))
+    ref = ref_phrase.reshape(B, dw).astype(np.float64) @ T
+    out.append(dict(shape=[dw, de, window, B, weighted, lazy], desc=desc, notes=notes,
+                    phrase_bits_equal=bool(np.array_equal(phrase.view(np.uint32), ref_phrase.view(np.uint32))),
+                    pre_err=float(np.abs(pre - ref).max() / np.abs(ref).max())))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_gather_inside_the_forward_product_writes_the_gather_kernels_bits():
+    """Round 6 experiment (NVSM_GATHER_FUSE=1, experiments build; off by default because it measured slower, profiles/NOTES_r06.md §1):
+    at per-rank batch sizes the forward product forms the phrase rows itself while it stages them (gemm_rsplit.hip GATH; replaces
+    cpp/params.cu:75-95 + :417 as one launch). The `phrase` side output must be the stand-alone gather kernel's bits
+    (nvsm_debug_gather_mean on the same table, ids and weights) — ragged last panel, no weights, lazily decayed table included."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dbg = os.path.join(root, "cunvsm_amd", "libcunvsm_amd_dbg.so")
+    if not os.path.exists(dbg):
+        pytest.skip("experiments build absent (make -C cunvsm_amd/csrc dbg)")
+    env = dict(os.environ, CUNVSM_AMD_LIB=dbg, NVSM_GATHER_FUSE="1", NVSM_LAZY_MIN_MB="0")
+    r = subprocess.run([sys.executable, "-c", GATHER_FUSED_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, cwd=root, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-2000:])
+    for e in json.loads(lines[-1][len("RESULT "):]):
+        assert "with the word gather inside" in e["desc"], e
+        assert "gather_in_product" in e["notes"] and "gather_mean_words" not in e["notes"], e
+        assert e["phrase_bits_equal"], e
+        assert e["pre_err"] <= 2e-5, e
+
+
 # ---------------------------------------------------------------------------------------------
 # initialisation + sampling replay the reference's RNG stream draw for draw
 # ---------------------------------------------------------------------------------------------

@@ -85,6 +85,8 @@ EXP_VARIANTS = [
     {"NVSM_HOIST_UNTOUCHED": "2"},
     {"NVSM_PLANES_IN_UPDATE": "0", "NVSM_SLAB_SUM_IN_UPDATE": "0"},
     {"NVSM_EARLY_SNAPSHOT": "0", "NVSM_STAMP_IN_PROLOGUE": "0", "NVSM_HOIST_UNTOUCHED": "0", "NVSM_PLANES_IN_UPDATE": "0", "NVSM_SLAB_SUM_IN_UPDATE": "0"},
+    # round 6: the word gather-mean inside the forward product's staging (gemm_rsplit.hip GATH) instead of a launch of its own
+    {"NVSM_GATHER_FUSE": "1"},
 ]
 DBG_LIB = os.path.join(ROOT, "cunvsm_amd", "libcunvsm_amd_dbg.so")
 
@@ -118,6 +120,9 @@ LARGE_EXP_VARIANTS = [
     # differently — the last bits of the loss, not the kernel's arithmetic)
     {"NVSM_LOSS_PIPE": "1", "NVSM_LOSS_EPW": "20"},
     {"NVSM_LOSS_PIPE": "0"},
+    # (the planes the projection update writes in the large-batch layout against launch_gemm_split_planes, and the
+    #  update's own slab sum against launch_splitk_reduce)
+    {"NVSM_PLANES_IN_UPDATE": "0", "NVSM_SLAB_SUM_IN_UPDATE": "0"},
 ]      # (not NVSM_DT_ON_MAIN: on the main stream the split-bf16 product's slabs are added up by launch_splitk_reduce or by the projection
        #  update in another grouping than the tiled product's on side stream 2 — another summation order)
 

@@ -669,6 +669,32 @@ void launch_host_pull(const HostPull& p, hipStream_t s) {
     hipLaunchKernelGGL(host_pull_kernel, dim3(blocks), dim3(256), 0, s, p);
 }
 
+// Data parallel without synchronised batch-norm statistics: the step's ONE collective is the f32 all-reduce of
+// [dT (d_e x d_w) | db (d_e) | loss hi | loss lo] — the bias gradient and the loss word ride behind the projection gradient instead
+// of in an f64 all-reduce of their own (model.cpp backward_T). The loss word travels as two floats (hi = (float) s, lo = (float)
+// (s - hi)): their sums, recombined in double, carry the fp64 word to ~1e-14 of its value per rank.
+__global__ void dp_pack_tail_kernel(const float* __restrict__ gb, const double* __restrict__ loss, float* __restrict__ tail, int de) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < de) tail[i] = gb[i];
+    if (i == de) {
+        const double s = *loss;
+        const float hi = static_cast<float>(s);
+        tail[de] = hi;
+        tail[de + 1] = static_cast<float>(s - static_cast<double>(hi));
+    }
+}
+__global__ void dp_unpack_tail_kernel(const float* __restrict__ tail, float* __restrict__ gb, double* __restrict__ loss, int de) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < de) gb[i] = tail[i];
+    if (i == de) *loss = static_cast<double>(tail[de]) + static_cast<double>(tail[de + 1]);
+}
+void launch_dp_pack_tail(const float* gb, const double* loss, float* tail, int de, hipStream_t s) {
+    hipLaunchKernelGGL(dp_pack_tail_kernel, dim3((de + 1 + 255) / 256), dim3(256), 0, s, gb, loss, tail, de);
+}
+void launch_dp_unpack_tail(const float* tail, float* gb, double* loss, int de, hipStream_t s) {
+    hipLaunchKernelGGL(dp_unpack_tail_kernel, dim3((de + 1 + 255) / 256), dim3(256), 0, s, tail, gb, loss, de);
+}
+
 __global__ void delay_kernel(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);

@@ -176,6 +176,10 @@ void launch_scale(float* x, int64_t n, float a, hipStream_t s);      // x *= a (
 // with the GPU waiting for its launches. src: device-visible addresses of page-locked memory; bytes: multiples of 4.
 struct HostPull { void* dst[4]; const void* src[4]; size_t bytes[4]; int count; };
 void launch_host_pull(const HostPull& p, hipStream_t s);
+// data parallel, one collective per step (model.cpp dp_fold_): tail = [gb (de floats) | loss as hi, lo floats] behind the projection
+// gradient, and back (gather_gemm.hip)
+void launch_dp_pack_tail(const float* gb, const double* loss, float* tail, int de, hipStream_t s);
+void launch_dp_unpack_tail(const float* tail, float* gb, double* loss, int de, hipStream_t s);
 void launch_delay(int microseconds, hipStream_t s);      // one wave spinning on the 100 MHz wall clock (profiling aid)
 void launch_iota(int* dst, int64_t n, hipStream_t s);
 

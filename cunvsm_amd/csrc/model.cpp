@@ -516,7 +516,7 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
     in_ids64_.alloc(N);
     if (cfg.sampler == NVSM_SAMPLER_HOST_MINSTD)
         for (int p = 0; p < 2; ++p) NVSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_ids_pin_[p]), N * sizeof(int64_t), hipHostMallocDefault));
-    if (cfg.world_size > 1) loss_tmp_.alloc(1, true);
+    if (cfg.world_size > 1) { loss_tmp_.alloc(1, true); loss_red_.alloc(1, true); }
     widx_.alloc(B * w); ids_buf_[0].alloc(N); ids_buf_[1].alloc(N); ids_p_ = ids_buf_[0].p;
     phrase_.alloc(B * dw); phrase_alt_.alloc(B * dw); phrase_p_ = phrase_.p; pre_.alloc(B * de); proj_.alloc(B * de); dy_.alloc(B * de); gphrase_.alloc(B * dw);
     if (cfg.l2_normalize_phrase_reprs) { phrase_raw_.alloc(B * dw); phrase_norms_.alloc(B); }
@@ -546,7 +546,8 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
     rplanes_fwd_.alloc(gemm_rsplit_planes_bytes(de, dw), true); rplanes_bwd_.alloc(gemm_rsplit_planes_bytes(dw, de), true);
     split_fwd_ = GemmSplitWs{planes_fwd_.p, planes_fwd_.n, false, rplanes_fwd_.p, rplanes_fwd_.n, false};
     split_bwd_ = GemmSplitWs{planes_bwd_.p, planes_bwd_.n, false, rplanes_bwd_.p, rplanes_bwd_.n, false};
-    gT_.alloc(static_cast<size_t>(de) * dw, true); gb_.alloc(de, true);
+    // (+ the tail of the data-parallel step's folded collective behind the projection gradient: db | loss hi | loss lo — backward_T)
+    gT_.alloc(static_cast<size_t>(de) * dw + de + 2, true); gb_.alloc(de, true);
     // split-K slabs of the dT product: 128 at the 51 200-window batch (400 rows each); a per-rank batch of a few thousand
     // windows cut 128 ways is 600 workgroups of two 32-deep K tiles each — all prologue, epilogue and 39 MB of partials
     // (158 us next to the updates at batch 6 400: step 0.360 ms; 50 slabs 0.291, 25 slabs 0.295, 12 slabs 0.296, interleaved
@@ -941,6 +942,7 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
     have_forward_ = have_grads_ = false;
     cost_valid_ = false;
     loss_reduced_ = false;
+    loss_folded_ = false;
     RangeScope range_cc("ComputeCost");                 // cpp/main.cu:409
     if (cfg_.l2_normalize_entity_reprs) join_E();      // that documents update still reads ids_, which the prologue rewrites
     // The previous step's CSR builds (radix sorts on the side streams) read ids_ / widx_, which this step's prologue is
@@ -1374,7 +1376,8 @@ void Model::backward_dx() {
     // ... and without batch-norm (the LSE recipe) the same kernel finalises the bias gradient Σdy and the rows' mean of squares:
     // colsum_finalize + GEMM + sum_parts as one launch
     if (!cfg_.batch_normalization && !l2p && fused_covers(false)) {
-        if (dp) allreduce_f64(stats_bwd_, 1 + de);
+        // (dp_fold(): Σdy only feeds the bias gradient here — it and the loss word ride on the dT all-reduce, backward_T)
+        if (dp && !dp_fold()) allreduce_f64(stats_bwd_, 1 + de);
         if (big) split_ready(); else rsplit_ready();
         BnDxFused bias_only{nullptr, nullptr, nullptr, nullptr, stats_bwd_ + 1, nullptr, nullptr, gb_.p, 1.0};
         bool launched = false;
@@ -1384,7 +1387,7 @@ void Model::backward_dx() {
         }
         if (!launched) throw Error(NVSM_ERR_UNSUPPORTED, "fused backward GEMM refused a shape its caller had checked");
         if (dx_follower_) NVSM_HIP_CHECK(hipStreamWaitEvent(dx_follower_, ev_bwdx_, 0));
-        if (dp) loss_reduced_ = true;
+        if (dp && !dp_fold()) loss_reduced_ = true;
         return;
     }
 
@@ -1408,6 +1411,10 @@ void Model::backward_dx() {
             if (dp && cfg_.sync_batch_norm) {
                 allreduce_f64(stats_bwd_, 1 + 2 * de);
                 dx_final([&] { bn_dx(B_global); });
+            } else if (dp && dp_fold()) {
+                // per-shard statistics: dx needs nothing from the other ranks; the bias gradient (this shard's dβ, written by bn_dx)
+                // and the loss word are summed over the ranks together with dT (backward_T): ONE collective per step
+                dx_final([&] { bn_dx(static_cast<double>(B)); });
             } else if (dp) {
                 bn_dx(static_cast<double>(B));
                 allreduce_f64(stats_bwd_, 1 + 2 * de);
@@ -1416,7 +1423,7 @@ void Model::backward_dx() {
                 dx_final([&] { bn_dx(static_cast<double>(B)); });
             }
         } else {
-            if (dp) allreduce_f64(stats_bwd_, 1 + de);
+            if (dp && !dp_fold()) allreduce_f64(stats_bwd_, 1 + de);
             dx_final(colsum);
         }
     }
@@ -1440,7 +1447,14 @@ void Model::backward_dx() {
             NVSM_HIP_CHECK(hipEventRecord(ev_bwdx_, stream_));
         }
     }
-    if (dp) loss_reduced_ = true;
+    if (dp && !dp_fold()) loss_reduced_ = true;
+}
+
+// Data parallel: may the step's small f64 all-reduce ride on the dT all-reduce? Only with synchronised batch-norm statistics does
+// anything in front of the dT product need another rank's sums (dx = f(Σdy, Σdy·x̂ over the GLOBAL batch)); with per-shard
+// statistics, and without batch-norm, [loss | Σdy] feed nothing but the bias gradient and the reported loss: one collective per step.
+bool Model::dp_fold() const {
+    return cfg_.world_size > 1 && !(cfg_.batch_normalization && cfg_.sync_batch_norm) && tune_.dp_fold;
 }
 
 // B6: ∂T (stored [dw][de]) = phraseᵀ[dw x B] · dx[B x de], split-K over the batch   (params.cu:526-531)
@@ -1493,7 +1507,24 @@ void Model::backward_T(hipStream_t strm) {
         }
     }
     // data parallel: one all-reduce of the dense projection gradient over xGMI
-    if (dp) { PROF_ON("allreduce_grad", strm); allreduce_f32(gT_.p, static_cast<int64_t>(de) * dw, strm); cost_valid_ = false; }
+    if (dp) {
+        PROF_ON("allreduce_grad", strm);
+        const int64_t nT = static_cast<int64_t>(de) * dw;
+        if (dp_fold()) {
+            // [dT | db | loss hi | loss lo] in one f32 all-reduce (gb_ holds this rank's Σdy — written by bn_dx / the backward
+            // product's prologue / colsum_finalize, all in front of this stream's dT product; the loss word is final since the loss kernel)
+            launch_dp_pack_tail(gb_.p, stats_bwd_, gT_.p + nT, de, strm);
+            allreduce_f32(gT_.p, nT + de + 2, strm);
+            // (the summed loss goes to a word of its own, read on THIS stream — get_cost / step_deferred —: the loss kernel's word
+            //  belongs to the main stream, which may be a step ahead of side stream 2 by the time this runs)
+            launch_dp_unpack_tail(gT_.p + nT, gb_.p, loss_red_.p, de, strm);
+            loss_reduced_ = true; loss_folded_ = true; loss_stream_ = strm;
+            prof.note("dp_one_collective");
+        } else {
+            allreduce_f32(gT_.p, nT, strm);
+        }
+        cost_valid_ = false;
+    }
 }
 
 float Model::scaled_regularization_lambda() const {
@@ -1515,8 +1546,10 @@ float Model::get_cost() {
             allreduce_f64(loss_tmp_.p, 1);
             src = loss_tmp_.p;
         }
-        NVSM_HIP_CHECK(hipMemcpyAsync(&s, src, sizeof(double), hipMemcpyDeviceToHost, stream_));
-        NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
+        hipStream_t ls = stream_;
+        if (loss_folded_) { src = loss_red_.p; ls = loss_stream_; }      // (summed behind the dT all-reduce, on that stream: backward_T)
+        NVSM_HIP_CHECK(hipMemcpyAsync(&s, src, sizeof(double), hipMemcpyDeviceToHost, ls));
+        NVSM_HIP_CHECK(hipStreamSynchronize(ls));
         raise_device_error();
         const double Bg = static_cast<double>(B_) * (cfg_.world_size > 1 ? cfg_.world_size : 1);
         cost_ = -(s / Bg);
@@ -2130,8 +2163,10 @@ int64_t Model::step_deferred(const nvsm_batch& batch, const int64_t* entity_ids,
     }
     // the loss word is final after the loss kernel (and, data parallel, after the all-reduce in the backward pass): both
     // are behind us on the main stream
-    NVSM_HIP_CHECK(hipMemcpyAsync(d.host, stats_bwd_, sizeof(double), hipMemcpyDeviceToHost, stream_));
-    NVSM_HIP_CHECK(hipEventRecord(d.ev, stream_));
+    // (data parallel with the folded collective: the summed word lives in loss_red_, final on the stream that ran the dT all-reduce)
+    hipStream_t ls = loss_folded_ ? loss_stream_ : stream_;
+    NVSM_HIP_CHECK(hipMemcpyAsync(d.host, loss_folded_ ? loss_red_.p : stats_bwd_, sizeof(double), hipMemcpyDeviceToHost, ls));
+    NVSM_HIP_CHECK(hipEventRecord(d.ev, ls));
     d.batch = static_cast<double>(B_) * (cfg_.world_size > 1 ? cfg_.world_size : 1);
     d.ticket = next_ticket_;
     return next_ticket_++;
@@ -2226,6 +2261,7 @@ int64_t Model::tensor_size(const std::string& name) {
     if (name == "bn_mean" || name == "bn_inv_std" || name == "grad_bias") return de;
     if (name == "grad_transform") return static_cast<int64_t>(de) * dw;
     if (name == "grad_entity") return N * de;
+    if (name == "arrival_counters") return 6;
     throw Error(NVSM_ERR_INVALID_ARGUMENT, "unknown tensor: " + name);
 }
 
@@ -2254,6 +2290,21 @@ void Model::get_tensor(const std::string& name, float* dst, int64_t count) {
         else
             launch_materialize_grad_entity(coef_.p, proj_.p, B_ * R_, R_, cfg_.entity_repr_size, grad_entity_.p, stream_);
         src = grad_entity_.p;
+    } else if (name == "arrival_counters") {
+        // How many arrival counters of the last-arriver hand-overs (device_utils.h grid_sum_ordered, update.hip table passes) are NOT
+        // zero with every stream of the handle quiet: [forward sums, loss sums, words rows, words level 2, documents rows, documents
+        // level 2]. Every launch that runs to completion returns its counters to zero; a counter left behind would make a later sum
+        // hand over early (tests/test_gpu_soak.py).
+        synchronize();
+        int k = 0;
+        for (DevBuf<int>* b : {&sums_fwd_.arrive, &sums_bwd_.arrive, &words_.arrive_row, &words_.arrive2, &ents_.arrive_row, &ents_.arrive2}) {
+            std::vector<int> h(b->n);
+            if (b->n) NVSM_HIP_CHECK(hipMemcpy(h.data(), b->p, b->n * sizeof(int), hipMemcpyDeviceToHost));
+            int64_t nz = 0;
+            for (int v : h) nz += v != 0;
+            dst[k++] = static_cast<float>(nz);
+        }
+        return;
     } else if (name == "entity_ids") {
         std::vector<int> h(count);
         synchronize();

@@ -274,6 +274,7 @@ class Model {
     bool dt_on_main_at(int64_t B) const;
     bool use_dt_at(int64_t B) const;
     int csr_stream_layout() const;
+    bool dp_fold() const;              // data parallel: [db | loss] ride on the dT all-reduce (one collective per step)
     bool gather_fused_at(int64_t B) const;      // the forward product at this batch size forms the phrase rows itself
     int last_csr_layout_ = -1;          // the layout of the previous step's builds (host-batch copies lean on it)
     void alloc_sums(SumsBufs& b, int colgroups, int contrib_cap, int width_cap);
@@ -309,6 +310,9 @@ class Model {
     bool dp_single_stream_ = false;
     bool comm_order_check(bool two_streams);      // all-reduces of known values in the step's order; every rank gets the same verdict
     DevBuf<double> loss_tmp_;         // data parallel get_cost before compute_gradients: all-reduced copy of the loss word
+    DevBuf<double> loss_red_;         // ... with the folded collective (dp_fold): the summed loss word, written behind the dT all-reduce
+    bool loss_folded_ = false;        //     this step's summed loss is in loss_red_, final on loss_stream_
+    hipStream_t loss_stream_ = nullptr;
     nvsm_allreduce_fn ar_fn_ = nullptr;
     void* ar_user_ = nullptr;
     std::vector<double> ar_host_;

@@ -21,6 +21,7 @@ struct Tuning {
     bool stop_events = true;            // NVSM_STOP_EVENTS=0      plain event records instead of events riding on kernel launches
     int sort_layout = -1;               // NVSM_SORT_LAYOUT=0..4   which side streams build the two CSRs (< 0: by batch size)
     long long entry_walk_min = 64ll * 4096;      // NVSM_ENTRY_WALK_MIN=n   entries from which a split table pass walks the sorted entries
+    bool dp_fold = true;                // NVSM_DP_FOLD=0          data parallel without synchronised batch-norm: [db | loss] in an f64 all-reduce of their own instead of behind dT
     // ---- experiments (-DNVSM_EXPERIMENTS) ------------------------------------------------------------------------------------
     int csr_grid_cap = -1;              // NVSM_CSR_GRID_CAP
     double split_ratio = 2.0;           // NVSM_SPLIT_RATIO

@@ -70,6 +70,8 @@ struct Hdf5Api {
 
 }  // namespace
 
+void hdf5_preload() { (void)Hdf5Api::get(); }
+
 void write_hdf5(const std::string& filename, const std::vector<Hdf5Dataset>& datasets) {
     Hdf5Api& h5 = Hdf5Api::get();
     h5.Eset_auto2(0 /* H5E_DEFAULT */, nullptr, nullptr);      // errors are reported through return codes below

@@ -19,5 +19,8 @@ struct Hdf5Dataset {
 
 // Throws FatalError (file exists, library missing, write error).
 void write_hdf5(const std::string& filename, const std::vector<Hdf5Dataset>& datasets);
+// Loads libhdf5 and initialises it now (the reference links it, so its loader pays this before main(); here it would otherwise
+// land inside the first model dump — on a cold box 0.9 s in the middle of the second epoch's batches-per-second figure).
+void hdf5_preload();
 
 }  // namespace nvsm_host

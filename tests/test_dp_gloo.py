@@ -207,6 +207,69 @@ def test_dp_fused_step(tmp_path, method, wide):
     assert not np.array_equal(r[0]["E"], r[1]["E"])
 
 
+def _worker_gpu_fold(rank, port, spec, sync_bn, fold, B, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["NVSM_DP_FOLD"] = "1" if fold else "0"      # (a documented switch: read once per handle, by nvsm_create)
+    import torch.distributed as dist
+    import cunvsm_amd as ca
+    from cunvsm_amd import dp
+    from tests.helpers import gpu_model, load_params
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
+    params, (words, ww, labels, iw, ids) = _global_problem(spec, B, 7)
+    w, wl, wwt, wi, wid = dp.shard_batch(words, labels, ww, iw, ids, spec["window"], spec["num_random"], rank, WORLD)
+    m = gpu_model(spec, B // WORLD, world_size=WORLD, rank=rank, sync_batch_norm=sync_bn, device=0)
+    load_params(m, params, True)
+    calls = []
+    inner = dp.torch_allreduce(dist)
+
+    def counting(buf):
+        calls.append((str(buf.dtype), int(buf.size)))
+        inner(buf)
+    m.set_allreduce_callback(counting)
+    costs, per_step = [], []
+    for s_ in range(3):
+        n0 = len(calls)
+        costs.append(m.step(ca.Batch(w, wl, wwt, wi), 0.05, entity_ids=wid, want_cost=True))
+        per_step.append(calls[n0:])
+    t = m.step_deferred(ca.Batch(w, wl, wwt, wi), 0.05, entity_ids=wid)      # ... and the loss read one step late
+    costs.append(m.deferred_cost(t))
+    np.savez(os.path.join(out_dir, "fold%d_rank%d.npz" % (int(fold), rank)), cost=np.array(costs), T=m.get_param("word_entity_mapping-transform"),
+             b=m.get_param("word_entity_mapping-bias"), calls=np.array([len(c) for c in per_step]),
+             sizes=np.array([sz for c in per_step[:1] for _, sz in c]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec,sync_bn,expect", [(SPEC, 0, (1, 2)), (SPEC_NOBN, 1, (1, 2)), (SPEC, 1, (3, 3))], ids=["per_shard_bn", "nobn", "sync_bn"])
+def test_dp_one_collective_per_step_without_synchronised_statistics(tmp_path, spec, sync_bn, expect):
+    """Round 6: with per-shard batch-norm statistics, and without batch-norm, nothing in front of the dT
+    product needs another rank's sums — [db | loss] ride behind dT in ONE f32 all-reduce per step (model.cpp dp_fold) instead of an
+    f64 all-reduce of their own (NVSM_DP_FOLD=0: the round-5 form). Same losses, same replicas; synchronised statistics keep three."""
+    import torch.multiprocessing as mp
+    from tests.helpers import rel_err
+    B = 256
+    spec = dict(spec, update_method="sparse_adam")
+    res = {}
+    for fold in (True, False):
+        port = _free_port()
+        mp.spawn(_worker_gpu_fold, args=(port, spec, sync_bn, fold, B, str(tmp_path)), nprocs=WORLD, join=True)
+        res[fold] = [np.load(os.path.join(str(tmp_path), "fold%d_rank%d.npz" % (int(fold), k))) for k in range(WORLD)]
+    de, dw = spec["entity_dim"], spec["word_dim"]
+    for fold, want in ((True, expect[0]), (False, expect[1])):
+        r = res[fold]
+        assert list(r[0]["calls"]) == [want] * 3 and list(r[1]["calls"]) == [want] * 3, (fold, r[0]["calls"])
+        np.testing.assert_array_equal(r[0]["T"], r[1]["T"])          # replicas in lock-step
+        np.testing.assert_array_equal(r[0]["b"], r[1]["b"])
+        np.testing.assert_array_equal(r[0]["cost"], r[1]["cost"])    # every rank reports the global loss
+    if expect[0] == 1:
+        assert list(res[True][0]["sizes"]) == [de * dw + de + 2]      # [dT | db | loss hi | loss lo]
+    # folded and unfolded agree to fp32 roundoff (the bias gradient is summed over the ranks in f32 instead of f64)
+    a, b = res[True][0], res[False][0]
+    assert np.abs(a["cost"] - b["cost"]).max() <= 1e-6 * np.abs(b["cost"]).max()
+    assert rel_err(a["T"], b["T"]) < 1e-6 and rel_err(a["b"], b["b"]) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------
 # loss TRAJECTORY of a data-parallel run against the single-process run (SURVEY.md §8e): the dense parameters follow the
 # all-reduced gradients, the embedding tables are rank-local and averaged at the end — not the single-GPU trajectory, but

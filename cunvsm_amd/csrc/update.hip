@@ -22,9 +22,13 @@ namespace cunvsm {
 //  LAST entry carries the same key — one more load for the lane that closes the row, which then finds the row's first entry by
 //  bisection (rows that long are a few hundred hot words; no documents row at |D| = 2 M) — instead of a launch of its own that read
 //  both bounds of EVERY table row: 141 us on the documents CSR chain at |D| = 2 M, 5-10 us and a launch per table elsewhere.)
+// (round 6: ... and, chunk_desc given, the wave that reserved a long row's chunks writes their descriptors too — it knows the row's
+//  first and last entry and the reserved ranges, which is all csr_chunk_fill_kernel looks up per entry: bounds + reservation + fill
+//  are ONE launch of a small batch's CSR build, a chain of launch latencies next to the forward pass.)
 __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* __restrict__ row_begin,
                                   int* __restrict__ row_end, int* __restrict__ touched, int* __restrict__ num_touched,
-                                  int* __restrict__ chunk_base, int* __restrict__ chunk2_base, int* __restrict__ num_chunks, int chunk) {
+                                  int* __restrict__ chunk_base, int* __restrict__ chunk2_base, int* __restrict__ num_chunks, int chunk,
+                                  int* __restrict__ chunk_desc, int* __restrict__ chunk2_desc, int max_chunks, int max_chunks2) {
     const int lane = threadIdx.x & 63;
     const uint64_t lt = (1ull << lane) - 1ull;
     // (whole waves iterate together: the touched-row list is appended to with ONE atomic per wave and turn — one per row
@@ -56,10 +60,32 @@ __global__ void csr_bounds_kernel(const int* __restrict__ key, int64_t n, int* _
                 const int nhi = less == 64 ? hi : lo + static_cast<int>(span * less / 64);
                 lo = nlo; hi = nhi;
             }
+            const int nch = (last + 1 - lo + chunk - 1) / chunk;         // (lo is the same in every lane)
+            int base = 0, base2 = 0;
             if (lane == l) {
-                const int nch = (last + 1 - lo + chunk - 1) / chunk;
-                chunk_base[kk] = atomicAdd(num_chunks, nch);
-                if (nch > kFan) chunk2_base[kk] = atomicAdd(num_chunks + 1, (nch + kFan - 1) / kFan);
+                base = atomicAdd(num_chunks, nch);
+                chunk_base[kk] = base;
+                if (nch > kFan) { base2 = atomicAdd(num_chunks + 1, (nch + kFan - 1) / kFan); chunk2_base[kk] = base2; }
+            }
+            if (chunk_desc) {                                            // what csr_chunk_fill_kernel writes for this row
+                base = __shfl(base, l, 64); base2 = __shfl(base2, l, 64);
+                for (int c = lane; c < nch; c += 64) {
+                    if (base + c < max_chunks) {
+                        const int first = lo + c * chunk;
+                        chunk_desc[(base + c) * 3 + 0] = kk;
+                        chunk_desc[(base + c) * 3 + 1] = first;
+                        chunk_desc[(base + c) * 3 + 2] = min(last + 1, first + chunk);
+                    }
+                }
+                if (nch > kFan) {
+                    const int nch2 = (nch + kFan - 1) / kFan;
+                    for (int c2 = lane; c2 < nch2; c2 += 64) {
+                        if (base2 + c2 < max_chunks2) {
+                            chunk2_desc[(base2 + c2) * 2 + 0] = base + c2 * kFan;
+                            chunk2_desc[(base2 + c2) * 2 + 1] = base + min(nch, (c2 + 1) * kFan);
+                        }
+                    }
+                }
             }
         }
         if (touched) {                                                   // list order is irrelevant: rows are independent
@@ -164,13 +190,19 @@ void launch_csr_build(const Csr& c, hipStream_t s, bool counters_cleared, int* o
     // 0.2413 -> 0.2389. Large batches keep the launch of their own: the build is off their critical path, and WITHOUT it the
     // updates it feeds start earlier and take bandwidth from the main stream (batch 51 200 +0.7 %, |D| = 2 M +0.6 %).
     const bool reserve_in_bounds = c.n > 0 && c.n < kCsrMergeMaxEntries;
+    // ... and can write their descriptors too (round 6, NVSM_CSR_FILL_IN_BOUNDS=1: one launch less again, bit-identical — but the wave
+    // that closes a hot row then serialises bisection + descriptor writes inside the bounds kernel, and the LSE step, whose CSR chain is
+    // co-critical, got 3 % SLOWER (batch 6 400 / 3 200 unchanged): off by default, NOTES_r06 §3), unless the chunks get a batch order
+    // (handles made for large batches: the fill kernel writes the order's keys, whose unused slots need the final chunk count)
+    const bool fill_in_bounds = reserve_in_bounds && !(c.chunk_order && order_key) && tuning().csr_fill_in_bounds;
     if (c.n > 0)
         hipLaunchKernelGGL(csr_bounds_kernel, dim3(csr_grid(c.n, sparse)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin, c.row_end,
-                           row_pass_split(c) ? c.touched : nullptr, c.num_touched, reserve_in_bounds ? c.chunk_base : nullptr, c.chunk2_base, c.num_chunks, c.chunk);
+                           row_pass_split(c) ? c.touched : nullptr, c.num_touched, reserve_in_bounds ? c.chunk_base : nullptr, c.chunk2_base, c.num_chunks, c.chunk,
+                           fill_in_bounds ? c.chunk_desc : nullptr, c.chunk2_desc, c.max_chunks, c.max_chunks2);
     if (!reserve_in_bounds)
         hipLaunchKernelGGL(csr_chunks_kernel, dim3(csr_grid(c.rows, sparse)), dim3(256), 0, s, c.row_begin, c.row_end, c.rows,
                            c.chunk_base, c.chunk2_base, c.num_chunks, c.chunk);
-    if (c.n > 0)
+    if (c.n > 0 && !fill_in_bounds)
         hipLaunchKernelGGL(csr_chunk_fill_kernel, dim3(csr_grid(c.n, sparse)), dim3(256), 0, s, c.sorted_key, c.n, c.row_begin,
                            c.row_end, c.chunk_base, c.chunk2_base, c.chunk_desc, c.chunk2_desc, c.max_chunks, c.max_chunks2, c.num_chunks,
                            c.sorted_entry, c.chunk_order ? order_key : nullptr, c.chunk);

@@ -87,6 +87,8 @@ EXP_VARIANTS = [
     {"NVSM_EARLY_SNAPSHOT": "0", "NVSM_STAMP_IN_PROLOGUE": "0", "NVSM_HOIST_UNTOUCHED": "0", "NVSM_PLANES_IN_UPDATE": "0", "NVSM_SLAB_SUM_IN_UPDATE": "0"},
     # round 6: the word gather-mean inside the forward product's staging (gemm_rsplit.hip GATH) instead of a launch of its own
     {"NVSM_GATHER_FUSE": "1"},
+    # ... and the long rows' chunk descriptors written by the bounds kernel instead of by csr_chunk_fill_kernel
+    {"NVSM_CSR_FILL_IN_BOUNDS": "1"},
 ]
 DBG_LIB = os.path.join(ROOT, "cunvsm_amd", "libcunvsm_amd_dbg.so")
 

@@ -53,11 +53,22 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # dense (MI355X_MICROARCH.md)
 
 
-def gemm_split_products(B):
-    """Partial products of the split-bf16 projection kernels at batch B (0: the exact-fp32 MFMA kernels) — mirrors
-    gemm_split_products() / gemm_rows_max_m() of the engine (NVSM_GEMM_SPLIT, NVSM_GEMM_ROWS_MAX)."""
+def gemm_split_products(B=None):
+    """Partial products of the split-bf16 projection kernels (0: the exact-fp32 MFMA kernels: NVSM_GEMM_SPLIT=0). Every batch size of
+    this bench runs them — gemm_split / gemm_dt above 8 192 windows, gemm_rsplit / gemm_dtw at per-rank batches; which product of a
+    step takes which kernel is in nvsm_describe (product_arithmetic below)."""
     v = int(os.environ.get("NVSM_GEMM_SPLIT", "6"))
-    return v if v in (6, 9) and B > int(os.environ.get("NVSM_GEMM_ROWS_MAX", "8192")) else 0
+    return v if v in (6, 9) else 0
+
+
+def product_arithmetic(desc):
+    """{gemm_fwd | gemm_bwd_x | gemm_bwd_T: partial products (0 = exact fp32 MFMAs)} from the engine's own description of a step
+    (nvsm_describe: "forward <kernel> (...) | backward <kernel> (...) | dT <kernel> (...)")."""
+    out = {}
+    for key, tag in (("gemm_fwd", "forward "), ("gemm_bwd_x", "backward "), ("gemm_bwd_T", "dT ")):
+        seg = [p for p in desc.split(" | ") if p.split(": ")[-1].startswith(tag) or p.startswith(tag)]
+        out[key] = gemm_split_products() if seg and "bf16 planes" in seg[0] else 0
+    return out
 
 
 def zipf_ids(rs, n, size):
@@ -814,6 +825,7 @@ def main():
     main_leg = Leg(env, wl, method, B, uniform_words=args.uniform_words, host_batches=args.host_batches,
                    seed=4321 if headline_strong else 1234)
     model = main_leg.model
+    main_desc = model.describe()      # which kernel each product of a step takes, table modes, switches off their defaults
 
     if world > 1:
         # communicator set-up (connections, first-use kernels) is lazy: two untimed steps take it out of the way even when
@@ -938,7 +950,7 @@ def main():
             # (d') the headline step with the projection products on the EXACT-fp32 MFMA kernels (NVSM_GEMM_SPLIT=0: gemm_tstat / tiled /
             #      gemm_panel, v_mfma_f32_*_f32) instead of the three-bf16-plane arithmetic: the apples-to-apples figure against the
             #      reference's sgemm (cpp/params.cu:417,528, cpp/objective.cu:453) — what the bf16-plane products buy is the difference
-            if args.config == "nvsm" and gemm_split_products(B) and "NVSM_GEMM_SPLIT" not in os.environ:
+            if args.config == "nvsm" and gemm_split_products() and "NVSM_GEMM_SPLIT" not in os.environ:
                 ent = run_secondary_leg(args, base + ["--config", "nvsm", "--batch", str(B), "--update-method", method], env_extra={"NVSM_GEMM_SPLIT": "0"})
                 secondary["exact_fp32_gemm"] = dict({k: ent[k] for k in ("value", "unit", "ms_per_step", "repeats", "ms_per_step_all", "spread")},
                                                     arithmetic="NVSM_GEMM_SPLIT=0: every projection product on exact-fp32 MFMAs (no bf16 planes)")
@@ -1041,6 +1053,7 @@ def main():
                 if prof.get("lazy_stamp_" + t, (0, 0))[1] > 0:
                     rows[t] = touched[t]
         # dominant kernel group and its roofline
+        arithmetic = product_arithmetic(main_desc)
         breakdown = {}
         for k, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
             if n == 0:
@@ -1076,11 +1089,7 @@ def main():
                 # matrix pipe then issues `products` times the useful flops at the bf16 rate
                 ent["TFLOPs"] = round(gemm_flops(wl, B) / (avg * 1e-3) / 1e12, 1)
                 ent["over_f32_mfma_peak"] = round(ent["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 3)      # 157.3 TF/s: what exact-fp32 MFMAs could do at best
-                nprod = gemm_split_products(B)
-                # (the dT product runs the split-bf16 kernel — gemm_dt.hip — from batch 40 960 on, the tiled exact-fp32 kernel
-                #  below: model.cpp use_dt())
-                if k == "gemm_bwd_T" and B < 40960:
-                    nprod = 0
+                nprod = arithmetic.get(k, 0)      # (which kernel a product of this batch size takes: nvsm_describe)
                 if nprod:
                     ent["arithmetic"] = "f32 as 3 bf16 planes, %d of 9 partial products, f32 accumulation" % nprod
                     ent["bf16_mfma_frac"] = round(ent["TFLOPs"] * nprod / BF16_MFMA_PEAK_TFLOPS, 3)
@@ -1165,8 +1174,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "dtype_detail": ("f32 storage and accumulation; the three projection products multiply f32 operands as 3 exact bf16 planes, "
-                             "%d of 9 partial products, on the bf16 matrix pipe (DESIGN 4.1)" % gemm_split_products(B)) if gemm_split_products(B)
-                            else "f32 throughout (exact-f32 MFMA kernels at this batch size)",
+                             "%d of 9 partial products, on the bf16 matrix pipe (DESIGN 4.1)" % gemm_split_products()) if all(arithmetic.values())
+                            else ("f32 throughout (exact-f32 MFMA kernels)" if not any(arithmetic.values()) else
+                                  "f32 storage and accumulation; products on bf16 planes: %s" % arithmetic),
+            "engine": main_desc,
             "data": "synthetic",
             "config": {"workload": "%s synthetic |V|=%d |D|=%d d_word=%d d_doc=%d window=%d neg=%d global batch=%d (%d/GPU) "
                                    "%s%s %s lambda=1e-2 lr=%g %s word ids, inputs %s, device negative sampler"

@@ -8,6 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _SO = os.environ.get("CUNVSM_AMD_LIB") or os.path.join(_HERE, "libcunvsm_amd.so")      # override: A/B of two builds
 _HEADER = os.path.join(_ROOT, "include", "cunvsm_amd.h")
+_HOOKS_SO = os.path.join(_HERE, "libcunvsm_amd_testhooks.so")      # nvsm_debug_*: unit-test / profiling hooks, NOT in the product library
+_HOOKS_HEADER = os.path.join(_ROOT, "include", "cunvsm_amd_test_hooks.h")
 
 TANH, HARD_TANH = 0, 1
 SGD, ADAGRAD, ADAM = 0, 1, 2
@@ -61,12 +63,56 @@ def build_library(force=False):
     return _SO
 
 
-def abi_symbols():
-    """Every function the public header declares (used by the CPU-side ABI test)."""
-    with open(_HEADER) as f:
+def _declared(header):
+    with open(header) as f:
         src = f.read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(nvsm_[a-z0-9_]+)\s*\(", src)) - {"nvsm_allreduce_fn"})
+
+
+def abi_symbols():
+    """Every function the public header declares (used by the CPU-side ABI test)."""
+    return _declared(_HEADER)
+
+
+def hook_symbols():
+    """Every function include/cunvsm_amd_test_hooks.h declares: exported by libcunvsm_amd_testhooks.so, never by the product library."""
+    return _declared(_HOOKS_HEADER)
+
+
+class _Library:
+    """The product library; a name it does not export (nvsm_debug_*) is looked up in the test-hooks library, loaded on first use."""
+
+    def __init__(self, product):
+        self.__dict__["product"] = product
+        self.__dict__["hooks"] = None
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self.product, name)
+        except AttributeError:
+            if not name.startswith("nvsm_debug_"):
+                raise
+        if self.hooks is None:
+            if not os.path.exists(_HOOKS_SO):
+                raise AttributeError("%s lives in %s, which is missing (make -C cunvsm_amd/csrc)" % (name, _HOOKS_SO))
+            H = C.CDLL(_HOOKS_SO, mode=C.RTLD_GLOBAL)      # (its launchers resolve against the product library already loaded)
+            vp, i64 = C.c_void_p, C.c_int64
+            P = C.POINTER
+            for hook, (res, args) in {
+                "nvsm_debug_delay": (C.c_int, [vp, C.c_int]),
+                "nvsm_debug_set_table_pass_form": (C.c_int, [C.c_int]),
+                "nvsm_debug_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+                "nvsm_debug_gemm_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]),
+                "nvsm_debug_dt_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]),
+                "nvsm_debug_sort": (C.c_int, [i64, C.c_int, vp, vp, vp, C.c_int, P(C.c_float)]),
+                "nvsm_debug_gather_mean": (C.c_int, [i64, C.c_int, vp, vp, vp, C.c_int, i64, vp]),
+            }.items():
+                fn = getattr(H, hook)
+                fn.restype = res
+                fn.argtypes = args
+            self.__dict__["hooks"] = H
+        return getattr(self.hooks, name)
 
 
 _lib = None
@@ -115,21 +161,15 @@ def lib():
         "nvsm_comm_size": (C.c_int, [vp, P(C.c_int)]), "nvsm_dp_average_tables": (C.c_int, [vp]),
         "nvsm_range_push": (None, [cp]), "nvsm_range_pop": (None, []),
         "nvsm_profile_enable": (C.c_int, [vp, C.c_int]), "nvsm_profile_reset": (C.c_int, [vp]),
-        "nvsm_profile_names": (C.c_int, [vp, vp, i64]), "nvsm_profile_select": (C.c_int, [vp, cp]), "nvsm_debug_delay": (C.c_int, [vp, C.c_int]),
-        "nvsm_debug_set_table_pass_form": (C.c_int, [C.c_int]),
+        "nvsm_profile_names": (C.c_int, [vp, vp, i64]), "nvsm_profile_select": (C.c_int, [vp, cp]),
         "nvsm_profile_get": (C.c_int, [vp, cp, P(C.c_double), P(i64)]),
-        "nvsm_debug_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
-        "nvsm_debug_gemm_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]),
-        "nvsm_debug_dt_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]),
-        "nvsm_debug_sort": (C.c_int, [i64, C.c_int, vp, vp, vp, C.c_int, P(C.c_float)]),
-        "nvsm_debug_gather_mean": (C.c_int, [i64, C.c_int, vp, vp, vp, C.c_int, i64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = L
-    return L
+    _lib = _Library(L)
+    return _lib
 
 
 def check(status):

@@ -142,6 +142,11 @@ bool gemm_dt_covers(int M, int N, int rows);
 int gemm_dt_slabs(int rows, int want);
 int gemm_dt_default_slabs(int rows, int cus);      // a slab per two CUs (two workgroups per slab), at least 64 rows each
 bool launch_gemm_dt(const float* A, const float* B, float* partial, int M, int N, int rows, int lda, int ldb, int want_slabs, hipStream_t s);
+// The same product in workgroups of ONE wave (gemm_dtw.hip, round 6): 32 x 64 tiles of the output per wave and slab, no LDS, no barrier —
+// for per-rank batches, where the product runs next to both table passes and a whole-CU (or four-wave) workgroup waits for room.
+bool gemm_dtw_covers(int M, int N, int rows);
+int gemm_dtw_slabs(int rows, int want);
+bool launch_gemm_dtw(const float* A, const float* B, float* partial, int M, int N, int rows, int lda, int ldb, int want_slabs, hipStream_t s);
 int gemm_split_products();               // NVSM_GEMM_SPLIT: 6 (default), 9, or 0 = exact-fp32 MFMA kernels only
 int gemm_rows_max_m();                   // largest M launch_gemm sends to the row-panel kernel (NVSM_GEMM_ROWS_MAX, default 8192; 0 = never): above it the split-bf16 kernel
 float* gemm_dump_buffer();               // 256 B per device nobody reads (gemm_tstat.hip): the target of masked-out stores

@@ -569,7 +569,7 @@ Model::Model(const nvsm_config& cfg) : tune_(Tuning::from_env()), cfg_(cfg), R_(
     // (the split-K dT kernel's slabs — up to a slab per two CUs — only where a batch of this handle can take that kernel: a per-rank
     //  or small-batch handle needs gemm_slabs_want_ slabs, 2-7 MB instead of 39)
     const bool dt_possible = dt_ok_ && gemm_split_products() != 0 && B >= std::min<int64_t>(tune_.dt_min_batch, kDtMainMinBatch);
-    const int slabs = std::max({gemm_slabs_want_, dt_possible ? std::max(tune_.dt_slabs, num_cus_ / 2) : 0, 1});
+    const int slabs = std::max({gemm_slabs_want_, tune_.dtw_slabs, kDtwSlabs, dt_possible ? std::max(tune_.dt_slabs, num_cus_ / 2) : 0, 1});
     gT_partial_.alloc(static_cast<size_t>(slabs) * de * dw);
     NVSM_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -632,6 +632,11 @@ void Model::raise_device_error() {
         if (s) (void)hipStreamSynchronize(s);
     E_pending_ = T_pending_ = false;
     words_tail_pending_ = false;
+    // (a failed step may have queued the hoisted decay of the words rows without entries with no update behind it — the handle is
+    //  then PARTIALLY updated, which the caller is told by the exception; what must not survive is the bookkeeping that would make
+    //  the next stand-alone update() skip that decay or refuse to run)
+    words_untouched_hoisted_ = false; words_untouched_pending_ = false; words_snapshot_early_ = false;
+    settle_words_stamp();
     for (DevBuf<int>* b : {&sums_fwd_.arrive, &sums_bwd_.arrive, &words_.arrive_row, &words_.arrive2, &ents_.arrive_row, &ents_.arrive2})
         if (b->p) (void)hipMemset(b->p, 0, b->n * sizeof(int));
     (void)hipDeviceSynchronize();      // (the fills are queued on the null stream, which the handle's streams do not follow)
@@ -1121,10 +1126,12 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             // The fused step knows lr and λ already: the decay of the words rows WITHOUT entries (SGD / Adagrad, λ > 0, a table
             // much larger than the batch: launch_untouched_rows) goes here, under the forward pass, instead of into the update's
             // tail where the next step's word gather waited for it (LSE batch 4096: 16-22 us per step). Nothing of this step
-            // reads those rows; the NEXT word gather may. NVSM_HOIST_UNTOUCHED=1 (default): in front of the event the words update
-            // waits for — the main stream is then behind the pass without a wait of its own (a wait is a packet the stream
-            // stops at for 6-10 us even when the event has long fired); 2: behind that event, with an event of its own that
-            // the next word gather follows (the build is not lengthened by the pass's 11 us).
+            // reads those rows; the NEXT word gather may. NVSM_HOIST_UNTOUCHED=2 (the default, tuning.h): behind the event the words
+            // update waits for, with an event of its own that the next word gather follows (the build is not lengthened by the
+            // pass's 11 us); 1: in front of that event — the main stream is then behind the pass without a wait of its own (a wait is
+            // a packet the stream stops at for 6-10 us even when the event has long fired). Mode 2 leans on `sw` being the SAME
+            // stream in consecutive steps (the next build's sort on it clears the row bounds this pass reads): the layout is a
+            // function of the batch size and the handle's switches only — checked below.
             words_untouched_hoisted_ = false;
             const bool hoist = hoist_untouched_ && !words_.lazy && (cfg_.update_method == NVSM_SGD || cfg_.update_method == NVSM_ADAGRAD);
             auto hoisted_pass = [&] {
@@ -1136,6 +1143,9 @@ void Model::compute_cost(const nvsm_batch& batch, const int64_t* entity_ids) {
             };
             if (hoist && tune_.hoist_untouched == 1) (void)hoisted_pass();
             NVSM_HIP_CHECK(hipEventRecord(ev_csr_, sw));
+            if (hoist && tune_.hoist_untouched == 2 && words_untouched_stream_prev_ && words_untouched_stream_prev_ != sw)
+                throw Error(NVSM_ERR_STATE, "the words CSR stream changed between steps while a hoisted decay leans on it");
+            if (hoist && tune_.hoist_untouched == 2) words_untouched_stream_prev_ = sw;
             if (hoist && tune_.hoist_untouched == 2 && hoisted_pass()) {
                 NVSM_HIP_CHECK(hipEventRecord(ev_untouched_, sw));
                 words_untouched_pending_ = true;
@@ -1493,6 +1503,22 @@ void Model::backward_T(hipStream_t strm) {
             if (!ok) throw Error(NVSM_ERR_UNSUPPORTED, "dT product refused a shape its caller had checked");
             prof.note("dt_split_bf16");
             if (dslabs > 1) reduce(dslabs);
+        } else if (use_dtw_at(B)) {
+            // per-rank batches: the split-bf16 product in workgroups of one wave (gemm_dtw.hip), which go wherever one wave of the
+            // table passes next to it has left
+            // Slabs: twelve (480 waves at the metric's dimensions: 40 tiles x 12) — in the step 8 and 12 tie, 4 / 6 lose 3-15 % at the
+            // LSE shape and at batch 12 800 (too few waves: 78 us alone at batch 6 400 against 25 with 16), 16 / 32 lose 0.5-2 % (more
+            // partials for the projection update to add up on the chain the next forward product waits for); alone the kernel likes
+            // 32-64 (20 us at batch 6 400; the tiled fp32 kernel 37, gemm_dt 18): profiles/r06_exp_dtw_*.txt. NVSM_DTW_SLABS overrides.
+            const int want = tune_.dtw_slabs > 0 ? tune_.dtw_slabs : kDtwSlabs;
+            const int wslabs = gemm_dtw_slabs(static_cast<int>(B), want);
+            bool ok = true;
+            timed_launch(prof, "gemm_bwd_T", strm, true, [&] {
+                ok = launch_gemm_dtw(phrase_p_, dy_.p, wslabs == 1 ? gT_.p : gT_partial_.p, dw, de, static_cast<int>(B), dw, de, want, strm);
+            });
+            if (!ok) throw Error(NVSM_ERR_UNSUPPORTED, "dT product (wave-sized) refused a shape its caller had checked");
+            prof.note("dt_wave_sized");
+            if (wslabs > 1) reduce(wslabs);
         } else if (slabs == 1) {
             timed_launch(prof, "gemm_bwd_T", strm, true, [&] {
                 launch_gemm(1, 0, phrase_p_, dy_.p, gT_.p, dw, de, static_cast<int>(B), dw, de, de, 1.f, nullptr, 1, 0, strm);
@@ -1906,7 +1932,7 @@ std::string Model::describe(int64_t batch) const {
     // (B_ decides use_dt() / dt_on_main() at run time: evaluated here for `B`)
     const bool dt = use_dt_at(B);
     const bool dt_main = dt_on_main_at(B);
-    out += std::string(" | dT ") + (dt ? "gemm_dt (3 bf16 planes, split-K)" : "gemm_f32_mfma / gemm_panel split-K (exact fp32 MFMA)") +
+    out += std::string(" | dT ") + (dt ? "gemm_dt (3 bf16 planes, split-K)" : (use_dtw_at(B) ? "gemm_dtw (3 bf16 planes, split-K, one-wave workgroups)" : "gemm_f32_mfma / gemm_panel split-K (exact fp32 MFMA)")) +
            (dt_main ? " on the main stream" : " on side stream 2");
     if (loss_reads_lazily(de, static_cast<int>(R_), cfg_.l2_normalize_entity_reprs != 0))      // (= the row-gathering kernel covers the shape)
         out += std::string(" | loss loss_rows (") + (R_ <= 17 && loss_two_row_sets(ents_.rows, de) ? "two row sets per wave: documents table beyond the Infinity Cache" : "one row set per wave") + ")";
@@ -1927,6 +1953,16 @@ bool Model::gather_fused_at(int64_t B) const {
     if (B <= gemm_rows_max_m())
         return (tune_.gather_fuse & 1) && gemm_rsplit_gather_covers(static_cast<int>(B), de, dw, cfg_.batch_normalization != 0, w);
     return false;
+}
+
+// The projection update may add up the dT product's slabs itself (TransformUpdateArgs::partial) where its sum is launch_splitk_reduce's
+// sum: the update kernel reproduces the VECTORISED reduce's order (16 interleaved groups, then the groups), which that launcher only
+// takes for d_e * d_w % 4 == 0 and 16 B aligned buffers — otherwise it adds the slabs one after the other, and the fused step would
+// differ from compute_cost; compute_gradients; update in the last bits.
+bool Model::slab_sum_fusable() const {
+    const size_t nT = static_cast<size_t>(cfg_.entity_repr_size) * cfg_.word_repr_size;
+    return tune_.slab_sum_in_update && cfg_.world_size <= 1 && nT % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(gT_partial_.p) | reinterpret_cast<uintptr_t>(gT_.p)) % 16 == 0;
 }
 
 // which side streams build the two tables' CSRs this step (compute_cost: NVSM_SORT_LAYOUT)
@@ -1951,6 +1987,11 @@ bool Model::dt_on_main() const { return dt_on_main_at(B_); }
 bool Model::use_dt_at(int64_t B) const {
     const bool early = B >= kDtMainMinBatch && !words_.lazy && !ents_.lazy && cfg_.world_size <= 1 && tune_.dt_on_main != 0;
     return dt_ok_ && gemm_split_products() != 0 && (B >= tune_.dt_min_batch || early);
+}
+// ... or on the wave-sized kernel (gemm_dtw.hip): the batches gemm_dt does not take, up to NVSM_DTW_MAX_B
+bool Model::use_dtw_at(int64_t B) const {
+    return !use_dt_at(B) && gemm_split_products() != 0 && tune_.dtw_max_batch > 0 && B >= 64 && B <= tune_.dtw_max_batch &&
+           gemm_dtw_covers(cfg_.word_repr_size, cfg_.entity_repr_size, static_cast<int>(B));
 }
 bool Model::dt_on_main_at(int64_t B) const {      // (one rule for step() and describe())
     const int dt_main_env = tune_.dt_on_main;
@@ -2030,7 +2071,7 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         hoist_lr_ = lr; hoist_sl_ = cfg_.regularization_lambda / static_cast<float>(Bg);      // = scaled_regularization_lambda() behind compute_cost
         hoist_untouched_ = tune_.hoist_untouched != 0 && lr >= 0.f && hoist_sl_ > 0.f;
     }
-    try { compute_cost(batch, entity_ids); } catch (...) { loss_stop_event_ = nullptr; hoist_untouched_ = false; throw; }
+    try { compute_cost(batch, entity_ids); } catch (...) { loss_stop_event_ = nullptr; hoist_untouched_ = false; words_untouched_hoisted_ = false; throw; }
     loss_stop_event_ = nullptr;
     hoist_untouched_ = false;
     // The caller wants this step's loss: the loss word is final behind the loss kernel, 0.3 ms into a 0.9 ms step. A copy on side
@@ -2095,14 +2136,14 @@ void Model::step(const nvsm_batch& batch, const int64_t* entity_ids, float lr, f
         // |D| = 2 M 1.71 -> 1.72 the other way (the main stream is their longer chain): hence the rule. NVSM_DT_ON_MAIN=0 / 1.
         if (dt_on_main()) {
             // (the slab sum leaves the main stream too: the projection update on side stream 2 adds the slabs up)
-            fuse_slab_sum_ = tune_.slab_sum_in_update && cfg_.world_size <= 1;
+            fuse_slab_sum_ = slab_sum_fusable();
             try { backward_T(stream_); } catch (...) { fuse_slab_sum_ = false; throw; }
             fuse_slab_sum_ = false;
             NVSM_HIP_CHECK(hipEventRecord(ev_gathered_, stream_));
             NVSM_HIP_CHECK(hipStreamWaitEvent(aux2_stream_, ev_gathered_, 0));
         } else {
             // (the slabs of the split-K product are added up by the projection update behind it on the same stream)
-            fuse_slab_sum_ = tune_.slab_sum_in_update && cfg_.world_size <= 1;      // (data parallel: the summed gradient is all-reduced first)
+            fuse_slab_sum_ = slab_sum_fusable();      // (data parallel: the summed gradient is all-reduced first)
             try { backward_T(aux2_stream_); } catch (...) { fuse_slab_sum_ = false; throw; }
             fuse_slab_sum_ = false;
         }

@@ -273,7 +273,10 @@ class Model {
     bool dt_on_main() const;
     bool dt_on_main_at(int64_t B) const;
     bool use_dt_at(int64_t B) const;
+    bool use_dtw_at(int64_t B) const;    // ... on the wave-sized kernel (gemm_dtw.hip: per-rank batches)
     int csr_stream_layout() const;
+    bool slab_sum_fusable() const;     // the projection update's own slab sum is launch_splitk_reduce's (vector order, alignment)
+    hipStream_t words_untouched_stream_prev_ = nullptr;      // the stream the hoisted words decay of the last step ran on (hoist_untouched == 2)
     bool dp_fold() const;              // data parallel: [db | loss] ride on the dT all-reduce (one collective per step)
     bool gather_fused_at(int64_t B) const;      // the forward product at this batch size forms the phrase rows itself
     int last_csr_layout_ = -1;          // the layout of the previous step's builds (host-batch copies lean on it)
@@ -287,6 +290,7 @@ class Model {
     bool dt_ok_ = false;               // the split-K dT kernel (gemm_dt.hip) covers this model's shapes
     int num_cus_ = 256;
     bool table_decays_lazily(bool documents, int64_t rows, int dim, int64_t max_entries) const;
+    static constexpr int kDtwSlabs = 12;                    // split-K slabs of the wave-sized dT kernel (gemm_dtw.hip; backward_T)
     static constexpr int64_t kDtMainMinBatch = 16384;      // eager tables, one rank: the dT product on the split-bf16 kernel, on the main stream, from here
     int chunk_entries(const TableState& t, int64_t n) const;      // entries per level-1 chunk of a long row for a batch of n entries of table t
     bool use_dt() const;               // this step's dT product runs on it (else: the exact-fp32 tiled / panel kernels)

@@ -80,6 +80,8 @@ Tuning Tuning::from_env() {
     t.stamp_in_prologue = env_flag("NVSM_STAMP_IN_PROLOGUE", t.stamp_in_prologue);
     t.gather_fuse = env_int("NVSM_GATHER_FUSE", t.gather_fuse);
     t.skip_dt = env_flag("NVSM_SKIP_DT", t.skip_dt);
+    t.dtw_max_batch = env_int("NVSM_DTW_MAX_B", t.dtw_max_batch);
+    t.dtw_slabs = env_int("NVSM_DTW_SLABS", t.dtw_slabs);
     t.csr_fill_in_bounds = env_flag("NVSM_CSR_FILL_IN_BOUNDS", t.csr_fill_in_bounds);
 #endif
     return t;
@@ -114,7 +116,7 @@ const char* tuning_describe(const Tuning& t, char* buf, int n) {
     add("dp_fold", t.dp_fold, d.dp_fold);
 #ifdef NVSM_EXPERIMENTS
     // the experiments build reads these too: every one that is off its default is named
-    add("csr_grid_cap", static_cast<double>(t.csr_grid_cap), static_cast<double>(d.csr_grid_cap)); add("split_ratio", static_cast<double>(t.split_ratio), static_cast<double>(d.split_ratio)); add("chunk_grid_cap", static_cast<double>(t.chunk_grid_cap), static_cast<double>(d.chunk_grid_cap)); add("merged_pass", static_cast<double>(t.merged_pass), static_cast<double>(d.merged_pass)); add("chunk_blocks", static_cast<double>(t.chunk_blocks), static_cast<double>(d.chunk_blocks)); add("row_blocks_cap", static_cast<double>(t.row_blocks_cap), static_cast<double>(d.row_blocks_cap)); add("entry_walk", static_cast<double>(t.entry_walk), static_cast<double>(d.entry_walk)); add("entry_walk_min_words", static_cast<double>(t.entry_walk_min_words), static_cast<double>(d.entry_walk_min_words)); add("entry_walk_min_docs", static_cast<double>(t.entry_walk_min_docs), static_cast<double>(d.entry_walk_min_docs)); add("gemm_panel", static_cast<double>(t.gemm_panel), static_cast<double>(d.gemm_panel)); add("pull_blocks", static_cast<double>(t.pull_blocks), static_cast<double>(d.pull_blocks)); add("rows_tpw", static_cast<double>(t.rows_tpw), static_cast<double>(d.rows_tpw)); add("rows_dbg", static_cast<double>(t.rows_dbg), static_cast<double>(d.rows_dbg)); add("split_nt", static_cast<double>(t.split_nt), static_cast<double>(d.split_nt)); add("split_deal", static_cast<double>(t.split_deal), static_cast<double>(d.split_deal)); add("gemm_tstat", static_cast<double>(t.gemm_tstat), static_cast<double>(d.gemm_tstat)); add("gemm_tstat_fwd_any", static_cast<double>(t.gemm_tstat_fwd_any), static_cast<double>(d.gemm_tstat_fwd_any)); add("loss_epw", static_cast<double>(t.loss_epw), static_cast<double>(d.loss_epw)); add("loss_pipe", static_cast<double>(t.loss_pipe), static_cast<double>(d.loss_pipe)); add("csr_after", static_cast<double>(t.csr_after), static_cast<double>(d.csr_after)); add("words_csr_late", static_cast<double>(t.words_csr_late), static_cast<double>(d.words_csr_late)); add("join_e", static_cast<double>(t.join_e), static_cast<double>(d.join_e)); add("split_fuse", static_cast<double>(t.split_fuse), static_cast<double>(d.split_fuse)); add("nt_mask", static_cast<double>(t.nt_mask), static_cast<double>(d.nt_mask)); add("dt_on_main", static_cast<double>(t.dt_on_main), static_cast<double>(d.dt_on_main)); add("fewer_events", static_cast<double>(t.fewer_events), static_cast<double>(d.fewer_events)); add("docs_after_dx", static_cast<double>(t.docs_after_dx), static_cast<double>(d.docs_after_dx)); add("docs_on_main", static_cast<double>(t.docs_on_main), static_cast<double>(d.docs_on_main)); add("chunk_order", static_cast<double>(t.chunk_order), static_cast<double>(d.chunk_order)); add("lazy_tables", static_cast<double>(t.lazy_tables), static_cast<double>(d.lazy_tables)); add("aux2_prio", static_cast<double>(t.aux2_prio), static_cast<double>(d.aux2_prio)); add("aux3_prio", static_cast<double>(t.aux3_prio), static_cast<double>(d.aux3_prio)); add("event_fence", static_cast<double>(t.event_fence), static_cast<double>(d.event_fence)); add("dt_slabs", static_cast<double>(t.dt_slabs), static_cast<double>(d.dt_slabs)); add("docs_delay_us", static_cast<double>(t.docs_delay_us), static_cast<double>(d.docs_delay_us)); add("dt_min_batch", static_cast<double>(t.dt_min_batch), static_cast<double>(d.dt_min_batch)); add("untouched_aside", static_cast<double>(t.untouched_aside), static_cast<double>(d.untouched_aside)); add("hoist_untouched", static_cast<double>(t.hoist_untouched), static_cast<double>(d.hoist_untouched)); add("slab_sum_in_update", static_cast<double>(t.slab_sum_in_update), static_cast<double>(d.slab_sum_in_update)); add("planes_in_update", static_cast<double>(t.planes_in_update), static_cast<double>(d.planes_in_update)); add("gemm_rsplit", static_cast<double>(t.gemm_rsplit), static_cast<double>(d.gemm_rsplit)); add("early_snapshot", static_cast<double>(t.early_snapshot), static_cast<double>(d.early_snapshot)); add("stamp_in_prologue", static_cast<double>(t.stamp_in_prologue), static_cast<double>(d.stamp_in_prologue)); add("gather_fuse", static_cast<double>(t.gather_fuse), static_cast<double>(d.gather_fuse)); add("skip_dt", static_cast<double>(t.skip_dt), static_cast<double>(d.skip_dt)); add("csr_fill_in_bounds", static_cast<double>(t.csr_fill_in_bounds), static_cast<double>(d.csr_fill_in_bounds));
+    add("csr_grid_cap", static_cast<double>(t.csr_grid_cap), static_cast<double>(d.csr_grid_cap)); add("split_ratio", static_cast<double>(t.split_ratio), static_cast<double>(d.split_ratio)); add("chunk_grid_cap", static_cast<double>(t.chunk_grid_cap), static_cast<double>(d.chunk_grid_cap)); add("merged_pass", static_cast<double>(t.merged_pass), static_cast<double>(d.merged_pass)); add("chunk_blocks", static_cast<double>(t.chunk_blocks), static_cast<double>(d.chunk_blocks)); add("row_blocks_cap", static_cast<double>(t.row_blocks_cap), static_cast<double>(d.row_blocks_cap)); add("entry_walk", static_cast<double>(t.entry_walk), static_cast<double>(d.entry_walk)); add("entry_walk_min_words", static_cast<double>(t.entry_walk_min_words), static_cast<double>(d.entry_walk_min_words)); add("entry_walk_min_docs", static_cast<double>(t.entry_walk_min_docs), static_cast<double>(d.entry_walk_min_docs)); add("gemm_panel", static_cast<double>(t.gemm_panel), static_cast<double>(d.gemm_panel)); add("pull_blocks", static_cast<double>(t.pull_blocks), static_cast<double>(d.pull_blocks)); add("rows_tpw", static_cast<double>(t.rows_tpw), static_cast<double>(d.rows_tpw)); add("rows_dbg", static_cast<double>(t.rows_dbg), static_cast<double>(d.rows_dbg)); add("split_nt", static_cast<double>(t.split_nt), static_cast<double>(d.split_nt)); add("split_deal", static_cast<double>(t.split_deal), static_cast<double>(d.split_deal)); add("gemm_tstat", static_cast<double>(t.gemm_tstat), static_cast<double>(d.gemm_tstat)); add("gemm_tstat_fwd_any", static_cast<double>(t.gemm_tstat_fwd_any), static_cast<double>(d.gemm_tstat_fwd_any)); add("loss_epw", static_cast<double>(t.loss_epw), static_cast<double>(d.loss_epw)); add("loss_pipe", static_cast<double>(t.loss_pipe), static_cast<double>(d.loss_pipe)); add("csr_after", static_cast<double>(t.csr_after), static_cast<double>(d.csr_after)); add("words_csr_late", static_cast<double>(t.words_csr_late), static_cast<double>(d.words_csr_late)); add("join_e", static_cast<double>(t.join_e), static_cast<double>(d.join_e)); add("split_fuse", static_cast<double>(t.split_fuse), static_cast<double>(d.split_fuse)); add("nt_mask", static_cast<double>(t.nt_mask), static_cast<double>(d.nt_mask)); add("dt_on_main", static_cast<double>(t.dt_on_main), static_cast<double>(d.dt_on_main)); add("fewer_events", static_cast<double>(t.fewer_events), static_cast<double>(d.fewer_events)); add("docs_after_dx", static_cast<double>(t.docs_after_dx), static_cast<double>(d.docs_after_dx)); add("docs_on_main", static_cast<double>(t.docs_on_main), static_cast<double>(d.docs_on_main)); add("chunk_order", static_cast<double>(t.chunk_order), static_cast<double>(d.chunk_order)); add("lazy_tables", static_cast<double>(t.lazy_tables), static_cast<double>(d.lazy_tables)); add("aux2_prio", static_cast<double>(t.aux2_prio), static_cast<double>(d.aux2_prio)); add("aux3_prio", static_cast<double>(t.aux3_prio), static_cast<double>(d.aux3_prio)); add("event_fence", static_cast<double>(t.event_fence), static_cast<double>(d.event_fence)); add("dt_slabs", static_cast<double>(t.dt_slabs), static_cast<double>(d.dt_slabs)); add("docs_delay_us", static_cast<double>(t.docs_delay_us), static_cast<double>(d.docs_delay_us)); add("dt_min_batch", static_cast<double>(t.dt_min_batch), static_cast<double>(d.dt_min_batch)); add("untouched_aside", static_cast<double>(t.untouched_aside), static_cast<double>(d.untouched_aside)); add("hoist_untouched", static_cast<double>(t.hoist_untouched), static_cast<double>(d.hoist_untouched)); add("slab_sum_in_update", static_cast<double>(t.slab_sum_in_update), static_cast<double>(d.slab_sum_in_update)); add("planes_in_update", static_cast<double>(t.planes_in_update), static_cast<double>(d.planes_in_update)); add("gemm_rsplit", static_cast<double>(t.gemm_rsplit), static_cast<double>(d.gemm_rsplit)); add("early_snapshot", static_cast<double>(t.early_snapshot), static_cast<double>(d.early_snapshot)); add("stamp_in_prologue", static_cast<double>(t.stamp_in_prologue), static_cast<double>(d.stamp_in_prologue)); add("gather_fuse", static_cast<double>(t.gather_fuse), static_cast<double>(d.gather_fuse)); add("skip_dt", static_cast<double>(t.skip_dt), static_cast<double>(d.skip_dt)); add("dtw_max_batch", static_cast<double>(t.dtw_max_batch), static_cast<double>(d.dtw_max_batch)); add("dtw_slabs", static_cast<double>(t.dtw_slabs), static_cast<double>(d.dtw_slabs)); add("csr_fill_in_bounds", static_cast<double>(t.csr_fill_in_bounds), static_cast<double>(d.csr_fill_in_bounds));
     at += std::snprintf(buf + at, static_cast<size_t>(n - at), "%s(experiments build)", at ? " " : "");
 #endif
     return buf;

@@ -64,6 +64,8 @@ struct Tuning {
     bool gemm_rsplit = true;            // NVSM_GEMM_RSPLIT (the split-bf16 row-panel kernel at per-rank batch sizes; 0: gemm_rows)
     bool early_snapshot = true;         // NVSM_EARLY_SNAPSHOT (words scalar snapshot behind the CSR build)
     bool stamp_in_prologue = true;      // NVSM_STAMP_IN_PROLOGUE (words stamps set by the next step's prologue)
+    int dtw_max_batch = 16383;          // NVSM_DTW_MAX_B (the wave-sized dT kernel, gemm_dtw.hip, up to this batch where gemm_dt does not run; 0: never — the tiled exact-fp32 kernel)
+    int dtw_slabs = 0;                  // NVSM_DTW_SLABS (0: the slabs of the tiled kernel, ~400 rows each)
     bool csr_fill_in_bounds = false;    // NVSM_CSR_FILL_IN_BOUNDS=1 (small batches: the bounds kernel also writes the long rows' chunk descriptors — one launch less, bit-identical; measured LSE +3 %, batch 6 400 / 3 200 ±0: NOTES_r06 §3 — hence off)
     bool skip_dt = false;               // NVSM_SKIP_DT (TIMING ONLY, wrong results: the dT product is not launched — is it on the step's critical path?)
     int gather_fuse = 0;                // NVSM_GATHER_FUSE=1 (the word gather-mean inside the per-rank forward product's staging, gemm_rsplit.hip GATH: bit-identical, measured 2-3.5 % SLOWER per step — profiles/NOTES_r06.md §1 — hence off)

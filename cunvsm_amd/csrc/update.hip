@@ -173,7 +173,7 @@ __global__ void csr_chunk_fill_kernel(const int* __restrict__ key, int64_t n, co
 // sits on is closed to the backward projection product behind the loss kernel, whose workgroups need a CU's whole register file
 // (173 us there for 65 alone): |V| = 500 k, |D| = 2 M 1.717 -> 1.668 ms (96: 1.675, 48: 1.647, 32: 1.61-1.65, 16: 1.79, 8: 2.19,
 // uncapped: 1.71), batch 6 400 0.298 -> 0.292, LSE 0.168 -> 0.164. NVSM_CSR_GRID_CAP overrides for every table (experiments).
-constexpr int64_t kCsrMergeMaxEntries = 64 * 4096;      // (the batch size from which a table gets a chunk order / an entry walk, too)
+constexpr int64_t kCsrMergeMaxEntries = 64 * 4096;      // batches below it: the bounds kernel reserves the long rows' chunk ranges (also the default of the entry walk's threshold, tuning.h entry_walk_min; a table gets a chunk ORDER from 60 * 4096 entries: model.cpp alloc_table)
 static int csr_grid(int64_t items, bool sparse_table) {
     const int cap_env = tuning().csr_grid_cap;
     const int cap = cap_env >= 0 ? cap_env : (sparse_table ? 64 : 0);

@@ -139,7 +139,11 @@ bool rendezvous_read(const std::string& path, const std::string& nonce, int64_t 
     // asked where the writer's pid means something: on its host, in its pid namespace (the header says which). A reader in
     // another container / on another node — an external launcher with --comm_id_file on a shared volume — relies on nonce and
     // creation time alone.
-    const bool same_place = h.host_hash == this_host_hash() && h.pidns_inode != 0 && h.pidns_inode == this_pidns_inode();
+    // (/proc/self/ns/pid unreadable on BOTH sides — inode 0 in the header and here — on the same host: the check is made as if the
+    //  namespaces agreed, as it was before the header carried one; a reader that knows its namespace never trusts a writer that did not)
+    const unsigned long long my_ns = this_pidns_inode();
+    const bool same_ns = h.pidns_inode != 0 ? h.pidns_inode == my_ns : my_ns == 0;
+    const bool same_place = h.host_hash == this_host_hash() && same_ns;
     if (h.pid == 0) return no("carries no writer pid");
     if (same_place && ::kill(static_cast<pid_t>(h.pid), 0) != 0 && errno == ESRCH) return no("was written by a process that no longer exists (stale)");
     std::memcpy(id, buf, kCommIdBytes);

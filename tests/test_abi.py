@@ -19,6 +19,27 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), "libcunvsm_amd.so does not export %s" % n
 
 
+def test_unit_test_hooks_live_in_their_own_library():
+    """nvsm_debug_* were exported from the PRODUCT library. They are declared in include/cunvsm_amd_test_hooks.h, built
+    into libcunvsm_amd_testhooks.so (no kernels of its own: it calls the product's launchers), and libcunvsm_amd.so exports none."""
+    import subprocess
+    ca.build_library()
+    hooks = ca._lib.hook_symbols()
+    assert len(hooks) >= 7 and all(h.startswith("nvsm_debug_") for h in hooks)
+    assert not set(hooks) & set(ca.abi_symbols())
+    exported = subprocess.run(["nm", "-D", "--defined-only", ca.library_path()], capture_output=True, text=True, check=True).stdout
+    assert "nvsm_debug_" not in exported and "nvsm_step" in exported
+    hooks_so = os.path.join(ROOT, "cunvsm_amd", "libcunvsm_amd_testhooks.so")
+    exported = subprocess.run(["nm", "-D", "--defined-only", hooks_so], capture_output=True, text=True, check=True).stdout
+    for h in hooks:
+        assert " T " + h in exported, h
+    L = ca.lib()
+    for h in hooks:
+        assert hasattr(L, h)          # (the binding finds them through the hooks library)
+    with pytest.raises(AttributeError):
+        L.product.nvsm_debug_gemm
+
+
 def test_version_and_defaults():
     L = ca.lib()
     assert b"gfx950" in L.nvsm_version()
@@ -76,6 +97,7 @@ def test_public_headers_compile(tmp_path):
     import subprocess
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "cunvsm_amd.h")])
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", "-I", inc, os.path.join(inc, "cunvsm_amd_test_hooks.h")])
     src = tmp_path / "use.cpp"
     src.write_text('#include "cunvsm_amd/model.hpp"\nint main() { nvsm_config c; nvsm_config_default(&c); return c.device; }\n')
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])

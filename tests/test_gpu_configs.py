@@ -30,8 +30,9 @@ def test_lse_small_batch_adagrad_full_size():
     rs = np.random.RandomState(404)
     params = random_params(spec, rs)
     params[PARAMS[2]] = (params[PARAMS[2]] * 4).astype(np.float32)
-    o, g = oracle_model(spec, orc.F64), gpu_model(spec, B)
+    o, o32, g = oracle_model(spec, orc.F64), oracle_model(spec, orc.F32), gpu_model(spec, B)
     load_params(o, params, False)
+    load_params(o32, params, False)
     load_params(g, params, True)
     w, k = spec["window"], spec["num_random"]
     for step in range(3):
@@ -42,17 +43,27 @@ def test_lse_small_batch_adagrad_full_size():
         ids = rs.randint(0, spec["num_entities"], (B, k + 1)).astype(np.int64)
         ids[:, 0] = labels
         ids = ids.ravel()
-        o.forward(words, ww, ids, iw)
-        o.backward()
-        o.update(lr)
+        for m in (o, o32):
+            m.forward(words, ww, ids, iw)
+            m.backward()
+            m.update(lr)
         cg = g.step(ca.Batch(words, labels, ww, iw), lr, entity_ids=ids, want_cost=True)
         co = o.get_cost()
         assert abs(co - cg) <= 2e-5 * abs(co), (step, co, cg)
+    # Tolerance ("state why 2e-3, or tighten it"). Adagrad's first steps divide every gradient component by the root of
+    # its own accumulated square — g / sqrt(g² + ε) ≈ ±1 —, so a component whose fp32 value is a few ulps off moves its parameter
+    # by a full step's worth of that error: ANY fp32 implementation sits 1.5e-5 (words) … 5e-3 (projection, 77 k parameters that all
+    # move) of the parameter change away from the fp64 oracle here, the fp32 build of the oracle itself included (tools/exp/
+    # lse_tol.py, profiles/r06_exp_lse_tolerance.txt: HIP 1.54e-5 / 2.14e-6 / 4.97e-3 / 3.3e-7, fp32 oracle 1.57e-5 / 2.20e-6 /
+    # 4.97e-3 / 6.1e-7). So the statement that can be held tightly is the relative one: the HIP path is no further from fp64 than
+    # the fp32 oracle is (x 1.25 for the order of its sums), and that distance itself stays within 1e-2 of the change.
     for name in PARAMS:
         new_o, new_g, old = o.get(name), g.get_param(name).astype(np.float64), params[name].astype(np.float64)
         change = np.linalg.norm(new_o - old)
-        assert np.linalg.norm(new_g - new_o) <= 2e-3 * change + 1e-7 * np.linalg.norm(old), \
-            (name, np.linalg.norm(new_g - new_o), change)
+        err_hip = np.linalg.norm(new_g - new_o)
+        err_f32 = np.linalg.norm(np.asarray(o32.get(name), np.float64) - new_o)
+        assert err_hip <= 1.25 * err_f32 + 1e-7 * change, (name, err_hip / change, err_f32 / change)
+        assert err_hip <= 1e-2 * change, (name, err_hip / change)
 
 
 def _f32_uniform(rng, n, a):

@@ -249,7 +249,7 @@ def test_mid_batch_dt_on_the_main_stream(method, Bp, monkeypatch):
     d = a.describe(Bp)
     assert "dT gemm_dt" in d and "on the main stream" in d and "documents eager" in d, d
     d12 = a.describe(12800)
-    assert "dT gemm_f32_mfma" in d12 and "on side stream 2" in d12, d12      # (below 16 384 windows: the tiled kernel beside the updates)
+    assert "dT gemm_dtw" in d12 and "on side stream 2" in d12, d12      # (below 16 384 windows: the wave-sized kernel beside the updates — round 6; the tiled fp32 kernel until then)
     load_params(o, params, False)
     for m in (a, b, e):
         load_params(m, params, True)

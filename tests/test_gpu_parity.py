@@ -134,6 +134,24 @@ def test_gemm_dt_split_bf16(M, N, K, split, products, monkeypatch):
     assert np.abs((Cout - ref) / scale).max() < 1.5e-6
 
 
+@pytest.mark.parametrize("M,N,K,split", [(300, 256, 6400, 16), (300, 256, 6400 + 17, 50), (128, 256, 4096, 10), (64, 200, 1000, 3), (320, 132, 77, 1),
+                                         (16, 256, 64, 4), (300, 256, 16, 1), (292, 228, 333, 2), (7, 4, 1, 1), (33, 68, 129, 5)])
+@pytest.mark.parametrize("products", ["6", "9"])
+def test_gemm_dtw_split_bf16(M, N, K, split, products, monkeypatch):
+    """gemm_dtw.hip (round 6: the projection gradient of per-rank batches in workgroups of one wave; replaces cpp/params.cu:526-531)
+    on ragged slabs (a last k step of 1 / 5 / 13 rows, a slab whose length is not a multiple of 8, a batch of one row), padding
+    columns on both operands, values over many binades; against an fp64 product, relative to Σ|a b| — gemm_dt.hip's test and bound."""
+    monkeypatch.setenv("NVSM_GEMM_SPLIT", products)
+    rs = np.random.RandomState(M + N + K)
+    A = (rs.standard_normal((K, M)) * np.exp2(rs.randint(-10, 3, (K, M)))).astype(np.float32)
+    Bm = (rs.standard_normal((K, N)) * np.exp2(rs.randint(-10, 3, (K, N))) + np.arange(N)[None, :] * 1e-3).astype(np.float32)
+    Cout = np.full((M, N), np.nan, np.float32)
+    ca._lib.check(ca.lib().nvsm_debug_gemm((1 << 29) | (split << 2) | 2, M, N, K, A.ctypes.data, Bm.ctypes.data, Cout.ctypes.data))
+    ref = A.T.astype(np.float64) @ Bm.astype(np.float64)
+    scale = np.abs(A.T).astype(np.float64) @ np.abs(Bm).astype(np.float64)
+    assert np.abs((Cout - ref) / scale).max() < 1.5e-6
+
+
 def test_gemm_identity_asymmetric():
     M = N = K = 128
     A = np.eye(M, dtype=np.float32)

@@ -195,7 +195,9 @@ def test_describe_names_the_kernels_a_step_takes():
         m.synchronize()
         notes = set(m.profile())
         assert ("dt_split_bf16" in notes) == want_dt, (B, notes)
-        assert ("dT gemm_dt" in d) == want_dt and ("on the main stream" in d) == want_dt, d
+        assert ("dT gemm_dt " in d) == want_dt and ("on the main stream" in d) == want_dt, d
+        # (per-rank batches: the split-bf16 product in workgroups of one wave, gemm_dtw.hip)
+        assert ("dt_wave_sized" in notes) == (not want_dt) and ("dT gemm_dtw" in d) == (not want_dt), (B, notes, d)
         # (per-rank batches: the split-bf16 row-panel kernel for both batch-sized products, the batch-norm backward inside the
         #  backward one; the projection update adds up the dT product's slabs in the fused step: no launch_splitk_reduce)
         assert ("forward gemm_split" in d) == (B > 8192) and ("forward gemm_rsplit" in d) == (B <= 8192), d

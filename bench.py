@@ -132,6 +132,20 @@ def algorithmic_bytes(kernel, wl, method, B, rows=None):
     return table.get(kernel)
 
 
+def rows_visited(desc, touched, method, B, lr, world=1):
+    """{"words": n, "entities": n} for the tables whose update passes visit only the rows a batch touches: lazily decayed tables
+    (nvsm_describe says which), and SGD / Adagrad tables whose per-step decay factor 1 - (lambda / B_global) * lr rounds to 1.0f —
+    the dense decay is then the identity in the reference's own fp32 arithmetic and the passes skip the rows without entries
+    (update.hip: p_always). The LSE leg (lambda 1e-2, lr 1e-2, batch 4 096: 1 - 2.4e-8) is such a case."""
+    rows = {}
+    sl = np.float32(1e-2) / np.float32(B * max(1, world))
+    identity = method in ("sgd", "adagrad") and np.float32(1.0 - float(sl) * float(lr)) == np.float32(1.0)
+    for t, name in (("words", "words lazy decay"), ("entities", "documents lazy decay")):
+        if touched and (name in desc or identity):
+            rows[t] = touched[t]
+    return rows
+
+
 def step_kernel_groups(method):
     """The kernel groups one fused step runs, by update method (model.cpp update_words): what roofline_step adds up."""
     words = {"sparse_adam": ["row_pass_words_mv", "adam_u_words", "row_pass_words_u"]}.get(method, ["row_pass_words"])
@@ -541,10 +555,11 @@ def update_roofline(leg, env, wl, method, B, uniform_words, steps, counter=None,
     m, lr = leg.model, leg.wl["lr"]
     desc = m.describe()
     lazy = "documents lazy decay" in desc
-    rows = {"entities": leg.touched_rows()["entities"]} if lazy else {}
+    rows = {k: v for k, v in rows_visited(desc, leg.touched_rows(), method, B, lr, env.world).items() if k == "entities"}
     ab = algorithmic_bytes(kernel, wl, method, B, rows)
     out = {"kernel": kernel, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": ab,
-           "table_rows_visited": rows.get("entities", wl["num_entities"]), "decay": "lazy" if lazy else "eager",
+           "table_rows_visited": rows.get("entities", wl["num_entities"]),
+           "decay": "lazy" if lazy else ("eager, identity in fp32 (1 - lambda lr / B rounds to 1): rows without entries are skipped" if rows else "eager"),
            "bytes": "gather of proj rows B*(k+1)*d_doc*4 + read and write of E and its first moments for every row the pass visits"}
 
     def timed(run):
@@ -611,7 +626,7 @@ def secondary_leg(env, args, wl, method):
                            "note": "in-step time of the kernel (events riding on its launch), from a pass of its own behind the timed regions"}
     desc = leg.model.describe()
     touched = leg.touched_rows()
-    rows = {t: touched[t] for t, name in (("words", "words lazy decay"), ("entities", "documents lazy decay")) if name in desc}
+    rows = rows_visited(desc, touched, method, B, wl["lr"])
     # the documents update: by GPU time the largest kernel of every step this bench runs (the main leg's kernel_breakdown; entry walk
     # at configs[4]'s tables) — in the step and alone
     ru = update_roofline(leg, env, wl, method, B, args.uniform_words, min(args.steps, 20))
@@ -1047,11 +1062,7 @@ def main():
                         global_batch=global_batch, batch_per_rank=B, steps=args.steps, **tstats)
         # a lazily decayed table's row passes only read and write the rows the batch touches (the engine notes a
         # `lazy_stamp_<table>` launch per update of such a table)
-        rows = {}
-        if touched:
-            for t in ("words", "entities"):
-                if prof.get("lazy_stamp_" + t, (0, 0))[1] > 0:
-                    rows[t] = touched[t]
+        rows = rows_visited(main_desc, touched, method, B, wl["lr"], world)
         # dominant kernel group and its roofline
         arithmetic = product_arithmetic(main_desc)
         breakdown = {}

@@ -298,6 +298,23 @@ __device__ __forceinline__ void split_body(const SplitArgs& g) {
             u32x4 al = *reinterpret_cast<const u32x4*>(sb + 2 * kPlane);
 #pragma unroll
             for (int rb = 0; rb < RBP; ++rb) {
+#ifndef NVSM_SPLIT_NO_PRIO
+                // Round 6: the wave that is FURTHER along in the tile yields — s_setprio falls with the row block, in four levels —
+                // so that the two waves of a SIMD stay within a few row blocks of each other. The matrix pipe serves the older wave
+                // first: left alone, wave w had issued its 156 MFMAs of a tile when wave w + 4 had issued half of its own, waited
+                // 1 850 cycles at the tile's barrier while its partner finished ALONE at three quarters of the pipe's rate (its fragment
+                // reads and staging exposed), 7 000 cycles per tile; with the priorities 6 500 (tools/exp/split_times.py,
+                // profiles/r06_exp_split_times*.txt): forward product 57.2 -> 56.3 us alone, the 51 200-window step 0.8604 -> 0.8577 ms.
+                {
+                    const int level = rb * 4 / RBP, before = rb > 0 ? (rb - 1) * 4 / RBP : -1;
+                    if (level != before) {
+                        if (level == 0) __builtin_amdgcn_s_setprio(3);
+                        else if (level == 1) __builtin_amdgcn_s_setprio(2);
+                        else if (level == 2) __builtin_amdgcn_s_setprio(1);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
+                }
+#endif
                 u32x4 nh = ah, nm = am, nl = al;
                 if (rb + 1 < RBP) {
                     const unsigned char* ap = sb + (rb + 1) * 16 * kSplitPitch;
@@ -306,6 +323,21 @@ __device__ __forceinline__ void split_body(const SplitArgs& g) {
                     nl = *reinterpret_cast<const u32x4*>(ap + 2 * kPlane);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef NVSM_SPLIT_LATE_BARRIER
+                // Round 6: the tile's ONE barrier stands HERE, in front of the last row block's MFMAs, not at the end of the tile. What
+                // it has to separate is already separate at this point — this wave's staging stores of tile kt + 1 (the last rides with
+                // row block 1 + (NLD - 1) STEP <= RBP - 2) and its fragment reads of tile kt's image (the last, for this row block,
+                // were issued one row block ago; lgkmcnt(0) below) — so behind it image cur may be overwritten and image cur ^ 1 read.
+                // At the end of the tile every wave then runs straight on into the next one (planes of B taken over, first fragment
+                // reads) in the shadow of this row block's twelve MFMAs instead of all eight waves meeting with an empty matrix pipe:
+                // 6 500 -> 6 1xx cycles per tile (tools/exp/split_times.py).
+                if (rb == RBP - 1) {
+                    static_assert(1 + (NLD - 1) * STEP <= RBP - 2, "the last staging chunk must be stored before the barrier's row block");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
                 // staging of the next tile rides with the MFMAs: chunk u of tile kt + 1 is cut into the other image (its
                 // readers passed the barrier that ended the previous turn) and chunk u of tile kt + 2 requested. Behind
                 // the chunk's load sit the later chunks of its tile, the planes of B and the earlier chunks of tile kt + 2.
@@ -348,7 +380,9 @@ __device__ __forceinline__ void split_body(const SplitArgs& g) {
 #pragma unroll
             for (int c = 0; c < CBW; ++c) bf[c] = bfn[c];
             SPLIT_TICK(ps, kt, 2);
+#ifdef NVSM_SPLIT_LATE_BARRIER
             __syncthreads();
+#endif
             SPLIT_TICK(ps, kt, 3);
         }
         if (ps == 0) SPLIT_STAMP(2);

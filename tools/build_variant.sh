@@ -4,10 +4,10 @@
 set -e
 cd "$(dirname "$0")/../cunvsm_amd/csrc"
 SUF=$1; FLAGS=$2; shift 2
-FILES=${@:-gather_gemm.hip gemm_panel.hip gemm_tstat.hip gemm_rows.hip gemm_rsplit.hip gemm_split.hip gemm_dt.hip loss_bn.hip update.hip sort.hip model.cpp tuning.cpp c_api.cpp}
+FILES=${@:-gather_gemm.hip gemm_panel.hip gemm_tstat.hip gemm_rows.hip gemm_rsplit.hip gemm_split.hip gemm_dt.hip gemm_dtw.hip loss_bn.hip update.hip sort.hip model.cpp tuning.cpp c_api.cpp}
 mkdir -p build_$SUF
 OBJS=""
-for f in gather_gemm.hip gemm_panel.hip gemm_tstat.hip gemm_rows.hip gemm_rsplit.hip gemm_split.hip gemm_dt.hip loss_bn.hip update.hip sort.hip model.cpp tuning.cpp c_api.cpp; do
+for f in gather_gemm.hip gemm_panel.hip gemm_tstat.hip gemm_rows.hip gemm_rsplit.hip gemm_split.hip gemm_dt.hip gemm_dtw.hip loss_bn.hip update.hip sort.hip model.cpp tuning.cpp c_api.cpp; do
   o=${f%.*}.o
   if echo " $FILES " | grep -q " $f "; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $FLAGS -x hip -c $f -o build_$SUF/$o &

@@ -607,7 +607,7 @@ def secondary_leg(env, args, wl, method):
     leg = Leg(env, wl, method, B, uniform_words=args.uniform_words)
     leg.run_steps(max(5, args.warmup))
     med, st = ms_stats(leg.timed_repeats(args.steps, min(args.repeats, 3)), args.steps, leg)
-    ent = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), batch=B, update_method=method,
+    ent = dict(value=round(B * 1e3 / med, 1), unit="windows/s", ms_per_step=round(med, 4), batch=B, update_method=method, steps_per_region=args.steps,
                workload="|V|=%d |D|=%d d_word=%d d_doc=%d" % (wl["num_words"], wl["num_entities"], wl["word_dim"], wl["entity_dim"]), **st)
     kernel = "loss_fused"
     leg.model.profile_enable(True)
@@ -656,7 +656,12 @@ def run_secondary_leg(args, flags, pmc=False, env_extra=None):
     """A secondary leg in a fresh process, as a user would run that configuration: a second engine in a process whose first has
     lived (streams created and destroyed) is mapped onto the runtime's hardware queues differently and runs 2-10 % slower."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--secondary-leg", "--steps", str(args.steps), "--warmup", str(args.warmup),
+    # A timed region starts from an idle GPU and ends with a drained one: the fill and drain of the step's three streams (≈ 0.15 ms) are 1 % of
+    # twenty 0.88 ms steps but 3 % of twenty 0.25 ms steps. The small-batch legs are steady-state figures (a rank's step in a long
+    # run), so their regions are at least 200 steps long; the leg's line says how many.
+    small = any(f in ("lse_small",) for f in flags) or any(flags[i] == "--batch" and int(flags[i + 1]) <= 12800 for i in range(len(flags) - 1))
+    steps = max(args.steps, 200) if small else args.steps
+    cmd = [sys.executable, os.path.abspath(__file__), "--secondary-leg", "--steps", str(steps), "--warmup", str(args.warmup),
            "--repeats", str(min(args.repeats, 3))] + flags + (["--leg-pmc"] if pmc and not args.no_pmc else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env_extra or {})))
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -1008,7 +1013,7 @@ def main():
                 shapes = {}
                 for n in (8, 4, 2):
                     ent = run_secondary_leg(args, base + ["--config", "nvsm", "--batch", str(Bg // n), "--update-method", method])
-                    shapes[str(Bg // n)] = dict(ms_per_step=ent["ms_per_step"], ranks=n,
+                    shapes[str(Bg // n)] = dict(ms_per_step=ent["ms_per_step"], ranks=n, steps_per_region=ent["steps_per_region"],
                                                 **{k: ent[k] for k in ("repeats", "ms_per_step_all", "spread")})
                 extra["per_rank_shapes"] = shapes
         else:

@@ -147,3 +147,8 @@ def test_bench_two_ranks_control_flow():
     assert abs(d["value"] - 51200 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
     assert d["strong"]["value"] == d["value"] and d["weak"]["global_batch"] == 2 * 51200 and d["weak"]["batch_per_rank"] == 51200
     assert d["final_cost"] == d["final_cost"] and d["final_cost"] > 0          # finite global loss
+    # the N-rank line carries: the transport and the communicator's rank count, both scaling figures, and the per-shard batch-norm
+    # variant (ONE collective per step) beside the synchronised one (three)
+    assert "comm_ranks" in d["config"] and "gloo" in d["config"]["collectives"] and d["config"]["collectives_per_step"] == 3
+    ps = d["per_shard_batch_norm"]
+    assert ps["collectives_per_step"] == 1 and ps["batch_per_rank"] == 25600 and ps["value"] > 0 and ps["scaling"] == "strong"

@@ -210,7 +210,7 @@ def pmc_prefix(kernel, walk=None):
     return PMC_KERNEL.get(kernel)
 
 
-def pmc_in_run(flags, timeout=300):
+def pmc_in_run(flags, timeout=120):
     """HBM counter bytes measured IN THIS RUN: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (a pass each, with --kernel-trace
     only, as MI355X_MICROARCH.md prescribes) of this very script in its bare form (8 steps of the same workload on this box, no
     events, no extra legs). Returns {"kernels": per-launch table, "step_bytes", "steps", "source", "in_run": True} or None (no
@@ -232,6 +232,8 @@ def pmc_in_run(flags, timeout=300):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "6", "--warmup", "2", "--repeats", "1", "--no-extra-legs", "--no-cpu-baseline", "--no-profile"] + flags
+            # (a counter pass of the bare bench takes 8-20 s; one that has not finished in two minutes is given up — subprocess.run kills it —
+            #  and the line falls back to the committed summaries: the bench must never hang on its own instrumentation)
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
             found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not found:
